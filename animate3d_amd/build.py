@@ -1,0 +1,77 @@
+"""Build libanimate3d_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake.
+
+    python -m animate3d_amd.build            # incremental
+    python -m animate3d_amd.build --force
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libanimate3d_hip.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path: str) -> str:
+    h = hashlib.sha256()
+    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "animate3d_hip.h")]:
+        with open(dep, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for src in sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        stamp = obj + ".sha"
+        dig = _digest(src)
+        objs.append(obj)
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig)
+        if not fresh:
+            jobs.append((src, obj, stamp, dig))
+
+    def compile_one(job):
+        src, obj, stamp, dig = job
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print("[a3d build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(stamp, "w") as f:
+            f.write(dig)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(compile_one, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print("[a3d build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,50 @@
+// Shared device helpers for the gfx950 kernels of libanimate3d_hip.so.
+// Wave = 64 lanes; MFMA shape used throughout: v_mfma_f32_32x32x16_bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/animate3d_hip.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+#define A3D_DEV static __device__ __forceinline__
+
+// bf16 <-> f32 (round-to-nearest-even on the way down, as torch does)
+A3D_DEV float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two values per instruction
+A3D_DEV uint32_t pack2bf(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+A3D_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
+A3D_DEV float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+A3D_DEV float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// MFMA 32x32x16 bf16.  Lane l supplies A[i = l&31][k-slots of group l>>5] and
+// B[k-slots of group l>>5][j = l&31] (8 bf16 each); the result register r of lane l is
+// D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+A3D_DEV f32x16_t mfma32(const u32x4_t& a, const u32x4_t& b, const f32x16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// row index inside a 32x32 MFMA result for register r of a lane in half g = lane>>5
+A3D_DEV int mfma_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+// bijective XCD-aware remap of a 1-D grid: block b runs on XCD b % 8; give every XCD a
+// contiguous range of logical ids so neighbouring tiles share that XCD's L2.
+A3D_DEV int64_t xcd_remap(int64_t bid, int64_t nblk) {
+  const int64_t q = nblk / 8, r = nblk % 8;
+  const int64_t xcd = bid % 8, idx = bid / 8;
+  const int64_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int a3d_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? A3D_OK : (int)e;
+}

@@ -1,0 +1,253 @@
+// GEMM and implicit-GEMM 3x3 convolution for gfx950 (bf16 in, fp32 accumulate, bf16 out).
+//
+//   Y[M,N] = alpha * (A[M,K] · W[N,K]^T + bias[N] + rowbias[m / rb_div][N]) + beta * R[M,N]
+//
+// A is either a dense row-major matrix (Linear / 1x1 conv) or the virtual im2col matrix of an
+// NHWC image batch (3x3 conv, pad 1, stride 1|2, optional nearest-2x upsample folded into the
+// addressing).  One 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each wave
+// owns 64x64 = 2x2 MFMA 32x32x16 tiles.  K advances in steps of 64 through a double-buffered,
+// padded LDS image (row stride 144 B = 9 x 16-B slots, odd => conflict-free ds_read_b128);
+// the next K-tile is fetched global->registers while the current one feeds the MFMAs, one
+// barrier per K-step.  The MFMA is issued as D^T = W · A^T so that every lane ends up with 4
+// consecutive output columns per register quad (8-byte stores, bias/residual as 8-byte loads).
+// The 1-D grid is remapped so that each XCD walks a contiguous range of tiles (tiles that
+// share the same A rows are neighbours => A is fetched from HBM once per XCD, W stays in L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LROW = BK + 8;                 // LDS row stride in elements (144 B)
+constexpr int TILE_ELEMS = 128 * LROW;       // one operand tile
+constexpr int SMEM_BYTES = 2 * 2 * TILE_ELEMS * 2;   // [buf][A|W]
+
+struct GemmParams {
+  const uint16_t* X; int64_t ldx;
+  const uint16_t* W; int64_t ldw;
+  const float* bias;
+  const uint16_t* rowbias; int64_t rb_div;
+  const uint16_t* R; int64_t ldr;
+  uint16_t* Y; int64_t ldy;
+  int64_t M, N, K;
+  float alpha, beta;
+  // conv geometry (CONV only)
+  int B, H, Wd, Cin, Ho, Wo, stride, up;
+  int64_t tiles_n, tiles_m;
+};
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  const int64_t nblk = p.tiles_n * p.tiles_m;
+  const int64_t lid = xcd_remap(blockIdx.x, nblk);
+  const int64_t tile_n = lid % p.tiles_n, tile_m = lid / p.tiles_n;
+  const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging assignment: thread owns 16-byte chunk column kc of rows srow + 32*i
+  const int kc = tid & 7;
+  const int srow = tid >> 3;
+
+  // per-row source bookkeeping for A
+  const uint16_t* a_ptr[4];   // dense: row pointer (+kc*8); conv: unused
+  int a_b[4], a_y[4], a_x[4]; // conv: output pixel coordinates
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t m = m0 + srow + 32 * i;
+    a_ok[i] = m < p.M;
+    if (m >= p.M) m = p.M - 1;
+    if constexpr (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int b = (int)(m / hw);
+      const int rem = (int)(m - (int64_t)b * hw);
+      a_b[i] = b; a_y[i] = rem / p.Wo; a_x[i] = rem - a_y[i] * p.Wo;
+      a_ptr[i] = nullptr;
+    } else {
+      a_ptr[i] = p.X + m * p.ldx + kc * 8;
+      a_b[i] = a_y[i] = a_x[i] = 0;
+    }
+  }
+  const uint16_t* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t n = n0 + srow + 32 * i;
+    if (n >= p.N) n = p.N - 1;
+    w_ptr[i] = p.W + n * p.ldw + kc * 8;
+  }
+
+  u32x4_t ra[4], rw[4];
+  auto load_tile = [&](int64_t k0) {
+    if constexpr (CONV) {
+      const int tap = (int)(k0 / p.Cin);
+      const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int He = p.up ? 2 * p.H : p.H, We = p.up ? 2 * p.Wd : p.Wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int yy = a_y[i] * p.stride + ky - 1;
+        const int xx = a_x[i] * p.stride + kx - 1;
+        const bool ok = a_ok[i] && yy >= 0 && yy < He && xx >= 0 && xx < We;
+        const int sy = p.up ? (yy >> 1) : yy, sx = p.up ? (xx >> 1) : xx;
+        if (ok) {
+          const uint16_t* src = p.X + (((int64_t)a_b[i] * p.H + sy) * p.Wd + sx) * p.Cin + ci0 + kc * 8;
+          ra[i] = *reinterpret_cast<const u32x4_t*>(src);
+        } else {
+          ra[i] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + k0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(w_ptr[i] + k0);
+  };
+  auto store_tile = [&](int buf) {
+    uint16_t* As = smem + (buf * 2 + 0) * TILE_ELEMS;
+    uint16_t* Ws = smem + (buf * 2 + 1) * TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4_t*>(As + (srow + 32 * i) * LROW + kc * 8) = ra[i];
+      *reinterpret_cast<u32x4_t*>(Ws + (srow + 32 * i) * LROW + kc * 8) = rw[i];
+    }
+  };
+
+  f32x16_t acc[2][2];   // [tn][tm]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int64_t nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    const bool more = kt + 1 < nk;
+    if (more) load_tile((kt + 1) * BK);
+    const uint16_t* As = smem + (cur * 2 + 0) * TILE_ELEMS;
+    const uint16_t* Ws = smem + (cur * 2 + 1) * TILE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      u32x4_t fw[2], fa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fw[t] = *reinterpret_cast<const u32x4_t*>(Ws + (wn * 64 + t * 32 + l31) * LROW + ks * 16 + g * 8);
+        fa[t] = *reinterpret_cast<const u32x4_t*>(As + (wm * 64 + t * 32 + l31) * LROW + ks * 16 + g * 8);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[tn], fa[tm], acc[tn][tm]);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per (tn, tm, quad q), 4 consecutive n for one m
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int64_t m = m0 + wm * 64 + tm * 32 + l31;
+    if (m >= p.M) continue;
+    const uint16_t* rb = p.rowbias ? p.rowbias + (m / p.rb_div) * p.N : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t n = n0 + wn * 64 + tn * 32 + 8 * q + 4 * g;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * q + j];
+        if (p.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (rb) {
+          const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(rb + n);
+          v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+        if (p.R) {
+          const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(p.R + m * p.ldr + n);
+          v[0] += p.beta * lo_bf(rv[0]); v[1] += p.beta * hi_bf(rv[0]);
+          v[2] += p.beta * lo_bf(rv[1]); v[3] += p.beta * hi_bf(rv[1]);
+        }
+        u32x2_t o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *reinterpret_cast<u32x2_t*>(p.Y + m * p.ldy + n) = o;
+      }
+    }
+  }
+}
+
+template <bool CONV>
+int launch(hipStream_t stream, GemmParams& p) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int64_t nblk = p.tiles_m * p.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_kernel<CONV>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, stream, p);
+  return a3d_launch_status();
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                             const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                             void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta) {
+  if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
+  if (K % BK != 0 || N % 4 != 0) return A3D_EINVAL;
+  if (ldx % 8 != 0 || ldw % 8 != 0 || ldy % 4 != 0 || (R && ldr % 4 != 0)) return A3D_EINVAL;
+  if (!aligned16(X) || !aligned16(W) || (reinterpret_cast<uintptr_t>(Y) & 7u) || (R && (reinterpret_cast<uintptr_t>(R) & 7u)))
+    return A3D_EINVAL;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)) return A3D_EINVAL;
+  if (rowbias && (rb_div <= 0 || (reinterpret_cast<uintptr_t>(rowbias) & 7u))) return A3D_EINVAL;
+  GemmParams p{};
+  p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
+  p.bias = bias; p.rowbias = (const uint16_t*)rowbias; p.rb_div = rowbias ? rb_div : 1;
+  p.R = (const uint16_t*)R; p.ldr = ldr; p.Y = (uint16_t*)Y; p.ldy = ldy;
+  p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
+  return launch<false>((hipStream_t)stream, p);
+}
+
+extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                                const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                                int B, int H, int W, int Cin, int Cout, int stride, int up2x) {
+  if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
+  if (Cin % BK != 0 || Cout % 4 != 0 || (stride != 1 && stride != 2)) return A3D_EINVAL;
+  if (up2x && stride != 1) return A3D_EINVAL;
+  if (!aligned16(X) || !aligned16(Wp) || (reinterpret_cast<uintptr_t>(Y) & 7u)) return A3D_EINVAL;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)) return A3D_EINVAL;
+  if (rowbias && rb_div <= 0) return A3D_EINVAL;
+  const int He = up2x ? 2 * H : H, We = up2x ? 2 * W : W;
+  GemmParams p{};
+  p.X = (const uint16_t*)X; p.ldx = Cin; p.W = (const uint16_t*)Wp; p.ldw = (int64_t)9 * Cin;
+  p.bias = bias; p.rowbias = (const uint16_t*)rowbias; p.rb_div = rowbias ? rb_div : 1;
+  p.R = (const uint16_t*)R; p.ldr = Cout; p.Y = (uint16_t*)Y; p.ldy = Cout;
+  p.B = B; p.H = H; p.Wd = W; p.Cin = Cin; p.stride = stride; p.up = up2x ? 1 : 0;
+  p.Ho = (He + 2 - 3) / stride + 1; p.Wo = (We + 2 - 3) / stride + 1;
+  p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
+  p.alpha = 1.f; p.beta = 1.f;
+  return launch<true>((hipStream_t)stream, p);
+}

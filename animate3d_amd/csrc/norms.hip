@@ -1,0 +1,225 @@
+// GroupNorm (+SiLU) and LayerNorm (+positional-embedding adds) for NHWC rows, gfx950.
+// Both are HBM-bound: 16-byte accesses, one read pass for statistics + one read/write pass.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_ROWS_PER_BLOCK = 128;   // rows of one instance handled by one workgroup
+
+// threads: x = 16-byte channel chunk (C/8 of them), y = row lane
+struct GNParams {
+  const uint16_t* X; uint16_t* Y; const float* gamma; const float* beta;
+  float* partial;   // [B][nchunk][groups][2]
+  float* stats;     // [B][groups][2]  (mean, rstd)
+  int B; int64_t rows; int C; int groups; int cg; int nchunk; float eps; int silu;
+};
+
+__global__ void gn_partial_kernel(const GNParams p) {
+  extern __shared__ float sred[];            // [groups][2]
+  const int c8 = threadIdx.x, ry = threadIdx.y, ny = blockDim.y;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < p.groups * 2; i += blockDim.x * blockDim.y) sred[i] = 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)chunk * GN_ROWS_PER_BLOCK;
+  const int64_t r1 = (r0 + GN_ROWS_PER_BLOCK < p.rows) ? r0 + GN_ROWS_PER_BLOCK : p.rows;
+  const int ch0 = c8 * 8;
+  const int g_lo = ch0 / p.cg, g_hi = (ch0 + 7) / p.cg;     // a chunk touches at most 2 groups (cg >= 8)
+  const int split = (g_lo + 1) * p.cg - ch0;                // first `split` channels belong to g_lo
+  float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
+  const uint16_t* base = p.X + ((int64_t)b * p.rows) * p.C + ch0;
+  for (int64_t r = r0 + ry; r < r1; r += ny) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + r * p.C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1]);
+      if (j < split) { s_lo += f; q_lo += f * f; } else { s_hi += f; q_hi += f * f; }
+    }
+  }
+  atomicAdd(&sred[g_lo * 2 + 0], s_lo);
+  atomicAdd(&sred[g_lo * 2 + 1], q_lo);
+  if (g_hi != g_lo) {
+    atomicAdd(&sred[g_hi * 2 + 0], s_hi);
+    atomicAdd(&sred[g_hi * 2 + 1], q_hi);
+  }
+  __syncthreads();
+  float* out = p.partial + ((int64_t)b * p.nchunk + chunk) * p.groups * 2;
+  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < p.groups * 2; i += blockDim.x * blockDim.y) out[i] = sred[i];
+}
+
+__global__ void gn_finalize_kernel(const GNParams p) {
+  // one block per instance b, one thread per group
+  const int b = blockIdx.x, grp = threadIdx.x;
+  if (grp >= p.groups) return;
+  double s = 0.0, q = 0.0;
+  const float* in = p.partial + (int64_t)b * p.nchunk * p.groups * 2 + grp * 2;
+  for (int c = 0; c < p.nchunk; ++c) { s += in[(int64_t)c * p.groups * 2]; q += in[(int64_t)c * p.groups * 2 + 1]; }
+  const double n = (double)p.rows * p.cg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  p.stats[((int64_t)b * p.groups + grp) * 2 + 0] = (float)mean;
+  p.stats[((int64_t)b * p.groups + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+}
+
+__global__ void gn_apply_kernel(const GNParams p) {
+  const int c8 = threadIdx.x, ry = threadIdx.y, ny = blockDim.y;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int64_t r0 = (int64_t)chunk * GN_ROWS_PER_BLOCK;
+  const int64_t r1 = (r0 + GN_ROWS_PER_BLOCK < p.rows) ? r0 + GN_ROWS_PER_BLOCK : p.rows;
+  const int ch0 = c8 * 8;
+  float sc[8], sh[8];       // y = x * sc + sh
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = ch0 + j, grp = ch / p.cg;
+    const float mean = p.stats[((int64_t)b * p.groups + grp) * 2], rstd = p.stats[((int64_t)b * p.groups + grp) * 2 + 1];
+    const float ga = p.gamma[ch], be = p.beta[ch];
+    sc[j] = rstd * ga;
+    sh[j] = be - mean * rstd * ga;
+  }
+  const int64_t off = ((int64_t)b * p.rows) * p.C + ch0;
+  for (int64_t r = r0 + ry; r < r1; r += ny) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p.X + off + r * p.C);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = ((j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1])) * sc[j] + sh[j];
+      if (p.silu) f[j] = f[j] / (1.f + __expf(-f[j]));
+    }
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+    *reinterpret_cast<u32x4_t*>(p.Y + off + r * p.C) = o;
+  }
+}
+
+// ---------------- LayerNorm: one wave per row, up to 3 16-byte chunks per lane (C <= 1536)
+struct LNParams {
+  const uint16_t* X; uint16_t* Y1; uint16_t* Y2; const float* gamma; const float* beta;
+  int64_t M; int C; float eps;
+  const uint16_t* pe1; int64_t pe1_div, pe1_mod;
+  const uint16_t* pe2; int64_t pe2_div, pe2_mod;
+};
+
+__global__ __launch_bounds__(256) void layer_norm_kernel(const LNParams p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wid;
+  if (m >= p.M) return;
+  const int nch = p.C / 8;
+  float f[3][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p.X + m * p.C + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { f[i][j] = (j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1]); sum += f[i][j]; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)p.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; sq += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)p.C + p.eps);
+  const uint16_t* e1 = p.pe1 ? p.pe1 + ((m / p.pe1_div) % p.pe1_mod) * p.C : nullptr;
+  const uint16_t* e2 = (p.Y2 && p.pe2) ? p.pe2 + ((m / p.pe2_div) % p.pe2_mod) * p.C : nullptr;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float y[8];
+      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c * 8), g1 = *reinterpret_cast<const float4*>(p.gamma + c * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.beta + c * 8), b1 = *reinterpret_cast<const float4*>(p.beta + c * 8 + 4);
+      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (f[i][j] - mean) * rstd * ga[j] + be[j];
+      {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = y[j];
+        if (e1) {
+          const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e1 + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        *reinterpret_cast<u32x4_t*>(p.Y1 + m * p.C + c * 8) = o;
+      }
+      if (p.Y2) {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = y[j];
+        if (e2) {
+          const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e2 + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        *reinterpret_cast<u32x4_t*>(p.Y2 + m * p.C + c * 8) = o;
+      }
+    }
+  }
+}
+
+inline int gn_nchunk(int64_t rows) { return (int)((rows + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK); }
+
+}  // namespace
+
+extern "C" int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups) {
+  return (int64_t)B * gn_nchunk(rows) * groups * 2 + (int64_t)B * groups * 2;
+}
+
+extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                                   float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
+  if (!X || !Y || !gamma || !beta || !ws || B <= 0 || rows <= 0 || C <= 0 || groups <= 0) return A3D_EINVAL;
+  if (C % 8 != 0 || C % groups != 0 || C / groups < 8 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
+  if (B > 65535) return A3D_EINVAL;
+  GNParams p{};
+  p.X = (const uint16_t*)X; p.Y = (uint16_t*)Y; p.gamma = gamma; p.beta = beta;
+  p.B = B; p.rows = rows; p.C = C; p.groups = groups; p.cg = C / groups; p.nchunk = gn_nchunk(rows);
+  p.eps = eps; p.silu = silu;
+  p.partial = ws; p.stats = ws + (int64_t)B * p.nchunk * groups * 2;
+  const int c8 = C / 8;
+  int ny = 256 / c8; if (ny < 1) ny = 1; if (ny > 32) ny = 32;
+  const dim3 block(c8, ny), grid(p.nchunk, B);
+  hipStream_t s = (hipStream_t)stream;
+  gn_partial_kernel<<<grid, block, groups * 2 * sizeof(float), s>>>(p);
+  gn_finalize_kernel<<<dim3(B), dim3((groups + 63) / 64 * 64), 0, s>>>(p);
+  gn_apply_kernel<<<grid, block, 0, s>>>(p);
+  return a3d_launch_status();
+}
+
+extern "C" int a3d_layer_norm_bf16(a3d_stream_t stream, const void* X, void* Y1, void* Y2, const float* gamma,
+                                   const float* beta, int64_t M, int C, float eps,
+                                   const void* pe1, int64_t pe1_div, int64_t pe1_mod,
+                                   const void* pe2, int64_t pe2_div, int64_t pe2_mod) {
+  if (!X || !Y1 || !gamma || !beta || M <= 0 || C <= 0 || C % 8 != 0 || C > 1536) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(Y2)) & 15u) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15u) return A3D_EINVAL;
+  if ((pe1 && (pe1_div <= 0 || pe1_mod <= 0)) || (pe2 && (pe2_div <= 0 || pe2_mod <= 0))) return A3D_EINVAL;
+  LNParams p{};
+  p.X = (const uint16_t*)X; p.Y1 = (uint16_t*)Y1; p.Y2 = (uint16_t*)Y2; p.gamma = gamma; p.beta = beta;
+  p.M = M; p.C = C; p.eps = eps;
+  p.pe1 = (const uint16_t*)pe1; p.pe1_div = pe1 ? pe1_div : 1; p.pe1_mod = pe1 ? pe1_mod : 1;
+  p.pe2 = (const uint16_t*)pe2; p.pe2_div = pe2 ? pe2_div : 1; p.pe2_mod = pe2 ? pe2_mod : 1;
+  const int64_t nblk = (M + 3) / 4;
+  if (nblk > 0x7fffffffLL) return A3D_EINVAL;
+  layer_norm_kernel<<<dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream>>>(p);
+  return a3d_launch_status();
+}

@@ -1,0 +1,264 @@
+"""ctypes binding of libanimate3d_hip.so (C-ABI in include/animate3d_hip.h) + the op set the
+UNet host code is written against.
+
+torch is used here only for device memory (``torch.empty``), the current HIP stream handle and
+pointer extraction; every arithmetic op goes through the C-ABI.  There is NO fallback: if the
+library is missing, fails to load, or a tensor is not a bf16 CUDA tensor, these calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanimate3d_hip.so")
+_lib = None
+
+c_i64, c_int, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+class _RowMapC(ctypes.Structure):
+    _fields_ = [("gdiv", c_i64), ("ga", c_i64), ("gb", c_i64), ("seg_len", c_i64), ("seg_stride", c_i64), ("ld", c_i64)]
+
+
+@dataclass(frozen=True)
+class RowMap:
+    """row(g, s) = (g // gdiv) * ga + (g % gdiv) * gb + (s // seg_len) * seg_stride + s % seg_len
+    (include/animate3d_hip.h: a3d_rowmap).  ``ld`` comes from the tensor it is applied to."""
+    gdiv: int
+    ga: int
+    gb: int
+    seg_len: int
+    seg_stride: int
+
+    def c(self, ld: int) -> _RowMapC:
+        return _RowMapC(self.gdiv, self.ga, self.gb, self.seg_len, self.seg_stride, ld)
+
+
+# symbol -> (restype, argtypes); mirrors include/animate3d_hip.h line by line
+_SIGNATURES = {
+    "a3d_version": (ctypes.c_char_p, []),
+    "a3d_gemm_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32]),
+    "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
+                                    c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
+    "a3d_temporal_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
+    "a3d_group_norm_ws_floats": (c_i64, [c_int, c_i64, c_int]),
+    "a3d_group_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_f32, c_int]),
+    "a3d_layer_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64]),
+    "a3d_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
+    "a3d_silu_bf16": (c_int, [c_vp, c_vp, c_vp, c_i64]),
+    "a3d_concat_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]),
+    "a3d_timestep_embed_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int]),
+    "a3d_im2col_in": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_unpack_out": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_cfg_ddim_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_f32, c_f32, c_f32]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree library and type every entry point.  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run `python -m animate3d_amd.build` (or __graft_entry__.build()). "
+                               "There is no CPU fallback for the MI355X kernels.")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "A3D_EINVAL (shape/alignment precondition)", -2: "A3D_EUNSUPPORTED"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {kind}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipOps:
+    """The op set of the denoise step, executed by the gfx950 kernels.  All activations are 2-D
+    ``[rows, C]`` bf16 CUDA tensors (NHWC images flattened to rows)."""
+
+    act_dtype = torch.bfloat16
+
+    def __init__(self, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs a visible MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
+        self.lib = load_library()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    # ---- helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _act(self, t: torch.Tensor, name: str):
+        if t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"{name}: expected a 2-D bf16 CUDA tensor with contiguous rows, got {t.dtype} {tuple(t.shape)} {t.device} strides {t.stride()}")
+        return t
+
+    def empty(self, rows: int, cols: int) -> torch.Tensor:
+        return torch.empty((rows, cols), dtype=torch.bfloat16, device=self.device)
+
+    # ---- GEMM family
+    def gemm(self, x, w, bias=None, *, residual=None, alpha: float = 1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None):
+        x, w = self._act(x, "gemm.x"), self._act(w, "gemm.w")
+        M, K = x.shape
+        N = w.shape[0]
+        assert w.shape[1] == K, (x.shape, w.shape)
+        y = out if out is not None else self.empty(M, N)
+        self._act(y, "gemm.out")
+        if residual is not None:
+            self._act(residual, "gemm.residual")
+            assert residual.shape == (M, N)
+        if rowbias is not None:
+            self._act(rowbias, "gemm.rowbias")
+            assert rowbias.is_contiguous() and rowbias.shape[1] == N
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.numel() == N
+        rc = self.lib.a3d_gemm_bf16(self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(rowbias), rb_div,
+                                    _p(residual), residual.stride(0) if residual is not None else 0, _p(y), y.stride(0),
+                                    M, N, K, alpha, beta)
+        _check(rc, f"a3d_gemm_bf16 M={M} N={N} K={K}")
+        return y
+
+    def conv3x3(self, x, B: int, H: int, W: int, w, bias, *, stride: int = 1, up2x: bool = False, rowbias=None, rb_div: int = 1, residual=None):
+        """x [B*H*W, Cin] -> (y [B*Ho*Wo, Cout], Ho, Wo); w packed [Cout, 9*Cin] (ky, kx, ci)."""
+        x, w = self._act(x, "conv.x"), self._act(w, "conv.w")
+        Cin = x.shape[1]
+        Cout = w.shape[0]
+        assert x.is_contiguous() and w.is_contiguous() and x.shape[0] == B * H * W and w.shape[1] == 9 * Cin
+        He, We = (2 * H, 2 * W) if up2x else (H, W)
+        Ho, Wo = (He - 1) // stride + 1, (We - 1) // stride + 1
+        y = self.empty(B * Ho * Wo, Cout)
+        if residual is not None:
+            assert residual.is_contiguous() and residual.shape == y.shape
+        if rowbias is not None:
+            assert rowbias.is_contiguous() and rowbias.shape[1] == Cout
+        rc = self.lib.a3d_conv3x3_bf16(self._stream(), _p(x), _p(w), _p(bias), _p(rowbias), rb_div, _p(residual), _p(y),
+                                       B, H, W, Cin, Cout, stride, 1 if up2x else 0)
+        _check(rc, f"a3d_conv3x3_bf16 B={B} H={H} W={W} Cin={Cin} Cout={Cout} stride={stride} up={up2x}")
+        return y, Ho, Wo
+
+    # ---- attention
+    def flash_attn(self, q, k, v, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
+                   out=None, out_scale: float = 1.0, accumulate: bool = False):
+        q, k, v = self._act(q, "attn.q"), self._act(k, "attn.k"), self._act(v, "attn.v")
+        C = q.shape[1]
+        D = C // heads
+        assert k.stride(0) == v.stride(0)
+        o = out if out is not None else self.empty(q.shape[0], C)
+        qm, km, om = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(o.stride(0))
+        rc = self.lib.a3d_flash_attn_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
+                                          groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, 1 if accumulate else 0)
+        _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
+        return o
+
+    def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int):
+        q, k, v = self._act(q, "tattn.q"), self._act(k, "tattn.k"), self._act(v, "tattn.v")
+        C = q.shape[1]
+        D = C // heads
+        assert q.stride(0) == k.stride(0) == v.stride(0)
+        o = self.empty(q.shape[0], C)
+        rc = self.lib.a3d_temporal_attn_bf16(self._stream(), _p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0),
+                                             videos, frames, L, heads, D, float(D) ** -0.5)
+        _check(rc, f"a3d_temporal_attn_bf16 videos={videos} frames={frames} L={L} D={D}")
+        return o
+
+    # ---- normalisation
+    def group_norm(self, x, B: int, rows: int, gamma, beta, groups: int, eps: float, silu: bool):
+        x = self._act(x, "gn.x")
+        assert x.is_contiguous() and x.shape[0] == B * rows
+        C = x.shape[1]
+        y = self.empty(x.shape[0], C)
+        ws = torch.empty(int(self.lib.a3d_group_norm_ws_floats(B, rows, groups)), dtype=torch.float32, device=self.device)
+        rc = self.lib.a3d_group_norm_bf16(self._stream(), _p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, rows, C, groups, eps, 1 if silu else 0)
+        _check(rc, f"a3d_group_norm_bf16 B={B} rows={rows} C={C}")
+        return y
+
+    def layer_norm(self, x, gamma, beta, eps: float, pe1=None, pe1_div: int = 1, pe2=None, pe2_div: int = 1, two: bool = False):
+        """y1 = LN(x) + pe1[(m // pe1_div) % len(pe1)]; with two=True also y2 with pe2."""
+        x = self._act(x, "ln.x")
+        assert x.is_contiguous()
+        M, C = x.shape
+        y1 = self.empty(M, C)
+        y2 = self.empty(M, C) if two else None
+        for pe in (pe1, pe2):
+            if pe is not None:
+                self._act(pe, "ln.pe")
+                assert pe.is_contiguous() and pe.shape[1] == C
+        rc = self.lib.a3d_layer_norm_bf16(self._stream(), _p(x), _p(y1), _p(y2), _p(gamma), _p(beta), M, C, eps,
+                                          _p(pe1), pe1_div, pe1.shape[0] if pe1 is not None else 1,
+                                          _p(pe2), pe2_div, pe2.shape[0] if pe2 is not None else 1)
+        _check(rc, f"a3d_layer_norm_bf16 M={M} C={C}")
+        return (y1, y2) if two else y1
+
+    # ---- elementwise / layout
+    def geglu(self, x):
+        x = self._act(x, "geglu.x")
+        M, N2 = x.shape
+        y = self.empty(M, N2 // 2)
+        _check(self.lib.a3d_geglu_bf16(self._stream(), _p(x), x.stride(0), _p(y), y.stride(0), M, N2 // 2), "a3d_geglu_bf16")
+        return y
+
+    def silu(self, x):
+        x = self._act(x, "silu.x")
+        assert x.is_contiguous()
+        y = torch.empty_like(x)
+        _check(self.lib.a3d_silu_bf16(self._stream(), _p(x), _p(y), x.numel()), "a3d_silu_bf16")
+        return y
+
+    def concat(self, a, b):
+        a, b = self._act(a, "concat.a"), self._act(b, "concat.b")
+        assert a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
+        y = self.empty(a.shape[0], a.shape[1] + b.shape[1])
+        _check(self.lib.a3d_concat_bf16(self._stream(), _p(a), a.shape[1], _p(b), b.shape[1], _p(y), a.shape[0]), "a3d_concat_bf16")
+        return y
+
+    def timestep_embed(self, t: torch.Tensor, dim: int):
+        assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 1
+        y = self.empty(t.shape[0], dim)
+        _check(self.lib.a3d_timestep_embed_bf16(self._stream(), _p(t), _p(y), t.shape[0], dim), "a3d_timestep_embed_bf16")
+        return y
+
+    def im2col_in(self, sample: torch.Tensor):
+        """[V, C, F, H, W] (fp32/bf16/fp16) -> [(V F) H W, 64] bf16 3x3 patches."""
+        assert sample.is_cuda and sample.dim() == 5 and sample.dtype in _DTYPE_CODE
+        sample = sample.contiguous()
+        V, C, F, H, W = sample.shape
+        y = self.empty(V * F * H * W, 64)
+        _check(self.lib.a3d_im2col_in(self._stream(), _p(sample), _DTYPE_CODE[sample.dtype], _p(y), V, C, F, H, W), "a3d_im2col_in")
+        return y
+
+    def unpack_out(self, x, V: int, C: int, F: int, H: int, W: int, dtype: torch.dtype):
+        x = self._act(x, "unpack.x")
+        assert x.is_contiguous() and x.shape == (V * F * H * W, C)
+        y = torch.empty((V, C, F, H, W), dtype=dtype, device=self.device)
+        _check(self.lib.a3d_unpack_out(self._stream(), _p(x), _p(y), _DTYPE_CODE[dtype], V, C, F, H, W), "a3d_unpack_out")
+        return y
+
+    def cfg_ddim_step(self, eps_pair, x, first_frame, guidance: float, alpha_t: float, alpha_prev: float):
+        """Fused pipeline epilogue (pipeline.py:1023-1031); fp32 [n, C, F, H, W] tensors."""
+        for t in (eps_pair, x, first_frame):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        n, C, F, H, W = x.shape
+        assert eps_pair.shape == (2 * n, C, F, H, W) and first_frame.numel() == n * C * H * W
+        y = torch.empty_like(x)
+        _check(self.lib.a3d_cfg_ddim_step_f32(self._stream(), _p(eps_pair), _p(x), _p(first_frame), _p(y), n, C, F, H * W,
+                                              guidance, alpha_t, alpha_prev), "a3d_cfg_ddim_step_f32")
+        return y

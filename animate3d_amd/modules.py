@@ -1,0 +1,220 @@
+"""Parameter tree of the MV-VDM UNet under the reference's (diffusers 0.28) state-dict names.
+
+These classes only HOLD parameters — none of them has a forward.  The arithmetic is issued by
+``animate3d_amd.unet`` through the HIP op set; the tree exists so that
+``load_state_dict(reference_checkpoint)`` / ``state_dict()`` / ``attn_processors`` /
+``set_attn_processor`` behave like the reference model's
+(animatediff/models/unet_motion_mv_model.py:439-497, inference.py:90-223; key families listed
+in SURVEY.md Appendix A.8).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .config import UNetConfig
+from .embeddings import sinusoidal_pos_1d
+
+
+class Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: the forward pass is issued by animate3d_amd.unet.MVUNetMotionModel")
+
+
+def _lin(i, o, bias=True):
+    return nn.Linear(i, o, bias=bias)
+
+
+# ---------------- attention processors (reference: animatediff/models/attention_processor.py)
+class MVDreamAttnProcessor(Holder):
+    """Multi-view self-attention without the I2V branch (reference class
+    MVDreamXFormersAttnProcessor, attention_processor.py:22-126).  No parameters."""
+    kind = "mvdream"
+
+
+class MVDreamI2VAttnProcessor(Holder):
+    """Multi-view self-attention + first-frame (I2V) attention (reference class
+    MVDreamI2VXFormersAttnProcessor, attention_processor.py:302-445)."""
+    kind = "mvdream_i2v"
+
+    def __init__(self, hidden_size: int):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.to_q_i2v = _lin(hidden_size, hidden_size, bias=False)
+        self.to_out_i2v = _lin(hidden_size, hidden_size, bias=True)
+
+
+class IPAdapterAttnProcessor(Holder):
+    """Text + IP-Adapter image cross-attention (reference class IPAdapterXFormersAttnProcessor,
+    attention_processor.py:129-298)."""
+    kind = "ip_adapter"
+
+    def __init__(self, hidden_size: int, cross_attention_dim: int, num_tokens=(4,), scale: float = 1.0):
+        super().__init__()
+        self.hidden_size, self.cross_attention_dim = hidden_size, cross_attention_dim
+        self.num_tokens = list(num_tokens)
+        self.scale = [scale] * len(self.num_tokens)
+        self.to_k_ip = nn.ModuleList([_lin(cross_attention_dim, hidden_size, bias=False) for _ in self.num_tokens])
+        self.to_v_ip = nn.ModuleList([_lin(cross_attention_dim, hidden_size, bias=False) for _ in self.num_tokens])
+
+
+class _PE(Holder):
+    def __init__(self, dim, max_len):
+        super().__init__()
+        self.register_buffer("pe", sinusoidal_pos_1d(dim, max_len))
+
+
+class _AlphaBlender(Holder):
+    def __init__(self):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.zeros(1))
+
+
+class SpatioTemporalI2VAttnProcessor(Holder):
+    """Motion-module processor: temporal attention + multi-view spatial attention, blended
+    (reference class SpatioTemporalI2VXFormersAttnProcessor, attention_processor.py:448-723;
+    released switch set: spatial attn on, sinusoid 2-D PE, camera encoding off, image attn off)."""
+    kind = "spatio_temporal"
+
+    def __init__(self, hidden_size: int, spatial_attn: bool = True, use_spatial_encoding: bool = True,
+                 use_alpha_blender: bool = True, max_seq_length: int = 32):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.use_spatial_attn, self.use_spatial_encoding, self.use_alpha_blender = spatial_attn, use_spatial_encoding, use_alpha_blender
+        if spatial_attn:
+            self.to_q_sp = _lin(hidden_size, hidden_size, bias=False)
+            self.to_k_sp = _lin(hidden_size, hidden_size, bias=False)
+            self.to_v_sp = _lin(hidden_size, hidden_size, bias=False)
+            self.to_out_sp = _lin(hidden_size, hidden_size, bias=True)
+            if use_spatial_encoding:
+                self.time_pos_embed = _PE(hidden_size, max_seq_length)
+            if use_alpha_blender:
+                self.alpha_blender = _AlphaBlender()
+            else:
+                nn.init.zeros_(self.to_out_sp.weight)
+                nn.init.zeros_(self.to_out_sp.bias)
+
+
+# ---------------- diffusers-named containers
+class Attention(Holder):
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int], heads: int, dim_head: int):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head = heads, dim_head
+        kv = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = _lin(query_dim, inner, bias=False)
+        self.to_k = _lin(kv, inner, bias=False)
+        self.to_v = _lin(kv, inner, bias=False)
+        self.to_out = nn.ModuleList([_lin(inner, query_dim, bias=True), nn.Dropout(0.0)])
+        self.processor = None
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def get_processor(self, return_deprecated_lora: bool = False):
+        return self.processor
+
+
+class GEGLU(Holder):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = _lin(dim_in, dim_out * 2)
+
+
+class FeedForward(Holder):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), _lin(dim * mult, dim)])
+
+
+class BasicTransformerBlock(Holder):
+    def __init__(self, dim, heads, head_dim, cross_attention_dim, double_self_attention=False):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn1 = Attention(dim, None, heads, head_dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn2 = Attention(dim, None if double_self_attention else cross_attention_dim, heads, head_dim)
+        self.norm3 = nn.LayerNorm(dim, eps=1e-5)
+        self.ff = FeedForward(dim)
+        self.pos_embed = None       # inference.py:176-192 nulls it; the processor owns the temporal PE
+
+
+class Transformer2DModel(Holder):
+    def __init__(self, heads, head_dim, in_channels, cross_attention_dim, groups):
+        super().__init__()
+        inner = heads * head_dim
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, head_dim, cross_attention_dim)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+
+
+class TransformerTemporalModel(Holder):
+    def __init__(self, heads, head_dim, in_channels, groups):
+        super().__init__()
+        inner = heads * head_dim
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.proj_in = _lin(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, head_dim, None, double_self_attention=True)])
+        self.proj_out = _lin(inner, in_channels)
+
+
+class ResnetBlock2D(Holder):
+    def __init__(self, in_c, out_c, temb_c, groups, eps):
+        super().__init__()
+        self.in_channels, self.out_channels = in_c, out_c
+        self.norm1 = nn.GroupNorm(groups, in_c, eps=eps)
+        self.conv1 = nn.Conv2d(in_c, out_c, 3, padding=1)
+        self.time_emb_proj = _lin(temb_c, out_c)
+        self.norm2 = nn.GroupNorm(groups, out_c, eps=eps)
+        self.conv2 = nn.Conv2d(out_c, out_c, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(in_c, out_c, 1) if in_c != out_c else None
+
+
+class Sampler2D(Holder):
+    """Downsample2D (3x3 stride-2 conv) / Upsample2D (nearest 2x + 3x3 conv): both hold ``conv``."""
+
+    def __init__(self, channels, stride=1):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=stride, padding=1)
+
+
+class TimestepEmbedding(Holder):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = _lin(in_dim, dim)
+        self.linear_2 = _lin(dim, dim)
+
+
+class ImageProjection(Holder):
+    def __init__(self, image_embed_dim, cross_attention_dim, num_tokens):
+        super().__init__()
+        self.num_image_text_embeds = num_tokens
+        self.image_embeds = _lin(image_embed_dim, num_tokens * cross_attention_dim)
+        self.norm = nn.LayerNorm(cross_attention_dim)
+
+
+class MultiIPAdapterImageProjection(Holder):
+    def __init__(self, layers):
+        super().__init__()
+        self.image_projection_layers = nn.ModuleList(layers)
+
+
+class MotionBlock(Holder):
+    """{CrossAttn}DownBlockMotion / UNetMidBlockCrossAttnMotion / {CrossAttn}UpBlockMotion."""
+
+    def __init__(self, cfg: UNetConfig, kind: str, resnet_io, out_c: int, temb_c: int, has_attn: bool, n_attn: int,
+                 n_motion: int, sampler: Optional[str]):
+        super().__init__()
+        self.kind, self.has_cross_attention = kind, has_attn
+        g, eps = cfg.norm_num_groups, cfg.norm_eps
+        self.resnets = nn.ModuleList([ResnetBlock2D(i, o, temb_c, g, eps) for i, o in resnet_io])
+        if has_attn:
+            self.attentions = nn.ModuleList([Transformer2DModel(cfg.num_attention_heads, out_c // cfg.num_attention_heads, out_c,
+                                                                cfg.cross_attention_dim, g) for _ in range(n_attn)])
+        self.motion_modules = nn.ModuleList([TransformerTemporalModel(cfg.motion_num_attention_heads, out_c // cfg.motion_num_attention_heads,
+                                                                      out_c, g) for _ in range(n_motion)])
+        self.downsamplers = nn.ModuleList([Sampler2D(out_c, 2)]) if sampler == "down" else None
+        self.upsamplers = nn.ModuleList([Sampler2D(out_c, 1)]) if sampler == "up" else None

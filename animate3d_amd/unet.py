@@ -1,0 +1,574 @@
+"""MI355X-native MV-VDM denoising UNet behind the reference's call surface.
+
+``MVUNetMotionModel`` here is a drop-in for the reference class of the same name
+(animatediff/models/unet_motion_mv_model.py:55-867): same ``forward`` signature and return type,
+same parameter names (a reference / diffusers state-dict loads key-for-key), same
+``attn_processors`` / ``set_attn_processor`` / ``config`` / ``dtype`` / ``device`` surface that
+``animatediff/pipelines/pipeline.py:1012-1020`` and the 4D-SDS guidance
+(``custom/threestudio-animate3d/guidance/animatemv_guidance.py:339-346``) touch.
+
+What is different is everything underneath:
+
+* activations are token-major NHWC rows ``[(b n f) h w, C]`` in bf16 for the whole step, so the
+  reference's three token groupings — per image, per multi-view group ``(b f)(n l)``, per pixel
+  sequence ``(b n h w) f`` (attention_processor.py:54,340,552-557) — are addressing modes of the
+  attention kernels, not ``rearrange(...).contiguous()`` copies;
+* every arithmetic op is a hand-written gfx950 kernel reached through the C-ABI of
+  ``libanimate3d_hip.so`` (include/animate3d_hip.h) — there is no eager/PyTorch fallback;
+* Q/K/V(/Q_i2v) projections are single fused GEMMs; residual adds, the AlphaBlender mix, the
+  time-embedding broadcast and the I2V sum are GEMM/conv epilogues; text / IP-Adapter K/V are
+  projected once per video instead of once per frame (the reference repeats them F times,
+  unet_motion_mv_model.py:754,763);
+* token geometry (views, frames, feature size per level) is derived from the call, not from
+  processor constructor constants (fixes SURVEY.md F5: hard-coded sample_size=256).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import modules as M
+from .config import UNetConfig
+from .embeddings import sine_pos_2d, sinusoidal_pos_1d
+from .hip_ops import RowMap
+
+
+class UNet3DConditionOutput:
+    """Same shape as diffusers' UNet3DConditionOutput: ``.sample`` is ``[V, C, F, H, W]``."""
+
+    def __init__(self, sample: torch.Tensor):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class MVUNetMotionModel(nn.Module):
+    def __init__(self, config: Optional[UNetConfig] = None, ops=None, num_views: Optional[int] = None,
+                 device: Optional[Union[str, torch.device]] = None, **config_overrides):
+        super().__init__()
+        cfg = config if config is not None else UNetConfig(**config_overrides)
+        self.config = cfg
+        self.sample_size = cfg.sample_size
+        self.num_views = num_views          # processors' view count; None => taken from forward(num_views=)
+        self._ops = ops
+        self._packed = None
+        self._pe_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.parallel = None                # set by animate3d_amd.parallel.shard_unet
+        if len(cfg.block_out_channels) != len(cfg.down_has_attn):
+            raise ValueError("block_out_channels and down_has_attn must have the same length")
+        ctx = torch.device(device) if device is not None else torch.device("cpu")
+        with ctx:
+            self._build(cfg)
+            self._install_default_processors()
+
+    # ------------------------------------------------------------------ construction
+    def _build(self, cfg: UNetConfig):
+        boc = cfg.block_out_channels
+        temb_c = boc[0] * 4
+        nlev = len(boc)
+        self.conv_in = nn.Conv2d(cfg.in_channels, boc[0], 3, padding=1)
+        self.time_embedding = M.TimestepEmbedding(boc[0], temb_c)
+        if cfg.camera_embedding_dim is not None:
+            self.camera_embedding = M.TimestepEmbedding(cfg.camera_embedding_dim, temb_c)
+        self.encoder_hid_proj = None
+        if cfg.encoder_hid_dim_type == "ip_image_proj":
+            self.encoder_hid_proj = M.MultiIPAdapterImageProjection(
+                [M.ImageProjection(cfg.ip_image_embed_dim, cfg.cross_attention_dim, cfg.ip_num_tokens)])
+        n = cfg.layers_per_block
+        self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()      # registered before mid_block: diffusers' module order (IP-Adapter key ids)
+        out_c = boc[0]
+        for i in range(nlev):
+            in_c, out_c = out_c, boc[i]
+            io = [(in_c if j == 0 else out_c, out_c) for j in range(n)]
+            self.down_blocks.append(M.MotionBlock(cfg, "down", io, out_c, temb_c, cfg.down_has_attn[i], n, n,
+                                                  "down" if i != nlev - 1 else None))
+        c = boc[-1]
+        self.mid_block = M.MotionBlock(cfg, "mid", [(c, c), (c, c)], c, temb_c, True, 1, 1, None)
+        rev, rev_attn = list(reversed(boc)), list(reversed(cfg.down_has_attn))
+        out_c = rev[0]
+        for i in range(nlev):
+            prev_c, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, nlev - 1)]
+            io = []
+            for j in range(n + 1):
+                skip_c = in_c if j == n else out_c
+                res_in = prev_c if j == 0 else out_c
+                io.append((res_in + skip_c, out_c))
+            self.up_blocks.append(M.MotionBlock(cfg, "up", io, out_c, temb_c, rev_attn[i], n + 1, n + 1,
+                                                "up" if i != nlev - 1 else None))
+        self.num_upsamplers = nlev - 1
+        self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, boc[0], eps=cfg.norm_eps)
+        self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
+
+    def _blocks(self):
+        for i, b in enumerate(self.down_blocks):
+            yield f"down_blocks.{i}", b, self.config.block_out_channels[i]
+        yield "mid_block", self.mid_block, self.config.block_out_channels[-1]
+        for i, b in enumerate(self.up_blocks):
+            yield f"up_blocks.{i}", b, list(reversed(self.config.block_out_channels))[i]
+
+    def _install_default_processors(self):
+        """inference.py:90-174 by layer ROLE (attn1 / attn2 / motion_modules), not by diffusers class
+        identity.  ``to_q_i2v := to_q`` and ``to_out_i2v := 0`` as inference.py:161-165."""
+        cfg = self.config
+        for _, blk, c in self._blocks():
+            if blk.has_cross_attention:
+                for t in blk.attentions:
+                    tb = t.transformer_blocks[0]
+                    if cfg.mvdream_image_attn:
+                        p = M.MVDreamI2VAttnProcessor(c)
+                        with torch.no_grad():
+                            p.to_q_i2v.weight.copy_(tb.attn1.to_q.weight)
+                            p.to_out_i2v.weight.zero_()
+                            p.to_out_i2v.bias.zero_()
+                    else:
+                        p = M.MVDreamAttnProcessor()
+                    tb.attn1.set_processor(p)
+                    ipp = M.IPAdapterAttnProcessor(c, cfg.cross_attention_dim, (cfg.ip_num_tokens,), cfg.ip_scale)
+                    tb.attn2.set_processor(ipp)
+            for m in blk.motion_modules:
+                tb = m.transformer_blocks[0]
+                for a in (tb.attn1, tb.attn2):
+                    sp = M.SpatioTemporalI2VAttnProcessor(c, cfg.motion_spatial_attn, cfg.motion_use_spatial_encoding,
+                                                          cfg.motion_use_alpha_blender, cfg.motion_max_seq_length)
+                    a.set_processor(sp)
+
+    # ------------------------------------------------------------------ diffusers-style surface
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def attn_processors(self) -> Dict[str, nn.Module]:
+        """name -> processor, keyed exactly like the reference (unet_motion_mv_model.py:439-462)."""
+        out = {}
+        for name, mod in self.named_modules():
+            if isinstance(mod, M.Attention):
+                out[f"{name}.processor"] = mod.get_processor()
+        return out
+
+    def set_attn_processor(self, processor):
+        """unet_motion_mv_model.py:465-497.  Accepts a dict name -> processor (count must match) or one
+        parameter-free processor for all layers.  Processors must be animate3d_amd.modules classes."""
+        names = list(self.attn_processors.keys())
+        if isinstance(processor, dict):
+            if len(processor) != len(names):
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                                 f" number of attention layers: {len(names)}. Please make sure to pass {len(names)} processor classes.")
+            processor = dict(processor)
+        for name, mod in self.named_modules():
+            if isinstance(mod, M.Attention):
+                p = processor.pop(f"{name}.processor") if isinstance(processor, dict) else processor
+                if not hasattr(p, "kind"):
+                    raise TypeError(f"{type(p).__name__} is not an animate3d_amd processor (see animate3d_amd.modules)")
+                mod.set_processor(p)
+        self._packed = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        res = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._packed = None
+        return res
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._pe_cache = {}
+        return super()._apply(fn, *a, **k)
+
+    @classmethod
+    def from_unet2d(cls, unet, motion_adapter=None, load_weights: bool = True, **kw):
+        """unet_motion_mv_model.py:275-368: build from a 2-D MVDream UNet (+ motion adapter) by copying
+        state-dict entries; ``unet`` / ``motion_adapter`` only need ``state_dict()``."""
+        model = cls(**kw)
+        if load_weights:
+            sd = {k: v for k, v in unet.state_dict().items()}
+            if motion_adapter is not None:
+                sd.update({k: v for k, v in motion_adapter.state_dict().items() if "motion_modules" in k})
+            model.load_state_dict(sd, strict=False)
+        return model
+
+    def _load_ip_adapter_weights(self, state_dict):
+        """Counterpart of diffusers' UNet2DConditionLoadersMixin._load_ip_adapter_weights for the
+        ip-adapter_sd15 layout {"image_proj": {proj.*, norm.*}, "ip_adapter": {"<2k+1>.to_k_ip.weight", ...}}
+        (inference.py:78-85)."""
+        if isinstance(state_dict, (list, tuple)):
+            state_dict = state_dict[0]
+        ip = self.encoder_hid_proj.image_projection_layers[0]
+        img = state_dict["image_proj"]
+        with torch.no_grad():
+            ip.image_embeds.weight.copy_(img["proj.weight"]); ip.image_embeds.bias.copy_(img["proj.bias"])
+            ip.norm.weight.copy_(img["norm.weight"]); ip.norm.bias.copy_(img["norm.bias"])
+            key_id = 1
+            for name, proc in self.attn_processors.items():
+                if "motion_modules" in name:
+                    continue
+                if name.endswith("attn1.processor"):
+                    continue
+                proc.to_k_ip[0].weight.copy_(state_dict["ip_adapter"][f"{key_id}.to_k_ip.weight"])
+                proc.to_v_ip[0].weight.copy_(state_dict["ip_adapter"][f"{key_id}.to_v_ip.weight"])
+                key_id += 2
+        self._packed = None
+
+    def init_synthetic(self, seed: int = 0):
+        """Seeded on-device synthetic weights of realistic scale (no checkpoints exist offline):
+        U(-1/sqrt(fan_in), 1/sqrt(fan_in)) matrices, norm gains near 1, small biases, every branch live
+        (to_out_i2v / to_out_sp ~ N(0, 0.02), mix_factor ~ U(-0.5, 0.5))."""
+        dev = self.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if p.ndim >= 2:
+                    bound = 1.0 / math.sqrt(p[0].numel())
+                    p.copy_((torch.rand(p.shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * bound)
+                elif name.endswith("mix_factor"):
+                    p.copy_(torch.rand(p.shape, generator=g, device=dev) - 0.5)
+                elif name.endswith("bias"):
+                    p.copy_(0.02 * (torch.rand(p.shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1))
+                else:
+                    p.copy_(1.0 + 0.1 * (torch.rand(p.shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1))
+            for name, p in self.named_parameters():
+                if name.endswith("to_out_i2v.weight") or name.endswith("to_out_sp.weight"):
+                    p.copy_(torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * 0.02)
+        self._packed = None
+        return self
+
+    # ------------------------------------------------------------------ op set / packed weights
+    @property
+    def ops(self):
+        if self._ops is None:
+            from .hip_ops import HipOps      # raises without an MI355X or without the built library
+            self._ops = HipOps(self.device)
+        return self._ops
+
+    def _w(self, t: torch.Tensor) -> torch.Tensor:        # kernel weight: act dtype, contiguous
+        return t.detach().to(self.ops.act_dtype).contiguous()
+
+    def _f(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:   # bias / affine: fp32
+        return None if t is None else t.detach().float().contiguous()
+
+    def _conv_w(self, conv: nn.Conv2d) -> torch.Tensor:   # [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
+        w = conv.weight.detach()
+        return self._w(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+
+    def _pack_resnet(self, r: M.ResnetBlock2D):
+        return SimpleNamespace(
+            n1=(self._f(r.norm1.weight), self._f(r.norm1.bias)), eps=r.norm1.eps,
+            c1=(self._conv_w(r.conv1), self._f(r.conv1.bias)),
+            temb=(self._w(r.time_emb_proj.weight), self._f(r.time_emb_proj.bias)),
+            n2=(self._f(r.norm2.weight), self._f(r.norm2.bias)),
+            c2=(self._conv_w(r.conv2), self._f(r.conv2.bias)),
+            sc=None if r.conv_shortcut is None else (self._conv_w(r.conv_shortcut), self._f(r.conv_shortcut.bias)))
+
+    def _pack_ff(self, tb):
+        return SimpleNamespace(n3=(self._f(tb.norm3.weight), self._f(tb.norm3.bias)),
+                               ff1=(self._w(tb.ff.net[0].proj.weight), self._f(tb.ff.net[0].proj.bias)),
+                               ff2=(self._w(tb.ff.net[2].weight), self._f(tb.ff.net[2].bias)))
+
+    def _pack_t2d(self, t: M.Transformer2DModel):
+        tb = t.transformer_blocks[0]
+        a1, a2 = tb.attn1, tb.attn2
+        p1, p2 = a1.processor, a2.processor
+        if p1.kind not in ("mvdream", "mvdream_i2v") or p2.kind != "ip_adapter":
+            raise TypeError("Transformer2D layers need a MVDream(I2V) processor on attn1 and an IPAdapter processor on attn2")
+        qkv = [a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]
+        i2v = p1.kind == "mvdream_i2v"
+        if i2v:
+            qkv.append(p1.to_q_i2v.weight)
+        out = SimpleNamespace(
+            heads=a1.heads, i2v=i2v,
+            norm=(self._f(t.norm.weight), self._f(t.norm.bias)),
+            pin=(self._conv_w(t.proj_in), self._f(t.proj_in.bias)),
+            n1=(self._f(tb.norm1.weight), self._f(tb.norm1.bias)),
+            qkv=self._w(torch.cat([w.detach() for w in qkv], 0)),
+            oi2v=(self._w(p1.to_out_i2v.weight), self._f(p1.to_out_i2v.bias)) if i2v else None,
+            o1=(self._w(a1.to_out[0].weight), self._f(a1.to_out[0].bias)),
+            n2=(self._f(tb.norm2.weight), self._f(tb.norm2.bias)),
+            q2=self._w(a2.to_q.weight),
+            kv_text=self._w(torch.cat([a2.to_k.weight.detach(), a2.to_v.weight.detach()], 0)),
+            kv_ip=[self._w(torch.cat([k.weight.detach(), v.weight.detach()], 0)) for k, v in zip(p2.to_k_ip, p2.to_v_ip)],
+            ip_scale=list(p2.scale), ip_tokens=list(p2.num_tokens),
+            o2=(self._w(a2.to_out[0].weight), self._f(a2.to_out[0].bias)),
+            pout=(self._conv_w(t.proj_out), self._f(t.proj_out.bias)))
+        out.ff = self._pack_ff(tb)
+        return out
+
+    def _pack_motion(self, m: M.TransformerTemporalModel):
+        tb = m.transformer_blocks[0]
+        attns = []
+        for a, ln in ((tb.attn1, tb.norm1), (tb.attn2, tb.norm2)):
+            pr = a.processor
+            if pr.kind != "spatio_temporal":
+                raise TypeError("motion-module attention layers need a SpatioTemporalI2VAttnProcessor")
+            C = a.to_q.weight.shape[0]
+            if hasattr(pr, "time_pos_embed"):
+                pe = pr.time_pos_embed.pe[0]
+            else:   # diffusers BasicTransformerBlock.pos_embed (sinusoidal) when the processor holds none
+                pe = sinusoidal_pos_1d(C, self.config.motion_max_seq_length)[0].to(a.to_q.weight.device)
+            ns = SimpleNamespace(
+                heads=a.heads, spatial=pr.use_spatial_attn, spatial_pe=pr.use_spatial_attn and pr.use_spatial_encoding,
+                n=(self._f(ln.weight), self._f(ln.bias)),
+                qkv=self._w(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach(), a.to_v.weight.detach()], 0)),
+                o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)),
+                pe_t=self._w(pe), alpha=None)
+            if pr.use_spatial_attn:
+                ns.qkv_sp = self._w(torch.cat([pr.to_q_sp.weight.detach(), pr.to_k_sp.weight.detach(), pr.to_v_sp.weight.detach()], 0))
+                ns.osp = (self._w(pr.to_out_sp.weight), self._f(pr.to_out_sp.bias))
+                if pr.use_alpha_blender:
+                    ns.alpha = float(torch.sigmoid(pr.alpha_blender.mix_factor.detach().float()).item())
+            attns.append(ns)
+        out = SimpleNamespace(norm=(self._f(m.norm.weight), self._f(m.norm.bias)),
+                              pin=(self._w(m.proj_in.weight), self._f(m.proj_in.bias)),
+                              attns=attns,
+                              pout=(self._w(m.proj_out.weight), self._f(m.proj_out.bias)))
+        out.ff = self._pack_ff(tb)
+        return out
+
+    def _pack_block(self, blk: M.MotionBlock):
+        return SimpleNamespace(
+            resnets=[self._pack_resnet(r) for r in blk.resnets],
+            t2d=[self._pack_t2d(t) for t in blk.attentions] if blk.has_cross_attention else None,
+            motion=[self._pack_motion(m) for m in blk.motion_modules],
+            down=None if blk.downsamplers is None else (self._conv_w(blk.downsamplers[0].conv), self._f(blk.downsamplers[0].conv.bias)),
+            up=None if blk.upsamplers is None else (self._conv_w(blk.upsamplers[0].conv), self._f(blk.upsamplers[0].conv.bias)))
+
+    def _pack(self):
+        """Kernel-layout copies of the weights (bf16 [N, K] matrices, fp32 biases/affines), built once."""
+        cfg = self.config
+        dev = self.device
+        te, P = self.time_embedding, SimpleNamespace()
+        P.time = (self._w(te.linear_1.weight), self._f(te.linear_1.bias), self._w(te.linear_2.weight), self._f(te.linear_2.bias))
+        P.cam = None
+        if cfg.camera_embedding_dim is not None:
+            ce = self.camera_embedding
+            w1 = torch.zeros(ce.linear_1.weight.shape[0], 64, device=dev, dtype=torch.float32)
+            w1[:, : cfg.camera_embedding_dim] = ce.linear_1.weight.detach().float()
+            P.cam = (self._w(w1), self._f(ce.linear_1.bias), self._w(ce.linear_2.weight), self._f(ce.linear_2.bias))
+        P.ip = None
+        if self.encoder_hid_proj is not None:
+            ipl = self.encoder_hid_proj.image_projection_layers[0]
+            P.ip = (self._w(ipl.image_embeds.weight), self._f(ipl.image_embeds.bias), self._f(ipl.norm.weight), self._f(ipl.norm.bias), ipl.norm.eps)
+        # conv_in as a K=64 GEMM over im2col patches (k = (ky*3+kx)*Cin + ci)
+        wi = self.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(self.conv_in.weight.shape[0], -1)
+        wpad = torch.zeros(wi.shape[0], 64, device=dev, dtype=torch.float32)
+        wpad[:, : wi.shape[1]] = wi
+        P.conv_in = (self._w(wpad), self._f(self.conv_in.bias))
+        P.down = [self._pack_block(b) for b in self.down_blocks]
+        P.mid = self._pack_block(self.mid_block)
+        P.up = [self._pack_block(b) for b in self.up_blocks]
+        P.norm_out = (self._f(self.conv_norm_out.weight), self._f(self.conv_norm_out.bias))
+        P.conv_out = (self._conv_w(self.conv_out), self._f(self.conv_out.bias))
+        self._packed = P
+        return P
+
+    def _pe_spatial(self, C: int, h: int, w: int) -> torch.Tensor:
+        """2-D sine PE table [h*w, C] for one level (embeddings.py:59-96), cached per geometry."""
+        key = (C, h, w)
+        if key not in self._pe_cache:
+            self._pe_cache[key] = sine_pos_2d(C // 2, h, w).to(device=self.device, dtype=self.ops.act_dtype).contiguous()
+        return self._pe_cache[key]
+
+    # ------------------------------------------------------------------ forward pieces
+    def _resnet(self, x, B2, H, W, pk, semb, rb_rows):
+        ops, g = self.ops, self.config.norm_num_groups
+        L = H * W
+        h = ops.group_norm(x, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
+        tp = ops.gemm(semb, pk.temb[0], pk.temb[1])                       # time_emb_proj(SiLU(temb))
+        h, _, _ = ops.conv3x3(h, B2, H, W, pk.c1[0], pk.c1[1], rowbias=tp, rb_div=rb_rows * L)
+        h = ops.group_norm(h, B2, L, pk.n2[0], pk.n2[1], g, pk.eps, True)
+        sc = x if pk.sc is None else ops.gemm(x, pk.sc[0], pk.sc[1])
+        out, _, _ = ops.conv3x3(h, B2, H, W, pk.c2[0], pk.c2[1], residual=sc)
+        return out
+
+    def _ff(self, h, pk):
+        ops = self.ops
+        n3 = ops.layer_norm(h, pk.n3[0], pk.n3[1], 1e-5)
+        u = ops.gemm(n3, pk.ff1[0], pk.ff1[1])
+        u = ops.geglu(u)
+        return ops.gemm(u, pk.ff2[0], pk.ff2[1], residual=h)
+
+    def _mv_maps(self, n, F, L):
+        qm = RowMap(gdiv=F, ga=n * F * L, gb=L, seg_len=L, seg_stride=F * L)     # "(b n f) l -> (b f) (n l)"
+        k0 = RowMap(gdiv=F, ga=n * F * L, gb=0, seg_len=L, seg_stride=F * L)     # same, frame 0 of every b
+        return qm, k0
+
+    def _t2d(self, x, V, n, F, H, W, pk, text_rows, ip_rows, T):
+        ops, g = self.ops, self.config.norm_num_groups
+        B2, L, C = V * F, H * W, x.shape[1]
+        G = (V // n) * F
+        S = n * L
+        h = ops.group_norm(x, B2, L, pk.norm[0], pk.norm[1], g, 1e-6, False)
+        h = ops.gemm(h, pk.pin[0], pk.pin[1])
+        # attn1: multi-view self-attention (+ first-frame attention)
+        n1 = ops.layer_norm(h, pk.n1[0], pk.n1[1], 1e-5)
+        qkv = ops.gemm(n1, pk.qkv)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C]
+        qm, k0 = self._mv_maps(n, F, L)
+        a = ops.flash_attn(q, k, v, qm, qm, G, pk.heads, S, S)
+        if pk.i2v:
+            ai = ops.flash_attn(qkv[:, 3 * C:4 * C], k, v, qm, k0, G, pk.heads, S, S)
+            a = ops.gemm(ai, pk.oi2v[0], pk.oi2v[1], residual=a)          # main + to_out_i2v(i2v)
+        h = ops.gemm(a, pk.o1[0], pk.o1[1], residual=h)
+        # attn2: text + IP-Adapter cross-attention, K/V projected once per video
+        n2 = ops.layer_norm(h, pk.n2[0], pk.n2[1], 1e-5)
+        q2 = ops.gemm(n2, pk.q2)
+        kvt = ops.gemm(text_rows, pk.kv_text)
+        qc = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
+        ca = ops.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), B2, pk.heads, L, T)
+        for ipr, w, scale, nt in zip(ip_rows, pk.kv_ip, pk.ip_scale, pk.ip_tokens):
+            kvi = ops.gemm(ipr, w)
+            ops.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), B2, pk.heads, L, nt,
+                           out=ca, out_scale=scale, accumulate=True)
+        h = ops.gemm(ca, pk.o2[0], pk.o2[1], residual=h)
+        h = self._ff(h, pk.ff)
+        return ops.gemm(h, pk.pout[0], pk.pout[1], residual=x)
+
+    def _motion(self, x, V, n, F, H, W, pk):
+        ops, g = self.ops, self.config.norm_num_groups
+        L, C = H * W, x.shape[1]
+        G = (V // n) * F
+        S = n * L
+        h = ops.group_norm(x, V, F * L, pk.norm[0], pk.norm[1], g, 1e-6, False)     # 3-D GroupNorm per video
+        h = ops.gemm(h, pk.pin[0], pk.pin[1])
+        qm, _ = self._mv_maps(n, F, L)
+        for a in pk.attns:
+            pe_t = a.pe_t[:F]
+            if a.spatial:
+                if a.spatial_pe:
+                    nt, ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L, pe2=self._pe_spatial(C, H, W), pe2_div=1, two=True)
+                else:
+                    nt = ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5)
+            else:
+                nt = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L)
+            qkv = ops.gemm(nt, a.qkv)
+            at = ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
+            if a.spatial:
+                qkvs = ops.gemm(ns, a.qkv_sp)
+                asp = ops.flash_attn(qkvs[:, :C], qkvs[:, C:2 * C], qkvs[:, 2 * C:], qm, qm, G, a.heads, S, S)
+                al = a.alpha
+                if al is None:                       # plain sum (use_alpha_blender = False)
+                    t1 = ops.gemm(at, a.o[0], a.o[1], residual=h)
+                    h = ops.gemm(asp, a.osp[0], a.osp[1], residual=t1)
+                else:                                # sigma(m) * spatial + (1 - sigma(m)) * temporal, + residual
+                    t1 = ops.gemm(at, a.o[0], a.o[1], residual=h, alpha=1.0 - al, beta=1.0)
+                    h = ops.gemm(asp, a.osp[0], a.osp[1], residual=t1, alpha=al, beta=1.0)
+            else:
+                h = ops.gemm(at, a.o[0], a.o[1], residual=h)
+        h = self._ff(h, pk.ff)
+        return ops.gemm(h, pk.pout[0], pk.pout[1], residual=x)
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], encoder_hidden_states: torch.Tensor,
+                timestep_cond: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                cross_attention_kwargs: Optional[Dict[str, Any]] = None, added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, return_dict: bool = True,
+                camera: Optional[torch.Tensor] = None, num_views: int = 4, i2v_cond_time_zero: bool = False):
+        """Same contract as the reference forward (unet_motion_mv_model.py:633-867): ``sample``
+        [V, C, F, h, w] with V = b*cfg*views in (b n) order, returns ``.sample`` of the same shape.
+        Inference only (the reference's callers wrap it in no_grad: pipeline.py:758, guidance :422)."""
+        assert sample.shape[0] % num_views == 0, "[UNet] input batch size must be dividable by num_views!"
+        if attention_mask is not None or timestep_cond is not None or down_block_additional_residuals is not None \
+                or mid_block_additional_residual is not None:
+            raise NotImplementedError("attention_mask / timestep_cond / ControlNet residuals are never passed by the reference callers")
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs (LoRA scale) is not supported")
+        cfg, ops = self.config, self.ops
+        V, Cin, F, H, W = sample.shape
+        n = self.num_views or num_views
+        if V % n != 0:
+            raise AssertionError("[UNet] input batch size must be dividable by the processors' num_views!")
+        nlev = len(cfg.block_out_channels)
+        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
+            raise ValueError(f"latent size {(H, W)} must be a multiple of {1 << (nlev - 1)}")
+        if F > cfg.motion_max_seq_length:
+            raise ValueError(f"num_frames {F} exceeds motion_max_seq_length {cfg.motion_max_seq_length}")
+        P = self._packed if self._packed is not None else self._pack()
+        dev, adt = sample.device, ops.act_dtype
+        B2 = V * F
+
+        # 1. time / camera embedding (unet_motion_mv_model.py:706-752)
+        if not torch.is_tensor(timestep):
+            t = torch.full((V,), float(timestep), dtype=torch.float32, device=dev)
+        else:
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1).expand(V).contiguous()
+
+        def time_mlp(tt):
+            e = ops.gemm(ops.timestep_embed(tt, cfg.block_out_channels[0]), P.time[0], P.time[1])
+            return ops.gemm(ops.silu(e), P.time[2], P.time[3])
+
+        emb = time_mlp(t)
+        cond_emb = time_mlp(torch.zeros_like(t)) if i2v_cond_time_zero else None
+        if camera is not None:
+            assert camera.shape[0] == V
+            if P.cam is None:
+                raise ValueError("camera passed but the model has no camera_embedding")
+            cam = torch.zeros((V, 64), dtype=adt, device=dev)
+            cam[:, : camera.shape[1]] = camera.to(device=dev, dtype=adt)
+            c1 = ops.silu(ops.gemm(cam, P.cam[0], P.cam[1]))
+            emb = ops.gemm(c1, P.cam[2], P.cam[3], residual=emb)
+            if cond_emb is not None:
+                cond_emb = ops.gemm(c1, P.cam[2], P.cam[3], residual=cond_emb)
+        if cond_emb is None:
+            semb, rb_rows = ops.silu(emb), F                 # one embedding per video, F images share it
+        else:                                               # frame 0 of every video gets the t=0 embedding (:748-752)
+            per_img = emb[:, None, :].repeat(1, F, 1)
+            per_img[:, 0] = cond_emb
+            semb, rb_rows = ops.silu(per_img.reshape(B2, -1).contiguous()), 1
+
+        # 2. conditioning tokens, once per video (reference repeats them per frame, :754-764)
+        T = encoder_hidden_states.shape[1]
+        text_rows = encoder_hidden_states.to(device=dev, dtype=adt).reshape(V * T, -1).contiguous()
+        ip_rows = []
+        if self.encoder_hid_proj is not None and cfg.encoder_hid_dim_type == "ip_image_proj":
+            if added_cond_kwargs is None or "image_embeds" not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which requires the "
+                                 "keyword argument `image_embeds` to be passed in  `added_conditions`")
+            img = added_cond_kwargs["image_embeds"]
+            img = img.to(device=dev, dtype=adt).reshape(V, -1).contiguous()
+            pr = ops.gemm(img, P.ip[0], P.ip[1]).reshape(V * cfg.ip_num_tokens, cfg.cross_attention_dim)
+            ip_rows.append(ops.layer_norm(pr, P.ip[2], P.ip[3], P.ip[4]))
+
+        # 3. conv_in over im2col patches; from here on x is [(V F) h w, C] rows
+        x = ops.gemm(ops.im2col_in(sample), P.conv_in[0], P.conv_in[1])
+        h_, w_ = H, W
+        skips = [x]
+        for blk, pk in zip(self.down_blocks, P.down):
+            for j, rp in enumerate(pk.resnets):
+                x = self._resnet(x, B2, h_, w_, rp, semb, rb_rows)
+                if pk.t2d is not None:
+                    x = self._t2d(x, V, n, F, h_, w_, pk.t2d[j], text_rows, ip_rows, T)
+                x = self._motion(x, V, n, F, h_, w_, pk.motion[j])
+                skips.append(x)
+            if pk.down is not None:
+                x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.down[0], pk.down[1], stride=2)
+                skips.append(x)
+        pk = P.mid
+        x = self._resnet(x, B2, h_, w_, pk.resnets[0], semb, rb_rows)
+        x = self._t2d(x, V, n, F, h_, w_, pk.t2d[0], text_rows, ip_rows, T)
+        x = self._motion(x, V, n, F, h_, w_, pk.motion[0])
+        x = self._resnet(x, B2, h_, w_, pk.resnets[1], semb, rb_rows)
+        for blk, pk in zip(self.up_blocks, P.up):
+            for j, rp in enumerate(pk.resnets):
+                x = ops.concat(x, skips.pop())
+                x = self._resnet(x, B2, h_, w_, rp, semb, rb_rows)
+                if pk.t2d is not None:
+                    x = self._t2d(x, V, n, F, h_, w_, pk.t2d[j], text_rows, ip_rows, T)
+                x = self._motion(x, V, n, F, h_, w_, pk.motion[j])
+            if pk.up is not None:
+                x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.up[0], pk.up[1], up2x=True)
+        x = ops.group_norm(x, B2, h_ * w_, P.norm_out[0], P.norm_out[1], cfg.norm_num_groups, cfg.norm_eps, True)
+        x, _, _ = ops.conv3x3(x, B2, h_, w_, P.conv_out[0], P.conv_out[1])
+        out_dtype = sample.dtype if sample.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
+        out = ops.unpack_out(x, V, cfg.out_channels, F, H, W, out_dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)

@@ -1,0 +1,145 @@
+/*
+ * animate3d_hip.h — C-ABI of libanimate3d_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of this project is the Python call surface of the reference's
+ * `MVUNetMotionModel.forward` (animatediff/models/unet_motion_mv_model.py:633-867); the
+ * host side (animate3d_amd/unet.py) mirrors that class.  Everything arithmetic below that
+ * surface is executed by the entry points declared here: plain pointers, sizes and a HIP
+ * stream, no torch types.  Each entry point names the reference call it replaces.
+ *
+ * Conventions
+ *   - activations / weights: bf16 (uint16_t storage), row-major, last dim contiguous
+ *   - bias / norm affine / statistics: fp32
+ *   - images are NHWC, flattened to rows: row = ((b*H + y)*W + x), image batch order is
+ *     the reference's (b n f) order (unet_motion_mv_model.py:767)
+ *   - ld* = leading dimension (elements between consecutive rows)
+ *   - every function returns 0 on success, a negative A3D_E* code on bad arguments, or a
+ *     positive hipError_t from the launch.  Nothing here allocates or synchronises.
+ */
+#ifndef ANIMATE3D_HIP_H
+#define ANIMATE3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* a3d_stream_t; /* hipStream_t */
+
+enum {
+  A3D_OK = 0,
+  A3D_EINVAL = -1,      /* shape / alignment precondition violated */
+  A3D_EUNSUPPORTED = -2 /* e.g. head_dim not in {40, 80, 160} */
+};
+
+/* dtype codes for the two layout-conversion entry points */
+enum { A3D_F32 = 0, A3D_BF16 = 1, A3D_F16 = 2 };
+
+/* Library / build identification ("animate3d_hip gfx950 <n kernels>"). */
+const char* a3d_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Row addressing for the attention kernels.  Sequence position s of attention group g
+ * lives at tensor row
+ *     row(g, s) = (g / gdiv) * ga + (g % gdiv) * gb + (s / seg_len) * seg_stride + s % seg_len
+ * This expresses the reference's einops regroupings as addressing instead of copies:
+ *   "(b n f) l c -> (b f) (n l) c"   (attention_processor.py:54,340,557):
+ *        g = b*F + f ; gdiv = F, ga = n*F*L, gb = L, seg_len = L, seg_stride = F*L
+ *   first-frame K/V (attention_processor.py:389-397): same with gb = 0
+ *   text / IP tokens shared by the F frames of a video (unet_motion_mv_model.py:754,763):
+ *        g = image index ; gdiv = F, ga = T, gb = 0, seg_len = T
+ * ------------------------------------------------------------------------------------ */
+typedef struct a3d_rowmap {
+  int64_t gdiv, ga, gb;
+  int64_t seg_len, seg_stride;
+  int64_t ld; /* elements per row of the underlying [rows, ld] tensor */
+} a3d_rowmap;
+
+/* Y[M,N] = alpha * (X[M,K] · W[N,K]^T + bias[N] + rowbias[m / rb_div][N]) + beta * R[M,N]
+ * Replaces every nn.Linear / 1x1 nn.Conv2d on the path (diffusers Attention.to_q/k/v/out,
+ * the processors' to_*_i2v / to_*_sp / to_*_ip Linear layers attention_processor.py:162-166,
+ * 322-323,490-493; Transformer2D/Temporal proj_in/out; FeedForward; TimestepEmbedding;
+ * ResnetBlock2D.time_emb_proj / conv_shortcut) with the residual add, AlphaBlender mix
+ * (attention_processor.py:709) and time-embedding broadcast fused as epilogues.
+ * bias, rowbias, R may be NULL.  Requires K % 64 == 0, N % 4 == 0, 16-byte aligned rows. */
+int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                  const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                  void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
+
+/* 3x3 convolution, padding 1, NHWC, as an implicit GEMM (K = 9*Cin):
+ *   Y[b, yo, xo, co] = bias[co] + rowbias[(row) / rb_div][co] + R[...]
+ *                      + sum_{ky,kx,ci} X[b, yo*stride+ky-1, xo*stride+kx-1, ci] * Wp[co][ky][kx][ci]
+ * up2x != 0 first applies nearest 2x upsampling to X (diffusers Upsample2D) by addressing.
+ * Replaces cuDNN conv2d in diffusers ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D and
+ * conv_out (unet_motion_mv_model.py:271,859).  Requires Cin % 64 == 0, Cout % 4 == 0. */
+int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                     const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                     int B, int H, int W, int Cin, int Cout, int stride, int up2x);
+
+/* softmax(Q K^T * scale) V per (group, head), flash-style (no score matrix in memory).
+ *   O[row_o(g,s), h*D + d] = out_scale * attn(...)   (+ previous O contents if accumulate)
+ * Replaces xformers.ops.memory_efficient_attention at attention_processor.py:103,233,268,
+ * 405,416,656.  head_dim in {40, 80, 160}.  K and V share kmap. */
+int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                        const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                        int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                        float scale, float out_scale, int accumulate);
+
+/* Temporal (AnimateDiff) self-attention over the F frames of every (video, pixel, head):
+ * rows of Q/K/V/O are ((v*F + f)*L + l).  Replaces the unfused
+ * get_attention_scores + torch.bmm of attention_processor.py:630-636.  frames <= 32. */
+int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+                           void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
+                           int head_dim, float scale);
+
+/* GroupNorm over `rows` consecutive rows x (C/groups) channels per instance, optional SiLU.
+ * 2-D GroupNorm: B = images, rows = H*W.  The motion module's 3-D GroupNorm over
+ * (C/32, F, H, W) (diffusers TransformerTemporalModel.norm): B = videos, rows = F*H*W.
+ * ws: fp32 scratch of a3d_group_norm_ws_floats(B, rows, groups) elements. */
+int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups);
+int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                        float* ws, int B, int64_t rows, int C, int groups, float eps, int silu);
+
+/* LayerNorm over C, with the positional-embedding adds of the motion-module processor fused:
+ *   Y1[m] = LN(X[m]) + pe1[(m / pe1_div) % pe1_mod]     (pe1 may be NULL)
+ *   Y2[m] = LN(X[m]) + pe2[(m / pe2_div) % pe2_mod]     (Y2 may be NULL)
+ * (time_pos_embed attention_processor.py:583-584; SinePositionalEncoding2D :561-563). */
+int a3d_layer_norm_bf16(a3d_stream_t stream, const void* X, void* Y1, void* Y2, const float* gamma,
+                        const float* beta, int64_t M, int C, float eps,
+                        const void* pe1, int64_t pe1_div, int64_t pe1_mod,
+                        const void* pe2, int64_t pe2_div, int64_t pe2_mod);
+
+/* Y[m, j] = X[m, j] * gelu_erf(X[m, N + j])   (diffusers GEGLU). N % 8 == 0. */
+int a3d_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N);
+
+/* Y = X * sigmoid(X), n elements (n % 8 == 0). */
+int a3d_silu_bf16(a3d_stream_t stream, const void* X, void* Y, int64_t n);
+
+/* Y[m] = [A[m, 0:Ca] | B[m, 0:Cb]]  (torch.cat([x, skip], dim=1) of the up blocks). */
+int a3d_concat_bf16(a3d_stream_t stream, const void* A, int64_t Ca, const void* Bsrc, int64_t Cb, void* Y, int64_t M);
+
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0): Y[v] = [cos(t_v f_j) | sin(t_v f_j)],
+ * fp32 math, bf16 out (unet_motion_mv_model.py:723-728). */
+int a3d_timestep_embed_bf16(a3d_stream_t stream, const float* t, void* Y, int V, int dim);
+
+/* sample [V, C, F, H, W] (dtype code) -> im2col rows [(V F) H W, 64] bf16 with
+ * k = (ky*3 + kx)*C + c for k < 9*C, zero above (3x3, pad 1).  Folds the
+ * permute/reshape of unet_motion_mv_model.py:767 and conv_in's patch gather. 9*C <= 64. */
+int a3d_im2col_in(a3d_stream_t stream, const void* sample, int dtype, void* Y, int V, int C, int F, int H, int W);
+
+/* rows [(V F) H W, C] bf16 -> [V, C, F, H, W] in `dtype` (unet_motion_mv_model.py:862). */
+int a3d_unpack_out(a3d_stream_t stream, const void* X, void* Y, int dtype, int V, int C, int F, int H, int W);
+
+/* CFG combine + DDIM step + first-frame re-pin, one elementwise pass (pipeline.py:1023-1031):
+ *   eps = e_uncond + s (e_text - e_uncond) ; x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t)
+ *   x_prev = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps ; frame 0 <- first_frame
+ * fp32 tensors [n, C, F, H, W]; eps_pair is [2n, C, F, H, W] in (uncond, text) order. */
+int a3d_cfg_ddim_step_f32(a3d_stream_t stream, const float* eps_pair, const float* x, const float* first_frame,
+                          float* x_prev, int64_t n, int C, int F, int64_t HW, float guidance,
+                          float alpha_t, float alpha_prev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANIMATE3D_HIP_H */

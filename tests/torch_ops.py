@@ -1,0 +1,150 @@
+"""Plain-PyTorch reference of the op set in animate3d_amd/hip_ops.py (TEST INFRASTRUCTURE).
+
+Same method names, argument meaning and row-major ``[rows, C]`` conventions as ``HipOps``, computed
+with stock torch ops in fp32.  Used (a) as the per-op reference the HIP kernels are compared with on
+the GPU and (b) to execute the product's host logic (animate3d_amd/unet.py) on a CPU so that its
+layout / addressing / weight-packing logic can be checked against the oracle without a GPU.
+The product never imports this file.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def rowmap_indices(m, groups: int, length: int) -> torch.Tensor:
+    """[groups, length] row indices of a RowMap (include/animate3d_hip.h: a3d_rowmap)."""
+    g = torch.arange(groups)[:, None]
+    s = torch.arange(length)[None, :]
+    return (g // m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (s // m.seg_len) * m.seg_stride + (s % m.seg_len)
+
+
+class TorchRefOps:
+    def __init__(self, act_dtype=torch.float32, device="cpu"):
+        self.act_dtype = act_dtype
+        self.device = torch.device(device)
+
+    def _o(self, t):
+        return t.to(self.act_dtype)
+
+    def empty(self, rows, cols):
+        return torch.empty((rows, cols), dtype=self.act_dtype, device=self.device)
+
+    def gemm(self, x, w, bias=None, *, residual=None, alpha=1.0, beta=1.0, rowbias=None, rb_div=1, out=None):
+        y = x.float() @ w.float().t()
+        if bias is not None:
+            y = y + bias.float()
+        if rowbias is not None:
+            idx = torch.arange(x.shape[0], device=x.device) // rb_div
+            y = y + rowbias.float()[idx]
+        y = alpha * y
+        if residual is not None:
+            y = y + beta * residual.float()
+        y = self._o(y)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def conv3x3(self, x, B, H, W, w, bias, *, stride=1, up2x=False, rowbias=None, rb_div=1, residual=None):
+        Cin, Cout = x.shape[1], w.shape[0]
+        img = x.float().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+        if up2x:
+            img = F.interpolate(img, scale_factor=2.0, mode="nearest")
+        w4 = w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        y = F.conv2d(img, w4, None if bias is None else bias.float(), stride=stride, padding=1)
+        Ho, Wo = y.shape[2], y.shape[3]
+        y = y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
+        if rowbias is not None:
+            idx = torch.arange(y.shape[0], device=x.device) // rb_div
+            y = y + rowbias.float()[idx]
+        if residual is not None:
+            y = y + residual.float()
+        return self._o(y), Ho, Wo
+
+    def flash_attn(self, q, k, v, qmap, kmap, groups, heads, q_len, kv_len, *, out=None, out_scale=1.0, accumulate=False):
+        C = q.shape[1]
+        D = C // heads
+        qi = rowmap_indices(qmap, groups, q_len).to(q.device)
+        ki = rowmap_indices(kmap, groups, kv_len).to(q.device)
+        qg = q.float()[qi].reshape(groups, q_len, heads, D).transpose(1, 2)
+        kg = k.float()[ki].reshape(groups, kv_len, heads, D).transpose(1, 2)
+        vg = v.float()[ki].reshape(groups, kv_len, heads, D).transpose(1, 2)
+        p = torch.softmax(qg @ kg.transpose(-1, -2) * (D ** -0.5), dim=-1)
+        o = (p @ vg).transpose(1, 2).reshape(groups, q_len, C) * out_scale
+        res = out if out is not None else torch.zeros((q.shape[0], C), dtype=self.act_dtype, device=q.device)
+        flat = qi.reshape(-1)
+        if accumulate:
+            res[flat] = self._o(res[flat].float() + o.reshape(-1, C))
+        else:
+            res[flat] = self._o(o.reshape(-1, C))
+        return res
+
+    def temporal_attn(self, q, k, v, videos, frames, L, heads):
+        C = q.shape[1]
+        D = C // heads
+
+        def seq(t):     # [(v f) l, C] -> [v, l, heads, f, D]
+            return t.float().reshape(videos, frames, L, heads, D).permute(0, 2, 3, 1, 4)
+
+        p = torch.softmax(seq(q) @ seq(k).transpose(-1, -2) * (D ** -0.5), dim=-1)
+        o = (p @ seq(v)).permute(0, 3, 1, 2, 4).reshape(videos * frames * L, C)
+        return self._o(o)
+
+    def group_norm(self, x, B, rows, gamma, beta, groups, eps, silu):
+        C = x.shape[1]
+        t = x.float().reshape(B, rows, groups, C // groups)
+        mean = t.mean(dim=(1, 3), keepdim=True)
+        var = t.var(dim=(1, 3), unbiased=False, keepdim=True)
+        y = ((t - mean) / torch.sqrt(var + eps)).reshape(B * rows, C) * gamma.float() + beta.float()
+        if silu:
+            y = F.silu(y)
+        return self._o(y)
+
+    def layer_norm(self, x, gamma, beta, eps, pe1=None, pe1_div=1, pe2=None, pe2_div=1, two=False):
+        y = F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps)
+        m = torch.arange(x.shape[0], device=x.device)
+        y1 = y if pe1 is None else y + pe1.float()[(m // pe1_div) % pe1.shape[0]]
+        if not two:
+            return self._o(y1)
+        y2 = y if pe2 is None else y + pe2.float()[(m // pe2_div) % pe2.shape[0]]
+        return self._o(y1), self._o(y2)
+
+    def geglu(self, x):
+        h, gate = x.float().chunk(2, dim=-1)
+        return self._o(h * F.gelu(gate))
+
+    def silu(self, x):
+        return self._o(F.silu(x.float()))
+
+    def concat(self, a, b):
+        return torch.cat([a, b], dim=1)
+
+    def timestep_embed(self, t, dim):
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        a = t.float()[:, None] * freqs[None]
+        return self._o(torch.cat([torch.cos(a), torch.sin(a)], dim=-1))
+
+    def im2col_in(self, sample):
+        V, C, Fr, H, W = sample.shape
+        img = sample.float().permute(0, 2, 1, 3, 4).reshape(V * Fr, C, H, W)
+        cols = F.unfold(img, kernel_size=3, padding=1)                    # [B, C*9, H*W], index c*9 + tap
+        cols = cols.reshape(V * Fr, C, 9, H * W).permute(0, 3, 2, 1).reshape(V * Fr * H * W, 9 * C)   # k = tap*C + c
+        out = torch.zeros((cols.shape[0], 64), dtype=torch.float32, device=sample.device)
+        out[:, : 9 * C] = cols
+        return self._o(out)
+
+    def unpack_out(self, x, V, C, Fr, H, W, dtype):
+        return x.float().reshape(V, Fr, H, W, C).permute(0, 4, 1, 2, 3).contiguous().to(dtype)
+
+    def cfg_ddim_step(self, eps_pair, x, first_frame, guidance, alpha_t, alpha_prev):
+        n = x.shape[0]
+        eu, et = eps_pair[:n], eps_pair[n:]
+        e = eu + guidance * (et - eu)
+        x0 = (x - math.sqrt(1 - alpha_t) * e) / math.sqrt(alpha_t)
+        y = math.sqrt(alpha_prev) * x0 + math.sqrt(1 - alpha_prev) * e
+        y[:, :, 0] = first_frame.reshape(n, x.shape[1], x.shape[3], x.shape[4])
+        return y
