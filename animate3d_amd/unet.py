@@ -279,7 +279,9 @@ class MVUNetMotionModel(nn.Module):
         p1, p2 = a1.processor, a2.processor
         if p1.kind not in ("mvdream", "mvdream_i2v") or p2.kind != "ip_adapter":
             raise TypeError("Transformer2D layers need a MVDream(I2V) processor on attn1 and an IPAdapter processor on attn2")
-        qkv = [a1.to_q.weight, a1.to_k.weight, a1.to_v.weight]
+        # fused projection rows ordered [K; V; Q; Q_i2v]: K|V and Q|Q_i2v are each one contiguous row range,
+        # so the view-sharded path can run them as two GEMMs (K|V is what gets all-gathered)
+        qkv = [a1.to_k.weight, a1.to_v.weight, a1.to_q.weight]
         i2v = p1.kind == "mvdream_i2v"
         if i2v:
             qkv.append(p1.to_q_i2v.weight)
@@ -320,7 +322,7 @@ class MVUNetMotionModel(nn.Module):
                 o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)),
                 pe_t=self._w(pe), alpha=None)
             if pr.use_spatial_attn:
-                ns.qkv_sp = self._w(torch.cat([pr.to_q_sp.weight.detach(), pr.to_k_sp.weight.detach(), pr.to_v_sp.weight.detach()], 0))
+                ns.qkv_sp = self._w(torch.cat([pr.to_k_sp.weight.detach(), pr.to_v_sp.weight.detach(), pr.to_q_sp.weight.detach()], 0))   # [K; V; Q]
                 ns.osp = (self._w(pr.to_out_sp.weight), self._f(pr.to_out_sp.bias))
                 if pr.use_alpha_blender:
                     ns.alpha = float(torch.sigmoid(pr.alpha_blender.mix_factor.detach().float()).item())
@@ -400,21 +402,40 @@ class MVUNetMotionModel(nn.Module):
         k0 = RowMap(gdiv=F, ga=n * F * L, gb=0, seg_len=L, seg_stride=F * L)     # same, frame 0 of every b
         return qm, k0
 
+    def _mv_attention(self, x, w_kvq, C, V, n, F, L, heads, i2v):
+        """Multi-view attention over the n*L tokens of every (b, f) group (+ the first-frame branch).
+        ``w_kvq`` rows are [K; V; Q; (Q_i2v)].  Unsharded: one fused GEMM, K/V/Q are column views.
+        View-sharded (animate3d_amd.parallel): this rank holds n of the N views; K|V is projected
+        into its own contiguous buffer, all-gathered over the view group (RCCL) and the kernels
+        read the gathered K/V through the unsharded row map while Q stays local."""
+        ops, par = self.ops, self.parallel
+        qm, k0 = self._mv_maps(n, F, L)
+        b = V // n
+        if par is None or par.view_shards == 1:
+            kvq = ops.gemm(x, w_kvq)
+            k, v, q = kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C]
+            a = ops.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L)
+            ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L) if i2v else None
+            return a, ai
+        N = n * par.view_shards
+        kv = ops.gemm(x, w_kvq[:2 * C])                       # [rows_local, 2C], contiguous
+        qq = ops.gemm(x, w_kvq[2 * C:])                       # [rows_local, C or 2C]
+        kv_all = par.all_gather_views(kv, b)                  # [b * N*F*L, 2C] in unsharded (b n f) l order
+        km, km0 = self._mv_maps(N, F, L)
+        k, v = kv_all[:, :C], kv_all[:, C:]
+        a = ops.flash_attn(qq[:, :C], k, v, qm, km, b * F, heads, n * L, N * L)
+        ai = ops.flash_attn(qq[:, C:2 * C], k, v, qm, km0, b * F, heads, n * L, N * L) if i2v else None
+        return a, ai
+
     def _t2d(self, x, V, n, F, H, W, pk, text_rows, ip_rows, T):
         ops, g = self.ops, self.config.norm_num_groups
         B2, L, C = V * F, H * W, x.shape[1]
-        G = (V // n) * F
-        S = n * L
         h = ops.group_norm(x, B2, L, pk.norm[0], pk.norm[1], g, 1e-6, False)
         h = ops.gemm(h, pk.pin[0], pk.pin[1])
         # attn1: multi-view self-attention (+ first-frame attention)
         n1 = ops.layer_norm(h, pk.n1[0], pk.n1[1], 1e-5)
-        qkv = ops.gemm(n1, pk.qkv)
-        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C]
-        qm, k0 = self._mv_maps(n, F, L)
-        a = ops.flash_attn(q, k, v, qm, qm, G, pk.heads, S, S)
+        a, ai = self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=pk.i2v)
         if pk.i2v:
-            ai = ops.flash_attn(qkv[:, 3 * C:4 * C], k, v, qm, k0, G, pk.heads, S, S)
             a = ops.gemm(ai, pk.oi2v[0], pk.oi2v[1], residual=a)          # main + to_out_i2v(i2v)
         h = ops.gemm(a, pk.o1[0], pk.o1[1], residual=h)
         # attn2: text + IP-Adapter cross-attention, K/V projected once per video
@@ -434,11 +455,8 @@ class MVUNetMotionModel(nn.Module):
     def _motion(self, x, V, n, F, H, W, pk):
         ops, g = self.ops, self.config.norm_num_groups
         L, C = H * W, x.shape[1]
-        G = (V // n) * F
-        S = n * L
         h = ops.group_norm(x, V, F * L, pk.norm[0], pk.norm[1], g, 1e-6, False)     # 3-D GroupNorm per video
         h = ops.gemm(h, pk.pin[0], pk.pin[1])
-        qm, _ = self._mv_maps(n, F, L)
         for a in pk.attns:
             pe_t = a.pe_t[:F]
             if a.spatial:
@@ -451,8 +469,7 @@ class MVUNetMotionModel(nn.Module):
             qkv = ops.gemm(nt, a.qkv)
             at = ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
             if a.spatial:
-                qkvs = ops.gemm(ns, a.qkv_sp)
-                asp = ops.flash_attn(qkvs[:, :C], qkvs[:, C:2 * C], qkvs[:, 2 * C:], qm, qm, G, a.heads, S, S)
+                asp, _ = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False)
                 al = a.alpha
                 if al is None:                       # plain sum (use_alpha_blender = False)
                     t1 = ops.gemm(at, a.o[0], a.o[1], residual=h)
@@ -493,6 +510,22 @@ class MVUNetMotionModel(nn.Module):
             raise ValueError(f"num_frames {F} exceeds motion_max_seq_length {cfg.motion_max_seq_length}")
         P = self._packed if self._packed is not None else self._pack()
         dev, adt = sample.device, ops.act_dtype
+        img_embeds = None if added_cond_kwargs is None else added_cond_kwargs.get("image_embeds")
+        if torch.is_tensor(timestep) and timestep.numel() not in (1, V):
+            raise ValueError(f"timestep must be a scalar or have one entry per video, got {tuple(timestep.shape)}")
+        # multi-GPU: cut this rank's (b, view) shard out of the full call (animate3d_amd.parallel)
+        par = self.parallel if (self.parallel is not None and self.parallel.world > 1) else None
+        V_full, n_full = V, n
+        if par is not None:
+            par.configure(V // n, n)
+            idx = par.local_videos(V, n).to(dev)
+            sample = sample.index_select(0, idx)
+            encoder_hidden_states = encoder_hidden_states.to(dev).index_select(0, idx)
+            camera = None if camera is None else camera.to(dev).index_select(0, idx)
+            img_embeds = None if img_embeds is None else img_embeds.to(dev).index_select(0, idx)
+            if torch.is_tensor(timestep) and timestep.numel() == V:
+                timestep = timestep.to(dev).reshape(-1).index_select(0, idx)
+            V, n = idx.numel(), n // par.view_shards
         B2 = V * F
 
         # 1. time / camera embedding (unet_motion_mv_model.py:706-752)
@@ -529,11 +562,10 @@ class MVUNetMotionModel(nn.Module):
         text_rows = encoder_hidden_states.to(device=dev, dtype=adt).reshape(V * T, -1).contiguous()
         ip_rows = []
         if self.encoder_hid_proj is not None and cfg.encoder_hid_dim_type == "ip_image_proj":
-            if added_cond_kwargs is None or "image_embeds" not in added_cond_kwargs:
+            if img_embeds is None:
                 raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which requires the "
                                  "keyword argument `image_embeds` to be passed in  `added_conditions`")
-            img = added_cond_kwargs["image_embeds"]
-            img = img.to(device=dev, dtype=adt).reshape(V, -1).contiguous()
+            img = img_embeds.to(device=dev, dtype=adt).reshape(V, -1).contiguous()
             pr = ops.gemm(img, P.ip[0], P.ip[1]).reshape(V * cfg.ip_num_tokens, cfg.cross_attention_dim)
             ip_rows.append(ops.layer_norm(pr, P.ip[2], P.ip[3], P.ip[4]))
 
@@ -569,6 +601,8 @@ class MVUNetMotionModel(nn.Module):
         x, _, _ = ops.conv3x3(x, B2, h_, w_, P.conv_out[0], P.conv_out[1])
         out_dtype = sample.dtype if sample.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
         out = ops.unpack_out(x, V, cfg.out_channels, F, H, W, out_dtype)
+        if par is not None:
+            out = par.all_gather_output(out, V_full, n_full)
         if not return_dict:
             return (out,)
         return UNet3DConditionOutput(sample=out)

@@ -799,3 +799,31 @@ def synthetic_inputs(cfg: UNetConfig, videos: int, num_views: int, num_frames: i
     cam = get_camera(num_views).repeat(videos // num_views, 1)
     return dict(sample=sample, timestep=501, encoder_hidden_states=ehs,
                 added_cond_kwargs={"image_embeds": img}, camera=cam, num_views=num_views)
+
+
+def build_fast(cfg: UNetConfig, num_views: int, num_frames: int, latent_hw, seed: int = 0) -> "MVUNetMotionModelRef":
+    """Construct the oracle without torch's default (slow, single-threaded) parameter init: build on the
+    meta device, materialise, refill the positional buffers and draw cheap seeded uniform weights.
+    Used by bench.py's cpu_baseline leg and smoke(), where only timing / same-weights parity matter."""
+    with torch.device("meta"):
+        m = MVUNetMotionModelRef(cfg, num_views, num_frames, latent_hw)
+    m = m.to_empty(device="cpu").eval()
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, TimePosEmbed):
+                mod.pe.copy_(sinusoidal_pos_1d(mod.pe.shape[2], mod.pe.shape[1]))
+        for name, p in m.named_parameters():
+            if p.ndim >= 2:
+                b = 1.0 / math.sqrt(p[0].numel())
+                p.uniform_(-b, b)
+            elif name.endswith("mix_factor"):
+                p.uniform_(-0.5, 0.5)
+            elif name.endswith("bias"):
+                p.uniform_(-0.02, 0.02)
+            else:
+                p.uniform_(0.9, 1.1)
+        for name, p in m.named_parameters():
+            if name.endswith("to_out_i2v.weight") or name.endswith("to_out_sp.weight"):
+                p.normal_(0.0, 0.02)
+    return m

@@ -1,0 +1,61 @@
+"""CPU checks of the C-ABI boundary: the library builds for gfx950, loads, and exports exactly the
+symbols include/animate3d_hip.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "animate3d_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from animate3d_amd import build
+    return build.build(verbose=False)
+
+
+def test_header_symbols_are_exported(lib_path):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], check=True, capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (a3d_[a-z0-9_]+)", out)))
+    assert exported == _declared(), (exported, _declared())
+
+
+def test_ctypes_binding_covers_header(lib_path):
+    from animate3d_amd import hip_ops
+    assert sorted(hip_ops.EXPORTED_SYMBOLS) == _declared()
+    lib = hip_ops.load_library()
+    assert lib.a3d_version().decode().startswith("animate3d_hip gfx950")
+    assert lib.a3d_group_norm_ws_floats(2, 300, 32) == 2 * 3 * 64 + 2 * 64
+
+
+def test_code_object_is_gfx950(lib_path):
+    roc = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+    out = subprocess.run(["strings", "-a", lib_path], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    assert not re.search(r"gfx9(0a|42|40)\b", out)
+
+
+def test_product_has_no_cpu_fallback():
+    """On a box without a GPU the product op set must refuse to run rather than fall back."""
+    import torch
+    from animate3d_amd.hip_ops import HipOps
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        HipOps()
+
+
+def test_product_never_imports_oracle_or_tests():
+    pkg = os.path.join(ROOT, "animate3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", src, flags=re.M), f

@@ -1,0 +1,231 @@
+"""GPU parity tests: every entry point of libanimate3d_hip.so against the plain-PyTorch fp32 reference
+of the same op (tests/torch_ops.py) on seeded inputs, through the C-ABI (animate3d_amd/hip_ops.py).
+
+Tolerances (bf16 storage, fp32 accumulate): the reference is computed in fp32 from the SAME bf16
+inputs, so the only differences are fp32 summation order, the bf16 rounding of P in P·V and the final
+bf16 rounding of the output (relative 2^-9 = 2.0e-3).  Bars: relative L2 error <= 4e-3 for GEMM-like
+ops and attention, max-abs error <= 2 bf16 ulps of the output scale for normalisation/elementwise ops.
+"""
+import math
+
+import pytest
+import torch
+
+from animate3d_amd.hip_ops import RowMap
+from tests.torch_ops import TorchRefOps
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from animate3d_amd.hip_ops import HipOps
+    return HipOps()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return TorchRefOps(act_dtype=torch.float32, device="cuda")
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device="cuda", dtype=torch.float32) * scale).to(dtype)
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def check(name, got, want, tol=4e-3, max_ulps=None):
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert torch.isfinite(got.float()).all(), f"{name}: non-finite output"
+    e = rel_l2(got, want)
+    mx = (got.float() - want.float()).abs().max().item()
+    scale = want.float().abs().max().item()
+    print(f"[parity] {name}: rel_l2={e:.3e} max_abs={mx:.3e} (ref max {scale:.3e})")
+    assert e <= tol, f"{name}: rel L2 error {e:.3e} > {tol:.1e} (max abs {mx:.3e})"
+    if max_ulps is not None:
+        assert mx <= max_ulps * scale * 2.0 ** -8, f"{name}: max abs {mx:.3e} > {max_ulps} bf16 ulps of {scale:.3e}"
+
+
+# ------------------------------------------------------------------ GEMM / conv
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (389, 1280, 640), (8, 1280, 320), (1000, 4, 320), (128, 128, 64), (130, 2560, 1280)])
+def test_gemm_plain(ops, ref, M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    check(f"gemm {M}x{N}x{K}", ops.gemm(x, w, bias), ref.gemm(x, w, bias))
+    check(f"gemm nobias {M}x{N}x{K}", ops.gemm(x, w), ref.gemm(x, w))
+
+
+def test_gemm_epilogues_and_strides(ops, ref):
+    M, N, K = 777, 640, 320
+    big = rnd(M, 3 * K, seed=4)
+    x = big[:, K:2 * K]                       # strided A (a slice of a fused QKV buffer)
+    w, bias = rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6, dtype=torch.float32)
+    res = rnd(M, N, seed=7)
+    check("gemm residual alpha/beta", ops.gemm(x, w, bias, residual=res, alpha=0.37, beta=1.0),
+          ref.gemm(x, w, bias, residual=res, alpha=0.37, beta=1.0))
+    rb = rnd(7, N, seed=8)
+    check("gemm rowbias", ops.gemm(x, w, bias, rowbias=rb, rb_div=111), ref.gemm(x, w, bias, rowbias=rb, rb_div=111))
+    out = torch.zeros(M, 2 * N, device="cuda", dtype=BF)
+    ops.gemm(x, w, bias, out=out[:, N:])
+    check("gemm strided out", out[:, N:], ref.gemm(x, w, bias))
+    assert (out[:, :N] == 0).all()
+
+
+def test_gemm_layout_asymmetric(ops):
+    """A = I (padded) with an asymmetric W catches operand / output transposes."""
+    K = N = 64
+    x = torch.eye(K, device="cuda", dtype=BF)
+    w = (torch.arange(N * K, device="cuda", dtype=torch.float32).reshape(N, K) % 251 - 125).to(BF)
+    y = ops.gemm(x, w)
+    assert torch.equal(y, w.t().contiguous())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(2, 8, 12, 64, 128, 1, False), (3, 8, 8, 128, 64, 2, False),
+                                                      (2, 6, 4, 64, 320, 1, True), (1, 16, 16, 320, 4, 1, False),
+                                                      (2, 5, 7, 64, 64, 2, False)])
+def test_conv3x3(ops, ref, B, H, W, Cin, Cout, stride, up):
+    x = rnd(B * H * W, Cin, seed=1)
+    w = rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=3, dtype=torch.float32)
+    y, Ho, Wo = ops.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up)
+    yr, Hr, Wr = ref.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up)
+    assert (Ho, Wo) == (Hr, Wr)
+    check(f"conv {B}x{H}x{W} {Cin}->{Cout} s{stride} up{int(up)}", y, yr)
+
+
+def test_conv3x3_epilogue(ops, ref):
+    B, H, W, Cin, Cout = 4, 8, 8, 64, 128
+    x, w = rnd(B * H * W, Cin, seed=1), rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5)
+    bias, rb, res = rnd(Cout, seed=3, dtype=torch.float32), rnd(2, Cout, seed=4), rnd(B * H * W, Cout, seed=5)
+    y, _, _ = ops.conv3x3(x, B, H, W, w, bias, rowbias=rb, rb_div=2 * H * W, residual=res)
+    yr, _, _ = ref.conv3x3(x, B, H, W, w, bias, rowbias=rb, rb_div=2 * H * W, residual=res)
+    check("conv rowbias+residual", y, yr)
+
+
+# ------------------------------------------------------------------ attention
+def _mv_maps(n, F, L):
+    return RowMap(F, n * F * L, L, L, F * L), RowMap(F, n * F * L, 0, L, F * L)
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+@pytest.mark.parametrize("b,n,F,L", [(1, 2, 3, 64), (2, 2, 2, 16), (1, 1, 2, 4), (1, 4, 2, 256), (1, 3, 2, 100)])
+def test_flash_attn_multiview_and_first_frame(ops, ref, D, b, n, F, L):
+    heads = 8
+    C = heads * D
+    rows = b * n * F * L
+    qkv = rnd(rows, 3 * C, seed=D + L)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    qm, k0 = _mv_maps(n, F, L)
+    S = n * L
+    check(f"mv attn D{D} b{b} n{n} F{F} L{L}", ops.flash_attn(q, k, v, qm, qm, b * F, heads, S, S),
+          ref.flash_attn(q, k, v, qm, qm, b * F, heads, S, S))
+    check(f"i2v attn D{D} b{b} n{n} F{F} L{L}", ops.flash_attn(q, k, v, qm, k0, b * F, heads, S, S),
+          ref.flash_attn(q, k, v, qm, k0, b * F, heads, S, S))
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_flash_attn_cross_text_ip(ops, ref, D):
+    heads, V, F, L, T = 8, 2, 3, 64, 77
+    C = heads * D
+    q = rnd(V * F * L, C, seed=1)
+    kvt, kvi = rnd(V * T, 2 * C, seed=2), rnd(V * 4, 2 * C, seed=3)
+    qc = RowMap(1, L, 0, L, 0)
+    o = ops.flash_attn(q, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), V * F, heads, L, T)
+    o_r = ref.flash_attn(q, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), V * F, heads, L, T)
+    check(f"text cross-attn D{D}", o, o_r)
+    ops.flash_attn(q, kvi[:, :C], kvi[:, C:], qc, RowMap(F, 4, 0, 4, 0), V * F, heads, L, 4, out=o, out_scale=0.7, accumulate=True)
+    o_r2 = ref.flash_attn(q, kvi[:, :C], kvi[:, C:], qc, RowMap(F, 4, 0, 4, 0), V * F, heads, L, 4, out=o_r.clone(), out_scale=0.7, accumulate=True)
+    check(f"text+ip cross-attn D{D}", o, o_r2, tol=6e-3)
+
+
+def test_flash_attn_rescale_branch(ops, ref):
+    """One key per tile far above the rest forces the running-max rescale at a chosen tile."""
+    heads, D, L = 8, 40, 512
+    C = heads * D
+    q, k, v = rnd(L, C, seed=1), rnd(L, C, seed=2), rnd(L, C, seed=3)
+    for t, row in enumerate((70, 200, 450)):
+        k[row] = q[5 + t] * (4.0 + 2 * t)
+    m = RowMap(1, L, 0, L, 0)
+    check("attn rescale spikes", ops.flash_attn(q, k, v, m, m, 1, heads, L, L), ref.flash_attn(q, k, v, m, m, 1, heads, L, L))
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+@pytest.mark.parametrize("V,F,L", [(2, 3, 16), (1, 4, 64), (2, 16, 64), (1, 32, 8)])
+def test_temporal_attn(ops, ref, D, V, F, L):
+    heads = 8
+    C = heads * D
+    qkv = rnd(V * F * L, 3 * C, seed=F + D)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    check(f"temporal attn D{D} V{V} F{F} L{L}", ops.temporal_attn(q, k, v, V, F, L, heads), ref.temporal_attn(q, k, v, V, F, L, heads))
+
+
+# ------------------------------------------------------------------ normalisation
+@pytest.mark.parametrize("B,rows,C", [(3, 64, 320), (2, 300, 640), (2, 256, 960), (1, 1000, 1280), (2, 64, 1920), (2, 16, 2560), (1, 4, 1280)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm(ops, ref, B, rows, C, silu):
+    x = rnd(B * rows, C, seed=C) + 0.5
+    gamma = 1 + 0.1 * rnd(C, seed=1, dtype=torch.float32)
+    beta = 0.1 * rnd(C, seed=2, dtype=torch.float32)
+    check(f"group_norm B{B} rows{rows} C{C} silu{int(silu)}", ops.group_norm(x, B, rows, gamma, beta, 32, 1e-5, silu),
+          ref.group_norm(x, B, rows, gamma, beta, 32, 1e-5, silu), tol=4e-3, max_ulps=3)
+
+
+@pytest.mark.parametrize("M,C", [(10, 320), (257, 640), (64, 1280), (8, 768)])
+def test_layer_norm(ops, ref, M, C):
+    x = rnd(M, C, seed=C) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=1, dtype=torch.float32), 0.1 * rnd(C, seed=2, dtype=torch.float32)
+    check(f"layer_norm {M}x{C}", ops.layer_norm(x, gamma, beta, 1e-5), ref.layer_norm(x, gamma, beta, 1e-5), max_ulps=3)
+    pe1, pe2 = rnd(3, C, seed=3), rnd(5, C, seed=4)
+    y1, y2 = ops.layer_norm(x, gamma, beta, 1e-5, pe1=pe1, pe1_div=4, pe2=pe2, pe2_div=1, two=True)
+    r1, r2 = ref.layer_norm(x, gamma, beta, 1e-5, pe1=pe1, pe1_div=4, pe2=pe2, pe2_div=1, two=True)
+    check(f"layer_norm+pe1 {M}x{C}", y1, r1, max_ulps=3)
+    check(f"layer_norm+pe2 {M}x{C}", y2, r2, max_ulps=3)
+
+
+# ------------------------------------------------------------------ elementwise / layout
+def test_geglu_silu_concat(ops, ref):
+    x = rnd(333, 2560, seed=1) * 2
+    check("geglu", ops.geglu(x), ref.geglu(x), max_ulps=3)
+    s = rnd(40, 1280, seed=2) * 3
+    check("silu", ops.silu(s), ref.silu(s), max_ulps=3)
+    a, b = rnd(100, 640, seed=3), rnd(100, 320, seed=4)
+    assert torch.equal(ops.concat(a, b), torch.cat([a, b], 1))
+
+
+def test_timestep_embed(ops, ref):
+    t = torch.tensor([0.0, 1.0, 501.0, 961.0, 999.0], device="cuda")
+    check("timestep", ops.timestep_embed(t, 320), ref.timestep_embed(t, 320), tol=3e-3, max_ulps=3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_im2col_and_unpack(ops, ref, dtype):
+    s = rnd(2, 4, 3, 8, 16, seed=1, dtype=dtype)
+    got, want = ops.im2col_in(s), ref.im2col_in(s).to(BF)
+    assert torch.equal(got, want)
+    x = rnd(2 * 3 * 8 * 16, 4, seed=2)
+    assert torch.equal(ops.unpack_out(x, 2, 4, 3, 8, 16, dtype), ref.unpack_out(x, 2, 4, 3, 8, 16, dtype))
+
+
+def test_cfg_ddim_step(ops, ref):
+    n, C, F, H, W = 2, 4, 3, 8, 8
+    eps, x = rnd(2 * n, C, F, H, W, seed=1, dtype=torch.float32), rnd(n, C, F, H, W, seed=2, dtype=torch.float32)
+    first = rnd(n, C, 1, H, W, seed=3, dtype=torch.float32)
+    got = ops.cfg_ddim_step(eps, x, first, 7.5, 0.31, 0.42)
+    want = ref.cfg_ddim_step(eps, x.clone(), first, 7.5, 0.31, 0.42)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_bad_arguments_raise(ops):
+    with pytest.raises(RuntimeError):
+        ops.gemm(rnd(8, 100), rnd(16, 100))                    # K % 64 != 0
+    with pytest.raises(RuntimeError):
+        ops.gemm(rnd(8, 64, dtype=torch.float32), rnd(16, 64))  # not bf16
+    q = rnd(64, 8 * 48)
+    with pytest.raises(RuntimeError):
+        ops.flash_attn(q, q, q, RowMap(1, 64, 0, 64, 0), RowMap(1, 64, 0, 64, 0), 1, 8, 64, 64)   # head_dim 48

@@ -37,8 +37,7 @@ def test_state_dict_keys_match_oracle_exactly():
 def test_missing_key_count_motion_only_checkpoint():
     """inference.py:214-223: loading a motion-modules-only checkpoint must report 726 missing keys on the
     full-width model (SURVEY.md §8c KAT 1).  Checked on key names only (meta device, no memory)."""
-    with torch.device("meta"):
-        model = MVUNetMotionModel(UNetConfig())
+    model = MVUNetMotionModel(UNetConfig(), device="meta")
     keys = list(model.state_dict().keys())
     saved = [k for k in keys if "i2v." in k or "motion_modules." in k]       # train.yaml:34-36 trainable subset
     assert len(keys) - len(saved) == 726

@@ -1,0 +1,95 @@
+"""GPU end-to-end parity of the MI355X UNet forward (HIP kernels, bf16) against
+
+  (1) the CPU oracle (fp32 restatement of the reference forward, oracle/unet_ref.py), and
+  (2) the same host logic executed with plain-torch ops that round to bf16 at the same points
+      (tests/torch_ops.py) — separates "kernel is wrong" from "bf16 is coarse".
+
+Real SD1.5 widths (320/640/1280/1280, head dims 40/80/160 — the only ones the attention kernels
+implement) at a small latent, so the oracle finishes in seconds.
+
+Stated tolerance (north_star: "within stated fp16/bf16 tolerance"): bf16 carries 8 significant bits
+(rounding 2^-9 = 0.2 % per store) through ~600 dependent kernels per step;
+bars: relative L2 error vs the fp32 oracle <= 3e-2, vs the bf16-rounding emulation <= 1.5e-2.
+"""
+import pytest
+import torch
+
+from animate3d_amd.config import UNetConfig
+from animate3d_amd.unet import MVUNetMotionModel
+from oracle import unet_ref as O
+from tests.torch_ops import TorchRefOps
+
+pytestmark = pytest.mark.gpu
+
+N_VIEWS, FRAMES, HW = 2, 3, (16, 16)
+
+
+@pytest.fixture(scope="module")
+def models():
+    torch.manual_seed(0)
+    ocfg = O.UNetConfig()
+    ref = O.MVUNetMotionModelRef(ocfg, N_VIEWS, FRAMES, HW).eval()
+    O.init_synthetic_weights(ref, seed=0, dense=True)
+    sd = ref.state_dict()
+    hip = MVUNetMotionModel(UNetConfig(), num_views=N_VIEWS, device="cuda")
+    missing, unexpected = hip.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    hip = hip.to(torch.bfloat16).eval()
+    emu = MVUNetMotionModel(UNetConfig(), num_views=N_VIEWS, device="cuda", ops=TorchRefOps(torch.bfloat16, "cuda"))
+    emu.load_state_dict(sd, strict=True)
+    emu = emu.to(torch.bfloat16).eval()
+    return ocfg, ref, hip, emu
+
+
+def _cuda(inp):
+    out = {}
+    for k, v in inp.items():
+        if torch.is_tensor(v):
+            out[k] = v.cuda()
+        elif isinstance(v, dict):
+            out[k] = {kk: vv.cuda() for kk, vv in v.items()}
+        else:
+            out[k] = v
+    return out
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm()).item(), (a - b).abs().max().item(), b.abs().max().item()
+
+
+@pytest.mark.parametrize("videos,seed,cond0", [(2, 1, False), (4, 2, False), (2, 3, True)])
+def test_forward_parity(models, videos, seed, cond0):
+    ocfg, ref, hip, emu = models
+    inp = O.synthetic_inputs(ocfg, videos, N_VIEWS, FRAMES, HW, seed=seed, cfg_doubled=videos >= 2 * N_VIEWS)
+    y_ref = ref(**inp, i2v_cond_time_zero=cond0).sample
+    y_hip = hip(**_cuda(inp), i2v_cond_time_zero=cond0).sample
+    y_emu = emu(**_cuda(inp), i2v_cond_time_zero=cond0).sample
+    assert y_hip.shape == y_ref.shape and y_hip.dtype == torch.float32 and y_hip.is_cuda
+    assert torch.isfinite(y_hip).all()
+    e_or, mx_or, sc = _rel(y_hip, y_ref)
+    e_em, mx_em, _ = _rel(y_hip, y_emu)
+    e_emu_or, _, _ = _rel(y_emu, y_ref)
+    print(f"[parity] unet V={videos} cond0={cond0}: hip-vs-oracle rel_l2={e_or:.3e} max_abs={mx_or:.3e} (|ref|max {sc:.3e}); "
+          f"hip-vs-bf16emu rel_l2={e_em:.3e} max_abs={mx_em:.3e}; bf16emu-vs-oracle rel_l2={e_emu_or:.3e}")
+    assert e_or <= 3e-2, f"HIP vs fp32 oracle: {e_or:.3e}"
+    assert e_em <= 1.5e-2, f"HIP vs bf16-rounding emulation: {e_em:.3e}"
+
+
+def test_output_dtype_and_determinism(models):
+    ocfg, ref, hip, _ = models
+    inp = _cuda(O.synthetic_inputs(ocfg, 2, N_VIEWS, FRAMES, HW, seed=5))
+    inp["sample"] = inp["sample"].to(torch.bfloat16)
+    a = hip(**inp).sample
+    b = hip(**inp).sample
+    assert a.dtype == torch.bfloat16 and torch.equal(a, b)
+
+
+def test_loaded_native_library():
+    """The .so that ran must be the in-tree one (no silent fallback)."""
+    import os
+    from animate3d_amd import hip_ops
+    lib = hip_ops.load_library()
+    assert lib.a3d_version().decode().startswith("animate3d_hip gfx950")
+    with open("/proc/self/maps") as f:
+        assert any(os.path.basename(hip_ops.lib_path()) in line for line in f)
