@@ -5,21 +5,31 @@
 // regrouping, the first-frame K/V selection of the I2V branch and the per-video text/IP tokens
 // are all just different maps over the same [rows, C] tensors (no rearrange copies).
 //
-// Structure (one 256-thread workgroup = 4 waves; each wave owns 32 query rows, KV tiles of 64):
+// Structure (one 256-thread workgroup = 4 waves; each wave owns 32 query rows; KV tiles of BKV keys):
 //   * S^T = K · Q^T with v_mfma_f32_32x32x16_bf16: A = K rows from LDS (16-B reads, padded rows),
 //     B = Q^T held in registers for the whole kernel.  The result layout gives every lane ONE
-//     query (lane&31) and 16 keys, so row max / row sum are in-lane plus one exchange with
-//     lane^32 — no LDS, no butterfly.
+//     query (lane&31) and 16 keys per 32-key sub-tile, so row max is in-lane plus one exchange
+//     with lane^32 — no LDS, no butterfly.
 //   * The K row that feeds MFMA row i is permuted (kperm) so that the 8 scores a lane holds in
 //     registers 8j..8j+7 are 8 CONSECUTIVE keys: P^T then is directly the B operand of
 //     O^T = V^T · P^T (no cross-lane movement), and the matching A operand is one 16-B read of
 //     a V^T image in LDS.  V is transposed while it is staged (4 keys x 8 dims per thread,
 //     8-byte LDS writes).
 //   * O^T accumulators keep the query in lane&31 too, so the online-softmax rescale is a plain
-//     per-lane multiply.
-//   * K/V tile t+1 is fetched global->registers while tile t is being consumed.
+//     per-lane multiply — and it is skipped (wave-uniform branch) whenever no running max grew.
+//   * Row sums come out of the matrix pipe: for D = 40 / 80 the V^T image has spare rows (O^T is
+//     computed in 32-row tiles), one of them holds ones, so O^T[row D] = sum_k P — the same
+//     bf16-rounded P that multiplies V, rescaled together with O.
+//   * K/V images are double-buffered in LDS: tile t+1 is written (from registers filled during
+//     the previous iteration) and tile t+2 is requested from HBM/L2 before tile t's MFMAs start;
+//     one barrier per tile.  Per-thread source pointers advance incrementally (no div/mod, no
+//     64-bit multiplies in the loop); only the last tile carries clamp + mask code.
 //   * grid.x = heads * q_tiles with the head fastest: with 8 heads block b runs on XCD b%8 =
 //     head, so all q-tiles of one (group, head) share one XCD's L2 copy of that K/V.
+//   ALIGNED = a KV tile never straddles a row-map segment (seg_len % BKV == 0, or one segment);
+//   the generic variant (small low-resolution levels only) recomputes rows with 32-bit div/mod.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -29,9 +39,8 @@ constexpr int BQ = 128;
 struct AttnParams {
   const uint16_t* Q; const uint16_t* K; const uint16_t* V; uint16_t* O;
   a3d_rowmap qm, km, om;
-  int heads; int64_t q_len, kv_len;
+  int heads; int q_len, kv_len;
   float scale_log2, out_scale; int accumulate;
-  int q_tiles; int kv_aligned;
 };
 
 A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
@@ -45,7 +54,7 @@ A3D_DEV int kperm(int i) {
   return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
 }
 
-template <int D, int BKV>
+template <int D, int BKV, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
   constexpr int NU = BKV / 32;             // 32-key sub-tiles per KV tile
   constexpr int VROW = BKV + 8;            // V^T image row stride (elements): odd number of 16-B slots
@@ -58,10 +67,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   constexpr int KPT = (KCHUNKS + 255) / 256;
   constexpr int VITEMS = (BKV / 4) * DCH;  // V staging items (4 keys x 8 dims)
   constexpr int VPT = (VITEMS + 255) / 256;
-  static_assert((KROW / 8) % 2 == 1, "K row stride must be an odd number of 16-B slots");
+  constexpr bool ONES = MT * 32 > D;       // spare V^T row available for the row sums
+  constexpr int KS_ELEMS = BKV * KROW, VT_ELEMS = MT * 32 * VROW;
+  static_assert((KROW / 8) % 2 == 1 && (VROW / 8) % 2 == 1, "LDS row strides must be an odd number of 16-B slots");
 
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[BKV * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[MT * 32 * VROW];
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (KS_ELEMS + VT_ELEMS)];
+  uint16_t* const Ks0 = smem;
+  uint16_t* const Vt0 = smem + 2 * KS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
@@ -70,16 +82,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   const int64_t grp = blockIdx.y;
   const int64_t hoff = (int64_t)head * D;
 
-  // zero the contraction padding of the K image once (columns D..DK-1 are never staged)
+  // one-time LDS init: zero the contraction padding of both K images, ones row of both V^T images
   if constexpr (DK > D) {
-    for (int i = tid; i < BKV * (DK - D); i += 256) {
-      const int r = i / (DK - D), c = i % (DK - D);
-      Ks[r * KROW + D + c] = 0;
+    for (int i = tid; i < 2 * BKV * (DK - D); i += 256) {
+      const int b = i / (BKV * (DK - D)), rem = i % (BKV * (DK - D));
+      Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + rem % (DK - D)] = 0;
     }
+  }
+  if constexpr (ONES) {
+    for (int i = tid; i < 2 * BKV; i += 256) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = 0x3F80;   // bf16 1.0
   }
 
   // ---- Q^T fragments: lane (q = l31, half g) holds Q[q][16*ks + 8*g .. +7]
-  const int64_t q_idx = (int64_t)qt * BQ + wid * 32 + l31;
+  const int q_idx = qt * BQ + wid * 32 + l31;
   const bool q_ok = q_idx < p.q_len;
   const int64_t q_row = map_row(p.qm, grp, q_ok ? q_idx : p.q_len - 1);
   u32x4_t qf[KS];
@@ -90,66 +105,84 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     else qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
   }
 
-  // ---- K/V row addressing.  Fast path (kv_aligned): a 64-key tile never straddles a segment, so
-  //      the tile's first row is wave-uniform and advanced incrementally; otherwise 32-bit
-  //      div/mod per staged row (only the small low-resolution levels take that path).
+  // ---- K/V staging: per-thread source pointers, advanced tile by tile
+  const int64_t ld = p.km.ld;
   const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
-  const uint32_t kseg_len = (uint32_t)p.km.seg_len;
-  int64_t tile_base = kgbase;      // row of the tile's first key (aligned path)
-  uint32_t tile_off = 0;           // its offset inside the segment
-  const uint16_t* Kh = p.K + hoff;
-  const uint16_t* Vh = p.V + hoff;
-  auto kv_row = [&](int64_t kv0, int r) -> int64_t {
-    int64_t s = kv0 + r;
+  const uint16_t* const Kh = p.K + hoff;
+  const uint16_t* const Vh = p.V + hoff;
+  const uint32_t seg_len = (uint32_t)p.km.seg_len;
+  const int64_t tile_step = (int64_t)BKV * ld;                                  // elements per tile
+  const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;             // extra jump at a segment end
+  int kr[KPT], kc[KPT], vq[VPT], vc[VPT];
+  const uint16_t* kptr[KPT];
+  const uint16_t* vptr[VPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int c = tid + 256 * i;
+    kr[i] = c / DCH; kc[i] = c % DCH;
+    kptr[i] = Kh + (kgbase + kr[i]) * ld + kc[i] * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int it = tid + 256 * i;
+    vq[i] = it / DCH; vc[i] = it % DCH;
+    vptr[i] = Vh + (kgbase + vq[i] * 4) * ld + vc[i] * 8;
+  }
+  uint32_t seg_off = 0;     // offset of the NEXT tile to load inside its segment (ALIGNED path)
+  int next_kv0 = 0;         // first key of the next tile to load
+
+  auto row_generic = [&](int s) -> int64_t {      // clamp + 32-bit div/mod (generic path, tails)
     if (s >= p.kv_len) s = p.kv_len - 1;
-    if (p.kv_aligned) return tile_base + (s - kv0);
-    const uint32_t su = (uint32_t)s;
-    const uint32_t seg = su / kseg_len;
-    return kgbase + (int64_t)seg * p.km.seg_stride + (su - seg * kseg_len);
+    const uint32_t seg = (uint32_t)s / seg_len;
+    return kgbase + (int64_t)seg * p.km.seg_stride + ((uint32_t)s - seg * seg_len);
   };
 
-  // ---- staging registers
   u32x4_t kreg[KPT];
   u32x4_t vreg[VPT][4];
-  auto load_kv = [&](int64_t t) {
-    const int64_t kv0 = t * BKV;
+  auto load_kv = [&](auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    if constexpr (ALIGNED && !TAIL) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      const int c = tid + 256 * i;
-      if (c < KCHUNKS) {
-        const int r = c / DCH, ch = c % DCH;
-        kreg[i] = *reinterpret_cast<const u32x4_t*>(Kh + kv_row(kv0, r) * p.km.ld + ch * 8);
-      }
+      for (int i = 0; i < KPT; ++i)
+        if (tid + 256 * i < KCHUNKS) kreg[i] = *reinterpret_cast<const u32x4_t*>(kptr[i]);
+#pragma unroll
+      for (int i = 0; i < VPT; ++i)
+        if (tid + 256 * i < VITEMS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vreg[i][r] = *reinterpret_cast<const u32x4_t*>(vptr[i] + r * ld);
+        }
+      // advance to the next tile (wave-uniform wrap test)
+      seg_off += BKV;
+      int64_t step = tile_step;
+      if (seg_off >= seg_len) { step += wrap_step; seg_off = 0; }
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) kptr[i] += step;
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) vptr[i] += step;
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i)
+        if (tid + 256 * i < KCHUNKS)
+          kreg[i] = *reinterpret_cast<const u32x4_t*>(Kh + row_generic(next_kv0 + kr[i]) * ld + kc[i] * 8);
+#pragma unroll
+      for (int i = 0; i < VPT; ++i)
+        if (tid + 256 * i < VITEMS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            vreg[i][r] = *reinterpret_cast<const u32x4_t*>(Vh + row_generic(next_kv0 + vq[i] * 4 + r) * ld + vc[i] * 8);
+        }
     }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int it = tid + 256 * i;
-      if (it < VITEMS) {
-        const int qd = it / DCH, ch = it % DCH;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          vreg[i][r] = *reinterpret_cast<const u32x4_t*>(Vh + kv_row(kv0, qd * 4 + r) * p.km.ld + ch * 8);
-      }
-    }
-    // advance the uniform tile cursor
-    tile_off += BKV;
-    tile_base += BKV;
-    if (tile_off >= kseg_len) { tile_base += p.km.seg_stride - (int64_t)tile_off; tile_off = 0; }
+    next_kv0 += BKV;
   };
-  auto store_kv = [&]() {
+  auto store_kv = [&](int buf) {
+    uint16_t* const Ks = Ks0 + buf * KS_ELEMS;
+    uint16_t* const Vt = Vt0 + buf * VT_ELEMS;
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      const int c = tid + 256 * i;
-      if (c < KCHUNKS) {
-        const int r = c / DCH, ch = c % DCH;
-        *reinterpret_cast<u32x4_t*>(Ks + r * KROW + ch * 8) = kreg[i];
-      }
-    }
+    for (int i = 0; i < KPT; ++i)
+      if (tid + 256 * i < KCHUNKS) *reinterpret_cast<u32x4_t*>(Ks + kr[i] * KROW + kc[i] * 8) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int it = tid + 256 * i;
-      if (it < VITEMS) {
-        const int qd = it / DCH, ch = it % DCH;
+    for (int i = 0; i < VPT; ++i)
+      if (tid + 256 * i < VITEMS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {   // word j of each row holds dims 2j (lo) and 2j+1 (hi)
           const uint32_t w0 = vreg[i][0][j], w1 = vreg[i][1][j], w2 = vreg[i][2][j], w3 = vreg[i][3][j];
@@ -158,11 +191,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           even[1] = (w2 & 0xffffu) | (w3 << 16);
           odd[0] = (w0 >> 16) | (w1 & 0xffff0000u);
           odd[1] = (w2 >> 16) | (w3 & 0xffff0000u);
-          *reinterpret_cast<u32x2_t*>(Vt + (ch * 8 + 2 * j) * VROW + qd * 4) = even;
-          *reinterpret_cast<u32x2_t*>(Vt + (ch * 8 + 2 * j + 1) * VROW + qd * 4) = odd;
+          *reinterpret_cast<u32x2_t*>(Vt + (vc[i] * 8 + 2 * j) * VROW + vq[i] * 4) = even;
+          *reinterpret_cast<u32x2_t*>(Vt + (vc[i] * 8 + 2 * j + 1) * VROW + vq[i] * 4) = odd;
         }
       }
-    }
   };
 
   f32x16_t oacc[MT];
@@ -171,18 +203,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const int krow_off = kperm(l31) * KROW + 8 * g;
+  const int vrow_off = l31 * VROW + 8 * g;
 
-  const int64_t ntiles = (p.kv_len + BKV - 1) / BKV;
-  const int krow = kperm(l31);
-  load_kv(0);
-
-  for (int64_t t = 0; t < ntiles; ++t) {
-    __syncthreads();          // everyone is done reading the previous tile
-    store_kv();
-    __syncthreads();
-    if (t + 1 < ntiles) load_kv(t + 1);
-
-    // ---- S^T = K · Q^T for the two 32-key sub-tiles
+  auto compute = [&](int buf, int kv0, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    const uint16_t* const Ks = Ks0 + buf * KS_ELEMS + krow_off;
+    const uint16_t* const Vt = Vt0 + buf * VT_ELEMS + vrow_off;
+    // ---- S^T = K · Q^T for the NU 32-key sub-tiles
     f32x16_t sacc[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -190,20 +218,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
       for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + (32 * u + krow) * KROW + 16 * ks + 8 * g);
+        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
         sacc[u] = mfma32(kf, qf[ks], sacc[u]);
       }
     }
-    // ---- mask keys past kv_len (only the last tile can have any)
-    const int64_t kv0 = t * BKV;
-    if (kv0 + BKV > p.kv_len) {
+    if constexpr (TAIL) {      // keys past kv_len
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t kv = kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7);
-          if (kv >= p.kv_len) sacc[u][r] = -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) >= p.kv_len) sacc[u][r] = -INFINITY;
     }
     // ---- online softmax (log2 domain); the query lives in lane&31, its other half in lane^32
     float mx = sacc[0][0];
@@ -212,11 +236,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-    const float mneg = -m_new * p.scale_log2;
-    m_run = m_new;
-    float psum = 0.f;
+    if (__any(mx > m_run)) {           // some running max grew: rescale everything held at the old max
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+      m_run = m_new;
+      if constexpr (!ONES) l_run *= alpha;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+    }
+    const float mneg = -m_run * p.scale_log2;
     u32x4_t pf[NU][2];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -224,32 +254,64 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], p.scale_log2, mneg));
-        psum += pv[r];
+        if constexpr (!ONES) l_run += pv[r];
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) pf[u][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
-    // ---- O^T += V^T · P^T
+    // ---- O^T += V^T · P^T   (row D of V^T is all ones: O^T[D] accumulates the row sums)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + (32 * mt + l31) * VROW + 32 * u + 16 * h + 8 * g);
+          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
           oacc[mt] = mfma32(vf, pf[u][h], oacc[mt]);
         }
+  };
+
+  const int ntiles = (p.kv_len + BKV - 1) / BKV;
+  const bool has_tail = (p.kv_len % BKV) != 0;
+  auto load_tile = [&](int t) {     // t = index of the tile being requested
+    if (has_tail && t == ntiles - 1) load_kv(std::true_type{}); else load_kv(std::false_type{});
+  };
+
+  // ---- prologue: tile 0 into buffer 0, tile 1 in flight
+  load_tile(0);
+  store_kv(0);
+  if (ntiles > 1) load_tile(1);
+  __syncthreads();
+  const int nfast = has_tail ? ntiles - 1 : ntiles;     // tiles the incremental-pointer path may load
+  int t = 0;
+  if constexpr (ALIGNED) {
+    for (; t + 2 < nfast; ++t) {                         // steady state: no clamp, no mask, no div/mod
+      store_kv((t + 1) & 1);                             // registers hold tile t+1 (requested one iteration ago)
+      load_kv(std::false_type{});                        // tile t+2
+      compute(t & 1, t * BKV, std::false_type{});
+      __syncthreads();
+    }
   }
+  for (; t < ntiles - 1; ++t) {                          // generic / last iterations
+    store_kv((t + 1) & 1);
+    if (t + 2 < ntiles) load_tile(t + 2);
+    compute(t & 1, t * BKV, std::false_type{});
+    __syncthreads();
+  }
+  if (has_tail) compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::true_type{});
+  else compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::false_type{});
 
   // ---- finalize: lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j]
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  if constexpr (ONES) {
+    constexpr int LM = D / 32, LR = ((D % 32) / 8) * 4;       // O^T row D sits in half g = 0, register LR of tile LM
+    static_assert((D % 32) % 8 == 0, "row D must map to half 0");
+    l_tot = __shfl(oacc[LM][LR], l31);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
   const float inv = p.out_scale / l_tot;
   if (q_ok) {
     uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
@@ -279,6 +341,12 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
 
+template <int D, int BKV>
+void launch(bool aligned, dim3 grid, hipStream_t s, const AttnParams& p) {
+  if (aligned) flash_attn_kernel<D, BKV, true><<<grid, dim3(256), 0, s>>>(p);
+  else flash_attn_kernel<D, BKV, false><<<grid, dim3(256), 0, s>>>(p);
+}
+
 }  // namespace
 
 extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
@@ -289,22 +357,21 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
   if (!map_ok(qmap, head_dim) || !map_ok(kmap, head_dim) || !map_ok(omap, head_dim)) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15u) return A3D_EINVAL;
   if (reinterpret_cast<uintptr_t>(O) & 7u) return A3D_EINVAL;
-  if (groups > 65535) return A3D_EINVAL;
+  if (groups > 65535 || q_len > 0x3fffffffLL || kv_len > 0x3fffffffLL || kmap->seg_len > 0x3fffffffLL) return A3D_EINVAL;
   AttnParams p{};
   p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.O = (uint16_t*)O;
   p.qm = *qmap; p.km = *kmap; p.om = *omap;
-  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len;
+  p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len;
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate;
-  p.q_tiles = (int)((q_len + BQ - 1) / BQ);
+  const int q_tiles = (int)((q_len + BQ - 1) / BQ);
   const int bkv = head_dim == 160 ? 32 : 64;
-  p.kv_aligned = (kmap->seg_len % bkv == 0 || kv_len <= kmap->seg_len) ? 1 : 0;
-  if (kv_len > 0x7fffffffLL || kmap->seg_len > 0x7fffffffLL) return A3D_EINVAL;
-  const dim3 grid((unsigned)(heads * p.q_tiles), (unsigned)groups), block(256);
+  const bool aligned = (kmap->seg_len % bkv == 0) || (kv_len <= kmap->seg_len);
+  const dim3 grid((unsigned)(heads * q_tiles), (unsigned)groups);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
-    case 40: flash_attn_kernel<40, 64><<<grid, block, 0, s>>>(p); break;
-    case 80: flash_attn_kernel<80, 64><<<grid, block, 0, s>>>(p); break;
-    case 160: flash_attn_kernel<160, 32><<<grid, block, 0, s>>>(p); break;
+    case 40: launch<40, 64>(aligned, grid, s, p); break;
+    case 80: launch<80, 64>(aligned, grid, s, p); break;
+    case 160: launch<160, 32>(aligned, grid, s, p); break;
     default: return A3D_EUNSUPPORTED;
   }
   return a3d_launch_status();

@@ -15,15 +15,15 @@ struct GNParams {
 };
 
 __global__ void gn_partial_kernel(const GNParams p) {
-  extern __shared__ float sred[];            // [groups][2]
-  const int c8 = threadIdx.x, ry = threadIdx.y, ny = blockDim.y;
+  // dynamic LDS: per-thread partials [ny][c8][4] = (sum_lo, sq_lo, sum_hi, sq_hi); reduced in a fixed order
+  // (deterministic: no atomics), one thread per group.
+  extern __shared__ float spart[];
+  const int c8 = threadIdx.x, ry = threadIdx.y, nx = blockDim.x, ny = blockDim.y;
   const int b = blockIdx.y, chunk = blockIdx.x;
-  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < p.groups * 2; i += blockDim.x * blockDim.y) sred[i] = 0.f;
-  __syncthreads();
   const int64_t r0 = (int64_t)chunk * GN_ROWS_PER_BLOCK;
   const int64_t r1 = (r0 + GN_ROWS_PER_BLOCK < p.rows) ? r0 + GN_ROWS_PER_BLOCK : p.rows;
   const int ch0 = c8 * 8;
-  const int g_lo = ch0 / p.cg, g_hi = (ch0 + 7) / p.cg;     // a chunk touches at most 2 groups (cg >= 8)
+  const int g_lo = ch0 / p.cg;                              // a chunk touches at most 2 groups (cg >= 8)
   const int split = (g_lo + 1) * p.cg - ch0;                // first `split` channels belong to g_lo
   float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
   const uint16_t* base = p.X + ((int64_t)b * p.rows) * p.C + ch0;
@@ -35,15 +35,23 @@ __global__ void gn_partial_kernel(const GNParams p) {
       if (j < split) { s_lo += f; q_lo += f * f; } else { s_hi += f; q_hi += f * f; }
     }
   }
-  atomicAdd(&sred[g_lo * 2 + 0], s_lo);
-  atomicAdd(&sred[g_lo * 2 + 1], q_lo);
-  if (g_hi != g_lo) {
-    atomicAdd(&sred[g_hi * 2 + 0], s_hi);
-    atomicAdd(&sred[g_hi * 2 + 1], q_hi);
-  }
+  float* mine = spart + ((size_t)ry * nx + c8) * 4;
+  mine[0] = s_lo; mine[1] = q_lo; mine[2] = s_hi; mine[3] = q_hi;
   __syncthreads();
-  float* out = p.partial + ((int64_t)b * p.nchunk + chunk) * p.groups * 2;
-  for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < p.groups * 2; i += blockDim.x * blockDim.y) out[i] = sred[i];
+  const int t = ry * nx + c8;
+  if (t < p.groups) {
+    const int grp = t;
+    const int cfirst = (grp * p.cg) / 8, clast = ((grp + 1) * p.cg - 1) / 8;    // chunks touching this group
+    float s = 0.f, q = 0.f;
+    for (int y = 0; y < ny; ++y)
+      for (int c = cfirst; c <= clast; ++c) {
+        const float* src = spart + ((size_t)y * nx + c) * 4;
+        const int lo_grp = (c * 8) / p.cg;
+        if (lo_grp == grp) { s += src[0]; q += src[1]; } else { s += src[2]; q += src[3]; }
+      }
+    float* out = p.partial + (((int64_t)b * p.nchunk + chunk) * p.groups + grp) * 2;
+    out[0] = s; out[1] = q;
+  }
 }
 
 __global__ void gn_finalize_kernel(const GNParams p) {
@@ -197,9 +205,10 @@ extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, 
   p.partial = ws; p.stats = ws + (int64_t)B * p.nchunk * groups * 2;
   const int c8 = C / 8;
   int ny = 256 / c8; if (ny < 1) ny = 1; if (ny > 32) ny = 32;
+  if (c8 * ny < groups) return A3D_EINVAL;
   const dim3 block(c8, ny), grid(p.nchunk, B);
   hipStream_t s = (hipStream_t)stream;
-  gn_partial_kernel<<<grid, block, groups * 2 * sizeof(float), s>>>(p);
+  gn_partial_kernel<<<grid, block, (size_t)c8 * ny * 4 * sizeof(float), s>>>(p);
   gn_finalize_kernel<<<dim3(B), dim3((groups + 63) / 64 * 64), 0, s>>>(p);
   gn_apply_kernel<<<grid, block, 0, s>>>(p);
   return a3d_launch_status();

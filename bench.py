@@ -31,8 +31,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-FLOP_PER_STEP_CONFIG2 = 394.78e12   # SURVEY.md Appendix C (1 MAC = 2 FLOP)
-FLOP_PER_STEP_CONFIG1 = 6.45e12
 
 
 def make_inputs(cfg, V, n, F, hw, device, seed=1):
@@ -73,21 +71,31 @@ class TimedOps:
         return out
 
 
-def cpu_baseline(cores):
-    """Oracle forward on BASELINE config 1 (1 view x 4 frames x 64x64 latent, fp32, no CFG): 6.45 TFLOP."""
+def cpu_baseline(threads):
+    """Bounded CPU sample: the oracle (plain-PyTorch fp32 restatement of the reference forward) on
+    BASELINE config 1 at the reference's own default resolution (1 view x 4 frames x 32x32 latent = 256^2 px,
+    no CFG; 1.25 TFLOP), timed on `threads` host threads.  Scaled figures are FLOP-ratio extrapolations."""
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.flops import step_flops
     from oracle import unet_ref as O
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     cfg = O.UNetConfig()
-    ref = O.build_fast(cfg, 1, 4, (64, 64), seed=0)
-    inp = O.synthetic_inputs(cfg, 1, 1, 4, (64, 64), seed=1)
+    hw = (32, 32)
+    ref = O.build_fast(cfg, 1, 4, hw, seed=None)      # constant weights: timing only
+    inp = O.synthetic_inputs(cfg, 1, 1, 4, hw, seed=1)
     t0 = time.time()
     ref(**inp)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": "1 forward of BASELINE config 1 (1 view x 4 frames x 64x64 latent, fp32, no CFG; 6.45 TFLOP/step = 1/61 of the "
-                      "GPU workload's 394.8 TFLOP/step); CPU oracle = plain-PyTorch restatement of the reference forward",
-            "seconds_per_step": dt, "tflops": FLOP_PER_STEP_CONFIG1 / dt / 1e12,
-            "config2_equivalent_steps_per_s": (1.0 / dt) * FLOP_PER_STEP_CONFIG1 / FLOP_PER_STEP_CONFIG2}
+    f_sample = step_flops(UNetConfig(), 1, 1, 4, *hw)["total"]
+    f_cfg1 = step_flops(UNetConfig(), 1, 1, 4, 64, 64)["total"]
+    f_cfg2 = step_flops(UNetConfig(), 8, 4, 16, 64, 64)["total"]
+    return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 forward, 1 view x 4 frames x 32x32 latent, fp32, no CFG ({f_sample / 1e12:.2f} TFLOP/step; BASELINE config 1 "
+                      f"at the reference's default 256^2 resolution); CPU oracle = plain-PyTorch restatement of the reference forward "
+                      f"(the reference itself needs diffusers/xformers, absent offline); host has {os.cpu_count()} logical CPUs",
+            "seconds_per_step": dt, "tflops": f_sample / dt / 1e12,
+            "config1_equivalent_steps_per_s": (1.0 / dt) * f_sample / f_cfg1,
+            "config2_equivalent_steps_per_s": (1.0 / dt) * f_sample / f_cfg2}
 
 
 def main():
@@ -99,6 +107,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default min(host CPUs, 16))")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,7 +176,8 @@ def main():
         roofline = None
 
     if rank == 0:
-        work = FLOP_PER_STEP_CONFIG2 if (n, F, hw) == (4, 16, (64, 64)) else None
+        from animate3d_amd.flops import step_flops
+        work = step_flops(cfg, V, n, F, *hw)["total"]      # 394.78 TFLOP at config 2
         line = {
             "metric": "UNet denoise-steps/sec, 4view x 16frame x 512^2 MV-VDM", "value": value, "unit": "denoise-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -176,12 +186,12 @@ def main():
                                    f"batch V={V} videos, one MVUNetMotionModel.forward per step, SD1.5 MV-VDM UNet 1.53 B params, "
                                    "seeded synthetic weights",
                        "parallelism": "single GPU" if world == 1 else f"cfg{model.parallel.cfg_shards} x views{model.parallel.view_shards} (K|V all-gather over RCCL)"},
-            "whole_step_tflops": (work * value / 1e12) if work else None,
-            "whole_step_mfma_frac": (work * value / 1e12 / (PEAK_BF16_TFLOPS * world)) if work else None,
+            "flop_per_step": work, "whole_step_tflops": work * value / 1e12,
+            "whole_step_mfma_frac": work * value / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(os.cpu_count() or 1, 16))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

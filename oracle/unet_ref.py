@@ -801,13 +801,21 @@ def synthetic_inputs(cfg: UNetConfig, videos: int, num_views: int, num_frames: i
                 added_cond_kwargs={"image_embeds": img}, camera=cam, num_views=num_views)
 
 
-def build_fast(cfg: UNetConfig, num_views: int, num_frames: int, latent_hw, seed: int = 0) -> "MVUNetMotionModelRef":
+def build_fast(cfg: UNetConfig, num_views: int, num_frames: int, latent_hw, seed: Optional[int] = 0) -> "MVUNetMotionModelRef":
     """Construct the oracle without torch's default (slow, single-threaded) parameter init: build on the
     meta device, materialise, refill the positional buffers and draw cheap seeded uniform weights.
     Used by bench.py's cpu_baseline leg and smoke(), where only timing / same-weights parity matter."""
     with torch.device("meta"):
         m = MVUNetMotionModelRef(cfg, num_views, num_frames, latent_hw)
     m = m.to_empty(device="cpu").eval()
+    if seed is None:      # timing only: constant fill (values do not change the FLOPs; avoids drawing 1.5e9 randoms)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, TimePosEmbed):
+                    mod.pe.copy_(sinusoidal_pos_1d(mod.pe.shape[2], mod.pe.shape[1]))
+            for name, p in m.named_parameters():
+                p.fill_(1.0 / math.sqrt(p[0].numel()) / 3 if p.ndim >= 2 else (0.0 if name.endswith(("bias", "mix_factor")) else 1.0))
+        return m
     torch.manual_seed(seed)
     with torch.no_grad():
         for mod in m.modules():
