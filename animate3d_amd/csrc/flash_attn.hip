@@ -41,6 +41,7 @@ struct AttnParams {
   a3d_rowmap qm, km, om;
   int heads; int q_len, kv_len;
   float scale_log2, out_scale; int accumulate;
+  float thr_raw;     // lazy-max threshold in raw score units
 };
 
 A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
@@ -54,7 +55,12 @@ A3D_DEV int kperm(int i) {
   return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
 }
 
-template <int D, int BKV, bool ALIGNED>
+// VAR bits: 1 = per-32-key-sub-tile online softmax (lets QK^T of the next sub-tile / PV of the previous one run
+//           under the softmax VALU work), 2 = lazy running max (exchange + rescale only when a score exceeds the
+//           running max by more than thr_raw), 4 = s_setprio(1) around MFMA groups.
+constexpr int V_SUB = 1, V_LAZY = 2, V_PRIO = 4;
+
+template <int D, int BKV, bool ALIGNED, int VAR>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
   constexpr int NU = BKV / 32;             // 32-key sub-tiles per KV tile
   constexpr int VROW = BKV + 8;            // V^T image row stride (elements): odd number of 16-B slots
@@ -229,48 +235,94 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         for (int r = 0; r < 16; ++r)
           if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) >= p.kv_len) sacc[u][r] = -INFINITY;
     }
-    // ---- online softmax (log2 domain); the query lives in lane&31, its other half in lane^32
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (__any(mx > m_run)) {           // some running max grew: rescale everything held at the old max
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-      m_run = m_new;
-      if constexpr (!ONES) l_run *= alpha;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
-    }
-    const float mneg = -m_run * p.scale_log2;
-    u32x4_t pf[NU][2];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      float pv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], p.scale_log2, mneg));
-        if constexpr (!ONES) l_run += pv[r];
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pf[u][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
-    }
-    // ---- O^T += V^T · P^T   (row D of V^T is all ones: O^T[D] accumulates the row sums)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    if constexpr ((VAR & V_SUB) == 0) {
+      // ---- whole-tile online softmax (log2 domain); the query lives in lane&31, its other half in lane^32
+      float mx = sacc[0][0];
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
-          oacc[mt] = mfma32(vf, pf[u][h], oacc[mt]);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (__any(mx > m_run)) {           // some running max grew: rescale everything held at the old max
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+        m_run = m_new;
+        if constexpr (!ONES) l_run *= alpha;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+      }
+      const float mneg = -m_run * p.scale_log2;
+      u32x4_t pf[NU][2];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], p.scale_log2, mneg));
+          if constexpr (!ONES) l_run += pv[r];
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf[u][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
+      }
+      // ---- O^T += V^T · P^T   (row D of V^T is all ones: O^T[D] accumulates the row sums)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+            oacc[mt] = mfma32(vf, pf[u][h], oacc[mt]);
+          }
+    } else {
+      // ---- one online-softmax step per 32-key sub-tile: sub-tile u's VALU work has the QK^T MFMAs of the later
+      //      sub-tiles and the PV MFMAs of sub-tile u-1 in flight underneath it.
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        float mx = sacc[u][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
+        bool grow;
+        if constexpr ((VAR & V_LAZY) != 0) grow = mx > m_run + p.thr_raw;      // this lane's 16 keys only; the vote covers the pair
+        else { mx = fmaxf(mx, __shfl_xor(mx, 32)); grow = mx > m_run; }
+        if (__any(grow)) {
+          if constexpr ((VAR & V_LAZY) != 0) mx = fmaxf(mx, __shfl_xor(mx, 32));
+          const float m_new = fmaxf(m_run, mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+          m_run = m_new;
+          if constexpr (!ONES) l_run *= alpha;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+        }
+        const float mneg = -m_run * p.scale_log2;
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], p.scale_log2, mneg));
+          if constexpr (!ONES) l_run += pv[r];
+        }
+        u32x4_t pf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf[h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
+        if constexpr ((VAR & V_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+            oacc[mt] = mfma32(vf, pf[h], oacc[mt]);
+          }
+        if constexpr ((VAR & V_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+      }
+    }
   };
 
   const int ntiles = (p.kv_len + BKV - 1) / BKV;
@@ -341,13 +393,21 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
 
-template <int D, int BKV>
+int g_flash_variant = 0;   // a3d_tune_flash(); 0 = default
+
+template <int D, int BKV, int VAR>
 void launch(bool aligned, dim3 grid, hipStream_t s, const AttnParams& p) {
-  if (aligned) flash_attn_kernel<D, BKV, true><<<grid, dim3(256), 0, s>>>(p);
-  else flash_attn_kernel<D, BKV, false><<<grid, dim3(256), 0, s>>>(p);
+  if (aligned) flash_attn_kernel<D, BKV, true, VAR><<<grid, dim3(256), 0, s>>>(p);
+  else flash_attn_kernel<D, BKV, false, 0><<<grid, dim3(256), 0, s>>>(p);
 }
 
 }  // namespace
+
+extern "C" int a3d_tune_flash(int variant) {
+  if (variant < 0 || variant > 5) return A3D_EINVAL;
+  g_flash_variant = variant;
+  return A3D_OK;
+}
 
 extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                                    const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
@@ -364,14 +424,35 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len;
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate;
   const int q_tiles = (int)((q_len + BQ - 1) / BQ);
-  const int bkv = head_dim == 160 ? 32 : 64;
+  p.thr_raw = 3.0f / p.scale_log2;        // lazy max: tolerate P up to 2^3
+  const int var = g_flash_variant;
+  const bool big = (var == 4 || var == 5) && head_dim == 40;
+  const int bkv = head_dim == 160 ? 32 : (big ? 128 : 64);
   const bool aligned = (kmap->seg_len % bkv == 0) || (kv_len <= kmap->seg_len);
   const dim3 grid((unsigned)(heads * q_tiles), (unsigned)groups);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
-    case 40: launch<40, 64>(aligned, grid, s, p); break;
-    case 80: launch<80, 64>(aligned, grid, s, p); break;
-    case 160: launch<160, 32>(aligned, grid, s, p); break;
+    case 40:
+      switch (var) {
+        case 1: launch<40, 64, V_SUB>(aligned, grid, s, p); break;
+        case 2: launch<40, 64, V_SUB | V_LAZY>(aligned, grid, s, p); break;
+        case 3: launch<40, 64, V_SUB | V_LAZY | V_PRIO>(aligned, grid, s, p); break;
+        case 4: launch<40, 128, V_SUB | V_LAZY>(aligned, grid, s, p); break;
+        case 5: launch<40, 128, V_SUB | V_LAZY | V_PRIO>(aligned, grid, s, p); break;
+        default: launch<40, 64, 0>(aligned, grid, s, p); break;
+      }
+      break;
+    case 80:
+      switch (var) {
+        case 0: launch<80, 64, 0>(aligned, grid, s, p); break;
+        case 1: launch<80, 64, V_SUB>(aligned, grid, s, p); break;
+        case 3: case 5: launch<80, 64, V_SUB | V_LAZY | V_PRIO>(aligned, grid, s, p); break;
+        default: launch<80, 64, V_SUB | V_LAZY>(aligned, grid, s, p); break;
+      }
+      break;
+    case 160:
+      if (var == 0) launch<160, 32, 0>(aligned, grid, s, p); else launch<160, 32, V_SUB | V_LAZY>(aligned, grid, s, p);
+      break;
     default: return A3D_EUNSUPPORTED;
   }
   return a3d_launch_status();

@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""In-process A/B micro-benchmarks of the dominant kernels on one MI355X (HIP events on the launch stream,
+interleaved rounds, median reported).  Usage:  python tools/microbench.py [flash] [gemm] [conv] [misc]"""
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from animate3d_amd.hip_ops import HipOps, RowMap  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device="cuda", dtype=torch.float32) * scale).to(BF)
+
+
+def timeit(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return statistics.median(ts), min(ts)
+
+
+def bench_flash(ops):
+    print("== flash attention variants (multi-view map; median ms / TFLOP/s; err = rel L2 vs variant 0)")
+    for (D, n, F, L, b) in [(40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4, 16, 256, 2)]:
+        heads, C = 8, 8 * D
+        rows = b * n * F * L
+        qkv = rnd(rows, 3 * C)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        qm = RowMap(F, n * F * L, L, L, F * L)
+        S, G = n * L, b * F
+        flops = 4.0 * G * S * S * C
+        ops.lib.a3d_tune_flash(0)
+        ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+        for var in range(6):
+            ops.lib.a3d_tune_flash(var)
+            out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+            err = ((out - ref).norm() / ref.norm()).item()
+            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5 if D == 40 else 10)
+            print(f"D={D:3d} S={S:5d} G={G} var={var}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
+        ops.lib.a3d_tune_flash(0)
+
+
+def bench_gemm(ops):
+    print("== GEMM  Y[M,N] = X[M,K] W[N,K]^T (+bias +residual); median ms / TFLOP/s")
+    shapes = [(524288, 1280, 320), (524288, 320, 320), (524288, 2560, 320), (524288, 320, 1280), (524288, 960, 320),
+              (131072, 2560, 640), (131072, 640, 640), (131072, 5120, 640), (131072, 640, 2560),
+              (32768, 5120, 1280), (32768, 1280, 1280), (32768, 10240, 1280), (32768, 1280, 5120), (8192, 1280, 1280), (8192, 10240, 1280)]
+    for (M, N, K) in shapes:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N)
+        med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res), reps=7)
+        fl = 2.0 * M * N * K
+        print(f"M={M:7d} N={N:5d} K={K:5d}: {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s (best {fl / mn / 1e9:7.1f})")
+
+
+def bench_conv(ops):
+    print("== conv3x3 NHWC implicit GEMM; median ms / TFLOP/s")
+    shapes = [(128, 64, 64, 320, 320, 1, False), (128, 64, 64, 960, 320, 1, False), (128, 64, 64, 640, 320, 1, False),
+              (128, 32, 32, 640, 640, 1, False), (128, 32, 32, 1920, 640, 1, False), (128, 16, 16, 1280, 1280, 1, False),
+              (128, 16, 16, 2560, 1280, 1, False), (128, 8, 8, 2560, 1280, 1, False), (128, 64, 64, 320, 320, 2, False),
+              (128, 32, 32, 640, 640, 1, True), (128, 64, 64, 320, 4, 1, False)]
+    for (B, H, W, Cin, Cout, st, up) in shapes:
+        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
+        bias = torch.randn(Cout, device="cuda")
+        med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
+        He, We = (2 * H, 2 * W) if up else (H, W)
+        Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
+        fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
+        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s (best {fl / mn / 1e9:7.1f})")
+
+
+def bench_misc(ops):
+    print("== memory-bound kernels at level 0 ([524288, 320] tokens); median ms / effective GB/s (algorithmic bytes)")
+    M, C, V, F, L = 524288, 320, 8, 16, 4096
+    x = rnd(M, C)
+    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    med, _ = timeit(lambda: ops.group_norm(x, 128, L, g, b, 32, 1e-5, True)); print(f"group_norm 2D     : {med:7.3f} ms  {3 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    med, _ = timeit(lambda: ops.group_norm(x, V, F * L, g, b, 32, 1e-6, False)); print(f"group_norm 3D     : {med:7.3f} ms  {3 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    med, _ = timeit(lambda: ops.layer_norm(x, g, b, 1e-5)); print(f"layer_norm        : {med:7.3f} ms  {2 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    pe1, pe2 = rnd(F, C), rnd(L, C)
+    med, _ = timeit(lambda: ops.layer_norm(x, g, b, 1e-5, pe1=pe1, pe1_div=L, pe2=pe2, pe2_div=1, two=True)); print(f"layer_norm 2 outs : {med:7.3f} ms  {3 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    u = rnd(M, 8 * C)
+    med, _ = timeit(lambda: ops.geglu(u)); print(f"geglu             : {med:7.3f} ms  {M * 12 * C * 2 / med / 1e6:7.0f} GB/s")
+    qkv = rnd(M, 3 * C)
+    med, _ = timeit(lambda: ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, 8)); print(f"temporal_attn D40 : {med:7.3f} ms  {4 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    a, bb = rnd(M, 640), rnd(M, 320)
+    med, _ = timeit(lambda: ops.concat(a, bb)); print(f"concat 640+320    : {med:7.3f} ms  {2 * M * 960 * 2 / med / 1e6:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["flash", "gemm", "conv", "misc"]
+    torch.manual_seed(0)
+    ops = HipOps()
+    print(torch.cuda.get_device_name(0))
+    for w in which:
+        {"flash": bench_flash, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc}[w](ops)
