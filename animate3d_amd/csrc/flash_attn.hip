@@ -5,43 +5,45 @@
 // regrouping, the first-frame K/V selection of the I2V branch and the per-video text/IP tokens
 // are all just different maps over the same [rows, C] tensors (no rearrange copies).
 //
-// Structure (one 256-thread workgroup = 4 waves; each wave owns 32 query rows; KV tiles of BKV keys):
-//   * S^T = K · Q^T with v_mfma_f32_32x32x16_bf16: A = K rows from LDS (16-B reads, padded rows),
-//     B = Q^T held in registers for the whole kernel.  The result layout gives every lane ONE
-//     query (lane&31) and 16 keys per 32-key sub-tile, so row max is in-lane plus one exchange
-//     with lane^32 — no LDS, no butterfly.
-//   * The K row that feeds MFMA row i is permuted (kperm) so that the 8 scores a lane holds in
-//     registers 8j..8j+7 are 8 CONSECUTIVE keys: P^T then is directly the B operand of
-//     O^T = V^T · P^T (no cross-lane movement), and the matching A operand is one 16-B read of
-//     a V^T image in LDS.  V is transposed while it is staged (4 keys x 8 dims per thread,
-//     8-byte LDS writes).
-//   * O^T accumulators keep the query in lane&31 too, so the online-softmax rescale is a plain
-//     per-lane multiply — and it is skipped (wave-uniform branch) whenever no running max grew.
-//   * Row sums come out of the matrix pipe: for D = 40 / 80 the V^T image has spare rows (O^T is
-//     computed in 32-row tiles), one of them holds ones, so O^T[row D] = sum_k P — the same
-//     bf16-rounded P that multiplies V, rescaled together with O.
-//   * K/V images are double-buffered in LDS: tile t+1 is written (from registers filled during
-//     the previous iteration) and tile t+2 is requested from HBM/L2 before tile t's MFMAs start;
-//     one barrier per tile.  Per-thread source pointers advance incrementally (no div/mod, no
-//     64-bit multiplies in the loop); only the last tile carries clamp + mask code.
-//   * grid.x = heads * q_tiles with the head fastest: with 8 heads block b runs on XCD b%8 =
-//     head, so all q-tiles of one (group, head) share one XCD's L2 copy of that K/V.
-//   ALIGNED = a KV tile never straddles a row-map segment (seg_len % BKV == 0, or one segment);
-//   the generic variant (small low-resolution levels only) recomputes rows with 32-bit div/mod.
+// Structure (one 256-thread workgroup = 4 waves; each wave owns QT x 32 query rows; KV tiles of BKV keys):
+//   * S^T = K · Q^T with v_mfma_f32_32x32x16_bf16: A = K rows from LDS (16-B reads, padded rows), B = Q^T held
+//     in registers for the whole kernel; one K fragment feeds the MFMAs of all QT query sub-tiles.  The result
+//     layout gives every lane ONE query per sub-tile (lane&31) and 16 keys per 32-key sub-tile.
+//   * The K row that feeds MFMA row i is permuted (kperm) so that the 8 scores a lane holds in registers
+//     8j..8j+7 are 8 CONSECUTIVE keys: P^T then is directly the B operand of O^T = V^T · P^T (no cross-lane
+//     movement), and the matching A operand is one 16-B read of a V^T image in LDS (V is transposed while it is
+//     staged: 4 keys x 8 dims per thread, v_perm_b32 + 8-byte LDS writes).
+//   * The measured limiter of the first versions was VALU issue (~13 VALU per MFMA), so the softmax is stripped
+//     to one v_exp + half a v_cvt_pk + half a v_max3 per score:
+//       - Q is pre-multiplied by scale*log2(e) when its fragments are loaded (once per kernel);
+//       - the running-max offset is subtracted INSIDE the matrix pipe: for D = 40 the contraction is padded to
+//         48 anyway, so K gets a constant-1 column and Q carries -m in that slot (OFS_PAD); for D = 80 the
+//         offset enters as the MFMA's C operand (OFS_ACC).  P = exp2(S') needs no fma;
+//       - the max is lazy: the offset only moves (exchange with lane^32, rescale O, re-base S') when some score
+//         exceeds it by more than 2^3 — one wave vote per tile on the common path;
+//       - row sums come out of the matrix pipe: a spare V^T row holds ones, so O^T[row D] = sum_k P.
+//   * O^T accumulators keep the query in lane&31 too, so the (rare) rescale is a plain per-lane multiply.
+//   * K/V images are double-buffered in LDS: tile t+1 is written (from registers filled during the previous
+//     iteration) and tile t+2 is requested from HBM/L2 before tile t's MFMAs start; one barrier per tile.
+//     Per-thread source pointers advance incrementally; only the last tile carries clamp + mask code.
+//   * grid.x = heads * q_tiles with the head fastest: with 8 heads block b runs on XCD b%8 = head, so all
+//     q-tiles of one (group, head) share one XCD's L2 copy of that K/V.
+//   ALIGNED = a KV tile never straddles a row-map segment (seg_len % BKV == 0, or one segment); the generic
+//   variant (small low-resolution levels only) recomputes rows with 32-bit div/mod.
 #include <type_traits>
 
 #include "common.h"
 
 namespace {
 
-constexpr int BQ = 128;
+constexpr int OFS_FMA = 0, OFS_PAD = 1, OFS_ACC = 2;
+constexpr float LAZY_THR = 3.0f;     // log2 units: P may reach 2^3 before the offset moves
 
 struct AttnParams {
   const uint16_t* Q; const uint16_t* K; const uint16_t* V; uint16_t* O;
   a3d_rowmap qm, km, om;
   int heads; int q_len, kv_len;
   float scale_log2, out_scale; int accumulate;
-  float thr_raw;     // lazy-max threshold in raw score units
 };
 
 A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
@@ -55,12 +57,9 @@ A3D_DEV int kperm(int i) {
   return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
 }
 
-// VAR bits: 1 = per-32-key-sub-tile online softmax (lets QK^T of the next sub-tile / PV of the previous one run
-//           under the softmax VALU work), 2 = lazy running max (exchange + rescale only when a score exceeds the
-//           running max by more than thr_raw), 4 = s_setprio(1) around MFMA groups.
-constexpr int V_SUB = 1, V_LAZY = 2, V_PRIO = 4;
+A3D_DEV float bf16_round(float x) { return lo_bf(pack2bf(x, 0.f)); }
 
-template <int D, int BKV, bool ALIGNED, int VAR>
+template <int D, int BKV, int QT, int OFS, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
   constexpr int NU = BKV / 32;             // 32-key sub-tiles per KV tile
   constexpr int VROW = BKV + 8;            // V^T image row stride (elements): odd number of 16-B slots
@@ -75,7 +74,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   constexpr int VPT = (VITEMS + 255) / 256;
   constexpr bool ONES = MT * 32 > D;       // spare V^T row available for the row sums
   constexpr int KS_ELEMS = BKV * KROW, VT_ELEMS = MT * 32 * VROW;
+  constexpr int BQW = 32 * QT, BQ = 4 * BQW;
+  constexpr int KS_PAD = D / 16, G_PAD = (D % 16) / 8;    // fragment slot of contraction index D (OFS_PAD)
   static_assert((KROW / 8) % 2 == 1 && (VROW / 8) % 2 == 1, "LDS row strides must be an odd number of 16-B slots");
+  static_assert(OFS != OFS_PAD || (DK > D && D % 8 == 0), "OFS_PAD needs a spare contraction slot");
+  static_assert(OFS != OFS_FMA || QT == 1, "the fma variant keeps one query sub-tile per wave");
 
   __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (KS_ELEMS + VT_ELEMS)];
   uint16_t* const Ks0 = smem;
@@ -88,27 +91,41 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   const int64_t grp = blockIdx.y;
   const int64_t hoff = (int64_t)head * D;
 
-  // one-time LDS init: zero the contraction padding of both K images, ones row of both V^T images
+  // one-time LDS init: contraction padding of both K images (OFS_PAD: column D = 1.0), ones row of both V^T images
   if constexpr (DK > D) {
     for (int i = tid; i < 2 * BKV * (DK - D); i += 256) {
       const int b = i / (BKV * (DK - D)), rem = i % (BKV * (DK - D));
-      Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + rem % (DK - D)] = 0;
+      const int c = rem % (DK - D);
+      Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + c] = (OFS == OFS_PAD && c == 0) ? 0x3F80 : 0;
     }
   }
   if constexpr (ONES) {
     for (int i = tid; i < 2 * BKV; i += 256) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = 0x3F80;   // bf16 1.0
   }
 
-  // ---- Q^T fragments: lane (q = l31, half g) holds Q[q][16*ks + 8*g .. +7]
-  const int q_idx = qt * BQ + wid * 32 + l31;
-  const bool q_ok = q_idx < p.q_len;
-  const int64_t q_row = map_row(p.qm, grp, q_ok ? q_idx : p.q_len - 1);
-  u32x4_t qf[KS];
+  // ---- Q^T fragments: lane (q = l31, half g) holds Q[q][16*ks + 8*g .. +7] for each of its QT queries
+  int q_idx[QT];
+  bool q_ok[QT];
+  u32x4_t qf[QT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int d0 = 16 * ks + 8 * g;
-    if (d0 < D) qf[ks] = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + d0);
-    else qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
+  for (int qs = 0; qs < QT; ++qs) {
+    q_idx[qs] = qt * BQ + wid * BQW + qs * 32 + l31;
+    q_ok[qs] = q_idx[qs] < p.q_len;
+    const int64_t q_row = map_row(p.qm, grp, q_ok[qs] ? q_idx[qs] : p.q_len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 16 * ks + 8 * g;
+      if (d0 < D) {
+        u32x4_t w = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + d0);
+        if constexpr (OFS != OFS_FMA) {      // fold scale * log2(e) into Q once
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = pack2bf(lo_bf(w[j]) * p.scale_log2, hi_bf(w[j]) * p.scale_log2);
+        }
+        qf[qs][ks] = w;
+      } else {
+        qf[qs][ks] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+    }
   }
 
   // ---- K/V staging: per-thread source pointers, advanced tile by tile
@@ -190,25 +207,38 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     for (int i = 0; i < VPT; ++i)
       if (tid + 256 * i < VITEMS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // word j of each row holds dims 2j (lo) and 2j+1 (hi)
+        for (int j = 0; j < 4; ++j) {   // word j of each key row holds dims 2j (lo half) and 2j+1 (hi half)
           const uint32_t w0 = vreg[i][0][j], w1 = vreg[i][1][j], w2 = vreg[i][2][j], w3 = vreg[i][3][j];
-          u32x2_t even, odd;
-          even[0] = (w0 & 0xffffu) | (w1 << 16);
-          even[1] = (w2 & 0xffffu) | (w3 << 16);
-          odd[0] = (w0 >> 16) | (w1 & 0xffff0000u);
-          odd[1] = (w2 >> 16) | (w3 & 0xffff0000u);
+          u32x2_t even, odd;            // v_perm_b32: selector bytes 0-3 pick from the 2nd operand, 4-7 from the 1st
+          even[0] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+          even[1] = __builtin_amdgcn_perm(w3, w2, 0x05040100u);
+          odd[0] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+          odd[1] = __builtin_amdgcn_perm(w3, w2, 0x07060302u);
           *reinterpret_cast<u32x2_t*>(Vt + (vc[i] * 8 + 2 * j) * VROW + vq[i] * 4) = even;
           *reinterpret_cast<u32x2_t*>(Vt + (vc[i] * 8 + 2 * j + 1) * VROW + vq[i] * 4) = odd;
         }
       }
   };
 
-  f32x16_t oacc[MT];
+  f32x16_t oacc[QT][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int qs = 0; qs < QT; ++qs)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qs][mt][r] = 0.f;
+  float m_off[QT];          // OFS_PAD/ACC: offset currently subtracted from the (scaled) scores; OFS_FMA: running max
+  float l_run = 0.f;        // only when !ONES
+  f32x16_t minit[OFS == OFS_ACC ? QT : 1];
+#pragma unroll
+  for (int qs = 0; qs < QT; ++qs) m_off[qs] = (OFS == OFS_FMA) ? -INFINITY : 0.f;
+  if constexpr (OFS == OFS_ACC) {
+#pragma unroll
+    for (int qs = 0; qs < QT; ++qs)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[qs][r] = 0.f;
+  }
+  bool first = true;        // wave-uniform: no offset chosen yet
   const int krow_off = kperm(l31) * KROW + 8 * g;
   const int vrow_off = l31 * VROW + 8 * g;
 
@@ -216,16 +246,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     constexpr bool TAIL = decltype(tail_c)::value;
     const uint16_t* const Ks = Ks0 + buf * KS_ELEMS + krow_off;
     const uint16_t* const Vt = Vt0 + buf * VT_ELEMS + vrow_off;
-    // ---- S^T = K · Q^T for the NU 32-key sub-tiles
-    f32x16_t sacc[NU];
+    // ---- S'^T = K · Q'^T (- offset) for the NU 32-key sub-tiles; one K fragment feeds all QT query sub-tiles
+    f32x16_t sacc[QT][NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+      for (int qs = 0; qs < QT; ++qs) {
+        if constexpr (OFS == OFS_ACC) sacc[qs][u] = minit[qs];
+        else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[qs][u][r] = 0.f;
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
-        sacc[u] = mfma32(kf, qf[ks], sacc[u]);
+#pragma unroll
+        for (int qs = 0; qs < QT; ++qs) sacc[qs][u] = mfma32(kf, qf[qs][ks], sacc[qs][u]);
       }
     }
     if constexpr (TAIL) {      // keys past kv_len
@@ -233,95 +270,99 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) >= p.kv_len) sacc[u][r] = -INFINITY;
+          if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) >= p.kv_len) {
+#pragma unroll
+            for (int qs = 0; qs < QT; ++qs) sacc[qs][u][r] = -INFINITY;
+          }
     }
-    if constexpr ((VAR & V_SUB) == 0) {
-      // ---- whole-tile online softmax (log2 domain); the query lives in lane&31, its other half in lane^32
-      float mx = sacc[0][0];
+
+    if constexpr (OFS == OFS_FMA) {
+      // ---- D = 160: scores are raw; running max in raw units, lazy by LAZY_THR / scale_log2
+      float mx = sacc[0][0][0];
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (__any(mx > m_run)) {           // some running max grew: rescale everything held at the old max
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-        m_run = m_new;
-        if constexpr (!ONES) l_run *= alpha;
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[0][u][r]);
+      if (__any(mx > m_off[0] + LAZY_THR / p.scale_log2)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_off[0], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_off[0] - m_new) * p.scale_log2);
+        m_off[0] = m_new;
+        l_run *= alpha;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[0][mt][r] *= alpha;
       }
-      const float mneg = -m_run * p.scale_log2;
-      u32x4_t pf[NU][2];
+      const float mneg = -m_off[0] * p.scale_log2;
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        float pv[16];
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], p.scale_log2, mneg));
-          if constexpr (!ONES) l_run += pv[r];
-        }
+        for (int r = 0; r < 16; ++r) sacc[0][u][r] = fmaf(sacc[0][u][r], p.scale_log2, mneg);
+    } else {
+      // ---- lazy offset update: the common path is max + compare + one wave vote per query sub-tile; the slow
+      //      path re-bases S', rescales O and moves the offset
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pf[u][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
-      }
-      // ---- O^T += V^T · P^T   (row D of V^T is all ones: O^T[D] accumulates the row sums)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int qs = 0; qs < QT; ++qs) {
+        float mx = sacc[qs][0][0];
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
-            oacc[mt] = mfma32(vf, pf[u][h], oacc[mt]);
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
+        if (__any(first || mx > LAZY_THR)) {
+          const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
+          float delta = first ? mxp : fmaxf(mxp, 0.f);
+          float new_off = m_off[qs] + delta;
+          if constexpr (OFS == OFS_PAD) { new_off = bf16_round(new_off); delta = new_off - m_off[qs]; }
+          m_off[qs] = new_off;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[qs][u][r] -= delta;
+          if (!first) {
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            if constexpr (!ONES) l_run *= alpha;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
           }
-    } else {
-      // ---- one online-softmax step per 32-key sub-tile: sub-tile u's VALU work has the QK^T MFMAs of the later
-      //      sub-tiles and the PV MFMAs of sub-tile u-1 in flight underneath it.
+          if constexpr (OFS == OFS_PAD) {
+            if (g == G_PAD) qf[qs][KS_PAD][0] = pack2bf(-new_off, 0.f);     // contraction slot D carries -offset
+          } else {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        float mx = sacc[u][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
-        bool grow;
-        if constexpr ((VAR & V_LAZY) != 0) grow = mx > m_run + p.thr_raw;      // this lane's 16 keys only; the vote covers the pair
-        else { mx = fmaxf(mx, __shfl_xor(mx, 32)); grow = mx > m_run; }
-        if (__any(grow)) {
-          if constexpr ((VAR & V_LAZY) != 0) mx = fmaxf(mx, __shfl_xor(mx, 32));
-          const float m_new = fmaxf(m_run, mx);
-          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
-          m_run = m_new;
-          if constexpr (!ONES) l_run *= alpha;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) minit[qs][r] = -new_off;
+          }
         }
-        const float mneg = -m_run * p.scale_log2;
+      }
+      first = false;
+    }
+
+    // ---- P = exp2(S'), O^T += V^T · P^T   (row D of V^T is all ones: O^T[D] accumulates the row sums)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      u32x4_t pf[QT][2];
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs) {
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[u][r], p.scale_log2, mneg));
+          pv[r] = __builtin_amdgcn_exp2f(sacc[qs][u][r]);
           if constexpr (!ONES) l_run += pv[r];
         }
-        u32x4_t pf[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pf[h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
-        if constexpr ((VAR & V_PRIO) != 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
-            oacc[mt] = mfma32(vf, pf[h], oacc[mt]);
-          }
-        if constexpr ((VAR & V_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
+          for (int j = 0; j < 4; ++j) pf[qs][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
       }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+#pragma unroll
+          for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vf, pf[qs][h], oacc[qs][mt]);
+        }
     }
   };
 
@@ -355,37 +396,40 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   if (has_tail) compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::true_type{});
   else compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::false_type{});
 
-  // ---- finalize: lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j]
-  float l_tot;
-  if constexpr (ONES) {
-    constexpr int LM = D / 32, LR = ((D % 32) / 8) * 4;       // O^T row D sits in half g = 0, register LR of tile LM
-    static_assert((D % 32) % 8 == 0, "row D must map to half 0");
-    l_tot = __shfl(oacc[LM][LR], l31);
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32);
-  }
-  const float inv = p.out_scale / l_tot;
-  if (q_ok) {
-    uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
+  // ---- finalize: lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j] for each query sub-tile
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+  for (int qs = 0; qs < QT; ++qs) {
+    float l_tot;
+    if constexpr (ONES) {
+      constexpr int LM = D / 32, LR = ((D % 32) / 8) * 4;       // O^T row D sits in half g = 0, register LR of tile LM
+      static_assert((D % 32) % 8 == 0, "row D must map to half 0");
+      l_tot = __shfl(oacc[qs][LM][LR], l31);
+    } else {
+      l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = p.out_scale / l_tot;
+    if (q_ok[qs]) {
+      uint16_t* orow = p.O + map_row(p.om, grp, q_idx[qs]) * p.om.ld + hoff;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d = 32 * mt + 8 * qd + 4 * g;
-        if (d < D) {
-          float v[4];
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = oacc[mt][4 * qd + j] * inv;
-          if (p.accumulate) {
-            const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
-            v[0] += lo_bf(prev[0]); v[1] += hi_bf(prev[0]); v[2] += lo_bf(prev[1]); v[3] += hi_bf(prev[1]);
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d = 32 * mt + 8 * qd + 4 * g;
+          if (d < D) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv;
+            if (p.accumulate) {
+              const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
+              v[0] += lo_bf(prev[0]); v[1] += hi_bf(prev[0]); v[2] += lo_bf(prev[1]); v[3] += hi_bf(prev[1]);
+            }
+            u32x2_t o;
+            o[0] = pack2bf(v[0], v[1]);
+            o[1] = pack2bf(v[2], v[3]);
+            *reinterpret_cast<u32x2_t*>(orow + d) = o;
           }
-          u32x2_t o;
-          o[0] = pack2bf(v[0], v[1]);
-          o[1] = pack2bf(v[2], v[3]);
-          *reinterpret_cast<u32x2_t*>(orow + d) = o;
         }
-      }
+    }
   }
 }
 
@@ -393,12 +437,14 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
 
-int g_flash_variant = 0;   // a3d_tune_flash(); 0 = default
+int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default (QT = 2 for D = 40), 1 = one query sub-tile per wave
 
-template <int D, int BKV, int VAR>
-void launch(bool aligned, dim3 grid, hipStream_t s, const AttnParams& p) {
-  if (aligned) flash_attn_kernel<D, BKV, true, VAR><<<grid, dim3(256), 0, s>>>(p);
-  else flash_attn_kernel<D, BKV, false, 0><<<grid, dim3(256), 0, s>>>(p);
+template <int D, int BKV, int QT, int OFS>
+void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
+  const int q_tiles = (p.q_len + 128 * QT - 1) / (128 * QT);
+  const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
+  if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true><<<grid, dim3(256), 0, s>>>(p);
+  else flash_attn_kernel<D, BKV, QT, OFS, false><<<grid, dim3(256), 0, s>>>(p);
 }
 
 }  // namespace
@@ -423,36 +469,16 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
   p.qm = *qmap; p.km = *kmap; p.om = *omap;
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len;
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate;
-  const int q_tiles = (int)((q_len + BQ - 1) / BQ);
-  p.thr_raw = 3.0f / p.scale_log2;        // lazy max: tolerate P up to 2^3
-  const int var = g_flash_variant;
-  const bool big = (var == 4 || var == 5) && head_dim == 40;
-  const int bkv = head_dim == 160 ? 32 : (big ? 128 : 64);
+  const int bkv = head_dim == 160 ? 32 : 64;
   const bool aligned = (kmap->seg_len % bkv == 0) || (kv_len <= kmap->seg_len);
-  const dim3 grid((unsigned)(heads * q_tiles), (unsigned)groups);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
     case 40:
-      switch (var) {
-        case 1: launch<40, 64, V_SUB>(aligned, grid, s, p); break;
-        case 2: launch<40, 64, V_SUB | V_LAZY>(aligned, grid, s, p); break;
-        case 3: launch<40, 64, V_SUB | V_LAZY | V_PRIO>(aligned, grid, s, p); break;
-        case 4: launch<40, 128, V_SUB | V_LAZY>(aligned, grid, s, p); break;
-        case 5: launch<40, 128, V_SUB | V_LAZY | V_PRIO>(aligned, grid, s, p); break;
-        default: launch<40, 64, 0>(aligned, grid, s, p); break;
-      }
+      if (g_flash_variant == 1 || q_len <= 128) launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p);
+      else launch<40, 64, 2, OFS_PAD>(aligned, groups, s, p);
       break;
-    case 80:
-      switch (var) {
-        case 0: launch<80, 64, 0>(aligned, grid, s, p); break;
-        case 1: launch<80, 64, V_SUB>(aligned, grid, s, p); break;
-        case 3: case 5: launch<80, 64, V_SUB | V_LAZY | V_PRIO>(aligned, grid, s, p); break;
-        default: launch<80, 64, V_SUB | V_LAZY>(aligned, grid, s, p); break;
-      }
-      break;
-    case 160:
-      if (var == 0) launch<160, 32, 0>(aligned, grid, s, p); else launch<160, 32, V_SUB | V_LAZY>(aligned, grid, s, p);
-      break;
+    case 80: launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p); break;
+    case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;
     default: return A3D_EUNSUPPORTED;
   }
   return a3d_launch_status();

@@ -42,7 +42,7 @@ def bench_flash(ops):
         flops = 4.0 * G * S * S * C
         ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in range(6):
+        for var in range(2):
             ops.lib.a3d_tune_flash(var)
             out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
             err = ((out - ref).norm() / ref.norm()).item()
