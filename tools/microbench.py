@@ -30,9 +30,9 @@ def timeit(fn, reps=5, warm=1):
     return statistics.median(ts), min(ts)
 
 
-def bench_flash(ops):
+def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4, 16, 256, 2))):
     print("== flash attention variants (multi-view map; median ms / TFLOP/s; err = rel L2 vs variant 0)")
-    for (D, n, F, L, b) in [(40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4, 16, 256, 2)]:
+    for (D, n, F, L, b) in shapes:
         heads, C = 8, 8 * D
         rows = b * n * F * L
         qkv = rnd(rows, 3 * C)
@@ -105,4 +105,6 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc}[w](ops)
+        {"flash": bench_flash, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+         "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
+         "gemm1": lambda o: [o.gemm(rnd(131072, 640), rnd(2560, 640)) for _ in range(3)]}[w](ops)
