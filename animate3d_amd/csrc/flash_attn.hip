@@ -59,7 +59,9 @@ A3D_DEV int kperm(int i) {
 
 A3D_DEV float bf16_round(float x) { return lo_bf(pack2bf(x, 0.f)); }
 
-template <int D, int BKV, int QT, int OFS, bool ALIGNED>
+// VAR (tuning experiments, a3d_tune_flash): 1 = s_setprio(1) around MFMA groups, 2 = V fragments read before the
+// exps of their sub-tile, 4 = sched_group_barrier pattern {1 MFMA, 4 TRANS, 2 VALU} over the exp/PV section.
+template <int D, int BKV, int QT, int OFS, bool ALIGNED, int VAR>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
   constexpr int NU = BKV / 32;             // 32-key sub-tiles per KV tile
   constexpr int VROW = BKV + 8;            // V^T image row stride (elements): odd number of 16-B slots
@@ -261,8 +263,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
+        if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int qs = 0; qs < QT; ++qs) sacc[qs][u] = mfma32(kf, qf[qs][ks], sacc[qs][u]);
+        if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(0);
       }
     }
     if constexpr (TAIL) {      // keys past kv_len
@@ -341,6 +345,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     // ---- P = exp2(S'), O^T += V^T · P^T   (row D of V^T is all ones: O^T[D] accumulates the row sums)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
+      u32x4_t vfr[(VAR & 2) ? MT : 1][2];
+      if constexpr ((VAR & 2) != 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) vfr[mt][h] = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+      }
       u32x4_t pf[QT][2];
 #pragma unroll
       for (int qs = 0; qs < QT; ++qs) {
@@ -355,14 +366,26 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
           for (int j = 0; j < 4; ++j) pf[qs][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
       }
+      if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+          u32x4_t vf;
+          if constexpr ((VAR & 2) != 0) vf = vfr[mt][h];
+          else vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
 #pragma unroll
           for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vf, pf[qs][h], oacc[qs][mt]);
         }
+      if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr ((VAR & 4) != 0) {
+#pragma unroll
+      for (int i = 0; i < NU * MT * 2 * QT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);   // 4 TRANS (v_exp)
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU (v_cvt_pk)
+      }
     }
   };
 
@@ -437,14 +460,14 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
 
-int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default (QT = 2 for D = 40), 1 = one query sub-tile per wave
+int g_flash_variant = 0;   // a3d_tune_flash(): D = 40 main-loop experiments, see the switch in a3d_flash_attn_bf16
 
-template <int D, int BKV, int QT, int OFS>
+template <int D, int BKV, int QT, int OFS, int VAR = 0>
 void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
   const int q_tiles = (p.q_len + 128 * QT - 1) / (128 * QT);
   const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
-  if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true><<<grid, dim3(256), 0, s>>>(p);
-  else flash_attn_kernel<D, BKV, QT, OFS, false><<<grid, dim3(256), 0, s>>>(p);
+  if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true, VAR><<<grid, dim3(256), 0, s>>>(p);
+  else flash_attn_kernel<D, BKV, QT, OFS, false, 0><<<grid, dim3(256), 0, s>>>(p);
 }
 
 }  // namespace
@@ -474,8 +497,15 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
     case 40:
-      if (g_flash_variant == 1 || q_len <= 128) launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p);
-      else launch<40, 64, 2, OFS_PAD>(aligned, groups, s, p);
+      if (q_len <= 128) { launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p); break; }
+      switch (g_flash_variant) {
+        case 1: launch<40, 64, 2, OFS_PAD, 1>(aligned, groups, s, p); break;
+        case 2: launch<40, 64, 2, OFS_PAD, 2>(aligned, groups, s, p); break;
+        case 3: launch<40, 64, 2, OFS_PAD, 4>(aligned, groups, s, p); break;
+        case 4: launch<40, 64, 2, OFS_PAD, 5>(aligned, groups, s, p); break;
+        case 5: launch<40, 64, 1, OFS_PAD, 5>(aligned, groups, s, p); break;
+        default: launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p); break;
+      }
       break;
     case 80: launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p); break;
     case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;
