@@ -30,12 +30,31 @@ struct GemmParams {
   uint16_t* Y; int64_t ldy;
   int64_t M, N, K;
   float alpha, beta;
+  int vec16;            // output / residual / rowbias rows allow 16-byte accesses
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up;
   int64_t tiles_n, tiles_m;
 };
 
-template <bool CONV>
+constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;
+
+// erf-GELU with Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below bf16 resolution): 2 transcendentals +
+// ~10 VALU instead of libm erff's ~25-instruction polynomial ladder — this runs in a GEMM epilogue.
+A3D_DEV float gelu_erf(float gte) {
+  const float x = fabsf(gte) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+  const float erfx = fmaf(-poly, e, 1.0f);                     // erf(|g|/sqrt2)
+  const float erfs = gte < 0.f ? -erfx : erfx;
+  return 0.5f * gte * (1.0f + erfs);
+}
+
+template <bool CONV, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int tid = threadIdx.x;
@@ -153,46 +172,120 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds, per (tn, tm, quad q), 4 consecutive n for one m
+  // ---- epilogue.  Each wave transposes its 64x64 fp32 sub-tile through a private LDS region (row stride 68
+  //      floats: conflict-free ds_write_b128 from the MFMA layout) and re-reads it row-major, so that every lane
+  //      owns 8 consecutive output columns: bias / rowbias / residual / output are 16-byte accesses and one wave
+  //      instruction touches 8 full 128-byte row segments (the direct MFMA-layout epilogue issued 8-byte stores
+  //      to 32 different rows per instruction and was store-issue bound at K = 320).
+  constexpr int SROW = 68;
+  float* const stg = reinterpret_cast<float*>(smem) + wid * (64 * SROW);
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int64_t m = m0 + wm * 64 + tm * 32 + l31;
-    if (m >= p.M) continue;
-    const uint16_t* rb = p.rowbias ? p.rowbias + (m / p.rb_div) * p.N : nullptr;
+  for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int64_t n = n0 + wn * 64 + tn * 32 + 8 * q + 4 * g;
-        if (n >= p.N) continue;
-        float v[4];
+        float4 v;
+        v.x = acc[tn][tm][4 * q]; v.y = acc[tn][tm][4 * q + 1]; v.z = acc[tn][tm][4 * q + 2]; v.w = acc[tn][tm][4 * q + 3];
+        *reinterpret_cast<float4*>(stg + (tm * 32 + l31) * SROW + tn * 32 + 8 * q + 4 * g) = v;
+      }
+  __syncthreads();
+
+  if constexpr (EPI == EPI_GEGLU) {
+    // columns [0,32) of the wave's sub-tile are h, [32,64) the matching gates (weight rows are interleaved on
+    // the host): out[m][j] = (h + b_h) * gelu_erf(gate + b_g); 4 lanes x 8 columns per output row.
+    const int cc = lane & 3;
+    const int64_t nh = n0 + wn * 64 + 8 * cc;                  // column of h in the interleaved N space
+    const int64_t oc = (n0 + wn * 64) / 2 + 8 * cc;            // output column
+    if (nh + 32 < p.N + 0 && oc + 8 <= p.N / 2) {
+      float bh[8], bg[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * q + j];
-        if (p.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (rb) {
-          const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(rb + n);
-          v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
-        }
+      for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? p.bias[nh + e] : 0.f; bg[e] = p.bias ? p.bias[nh + 32 + e] : 0.f; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
-        if (p.R) {
-          const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(p.R + m * p.ldr + n);
-          v[0] += p.beta * lo_bf(rv[0]); v[1] += p.beta * hi_bf(rv[0]);
-          v[2] += p.beta * lo_bf(rv[1]); v[3] += p.beta * hi_bf(rv[1]);
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * j + (lane >> 2);
+        const int64_t m = m0 + wm * 64 + row;
+        if (m >= p.M) continue;
+        const float4 h0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
+        const float4 h1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(stg + row * SROW + 32 + 8 * cc);
+        const float4 g1 = *reinterpret_cast<const float4*>(stg + row * SROW + 32 + 8 * cc + 4);
+        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (hv[e] + bh[e]) * gelu_erf(gv[e] + bg[e]);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(y[2 * e], y[2 * e + 1]);
+        *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
+      }
+    }
+  } else {
+    const int cc = lane & 7;
+    const int64_t n = n0 + wn * 64 + 8 * cc;
+    if (n < p.N) {
+      const bool full = (n + 8 <= p.N) && p.vec16;            // else: N % 8 == 4 tail or unaligned rows -> 8-byte halves
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        const int64_t m = m0 + wm * 64 + row;
+        if (m >= p.M) continue;
+        const float4 a0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
+        const float4 a1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        const uint16_t* rb = p.rowbias ? p.rowbias + (m / p.rb_div) * p.N + n : nullptr;
+        const uint16_t* rr = p.R ? p.R + m * p.ldr + n : nullptr;
+        uint16_t* yy = p.Y + m * p.ldy + n;
+        if (full) {
+          if (rb) {
+            const u32x4_t t = *reinterpret_cast<const u32x4_t*>(rb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(t[e]); v[2 * e + 1] += hi_bf(t[e]); }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          if (rr) {
+            const u32x4_t t = *reinterpret_cast<const u32x4_t*>(rr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(t[e]); v[2 * e + 1] += p.beta * hi_bf(t[e]); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+          *reinterpret_cast<u32x4_t*>(yy) = o;
+        } else {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            if (n + 4 * hh + 4 > p.N) continue;
+            float w[4] = {v[4 * hh], v[4 * hh + 1], v[4 * hh + 2], v[4 * hh + 3]};
+            if (rb) {
+              const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rb + 4 * hh);
+              w[0] += lo_bf(t[0]); w[1] += hi_bf(t[0]); w[2] += lo_bf(t[1]); w[3] += hi_bf(t[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] *= p.alpha;
+            if (rr) {
+              const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rr + 4 * hh);
+              w[0] += p.beta * lo_bf(t[0]); w[1] += p.beta * hi_bf(t[0]); w[2] += p.beta * lo_bf(t[1]); w[3] += p.beta * hi_bf(t[1]);
+            }
+            u32x2_t o;
+            o[0] = pack2bf(w[0], w[1]);
+            o[1] = pack2bf(w[2], w[3]);
+            *reinterpret_cast<u32x2_t*>(yy + 4 * hh) = o;
+          }
         }
-        u32x2_t o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        *reinterpret_cast<u32x2_t*>(p.Y + m * p.ldy + n) = o;
       }
     }
   }
 }
 
-template <bool CONV>
+template <bool CONV, int EPI = EPI_LINEAR>
 int launch(hipStream_t stream, GemmParams& p) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
@@ -200,12 +293,12 @@ int launch(hipStream_t stream, GemmParams& p) {
   if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_kernel<CONV>, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, stream, p);
+  gemm_kernel<CONV, EPI><<<dim3((unsigned)nblk), dim3(256), SMEM_BYTES, stream>>>(p);
   return a3d_launch_status();
 }
 
@@ -228,6 +321,7 @@ extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, co
   p.bias = bias; p.rowbias = (const uint16_t*)rowbias; p.rb_div = rowbias ? rb_div : 1;
   p.R = (const uint16_t*)R; p.ldr = ldr; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
+  p.vec16 = (ldy % 8 == 0) && aligned16(Y) && (!R || (ldr % 8 == 0 && aligned16(R))) && (!rowbias || (N % 8 == 0 && aligned16(rowbias)));
   return launch<false>((hipStream_t)stream, p);
 }
 
@@ -249,5 +343,18 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
   p.Ho = (He + 2 - 3) / stride + 1; p.Wo = (We + 2 - 3) / stride + 1;
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
+  p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
   return launch<true>((hipStream_t)stream, p);
+}
+
+extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                                   const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K) {
+  if (!X || !W || !Y || M <= 0 || N2 <= 0 || K <= 0) return A3D_EINVAL;
+  if (K % BK != 0 || N2 % 64 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 8 != 0) return A3D_EINVAL;
+  if (!aligned16(X) || !aligned16(W) || !aligned16(Y)) return A3D_EINVAL;
+  GemmParams p{};
+  p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
+  p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
+  p.M = M; p.N = N2; p.K = K; p.alpha = 1.f; p.beta = 0.f; p.vec16 = 1;
+  return launch<false, EPI_GEGLU>((hipStream_t)stream, p);
 }

@@ -1,96 +1,160 @@
 // Temporal (AnimateDiff) self-attention over the F <= 32 frames of every (video, pixel, head).
 //
 // The reference materialises [(b n h w) heads, F, F] scores with baddbmm + softmax + bmm
-// (attention_processor.py:630-636).  Here one thread owns one query (video, pixel, head, frame):
-// F scores live in registers, K and V rows are read in 16-byte chunks straight from the
-// [(v f) l, C] token tensors (row stride L*ld between frames) and are shared through L1/L2 by
-// the F threads of the same pixel, which sit in adjacent lanes.  ~0.05 % of the step's FLOPs;
-// the kernel is bound by the three reads + one write of the token tensors.
+// (attention_processor.py:630-636).  ~0.05 % of the step's FLOPs: the kernel is bound by the three reads +
+// one write of the token tensors, so it is organised around full-line HBM accesses:
+//   * a workgroup owns PIX consecutive pixels x one 320-channel slab (640 B per token row) x all F frames;
+//     the Q, K, V slabs are copied to LDS with 16-byte loads (40 lanes cover one 640-B row segment);
+//   * one thread owns one query (pixel, 40-dim slice, frame i): scores against the F keys with
+//     v_dot2c_f32_bf16 on packed bf16 pairs (keys are LDS broadcasts across the query lanes), slices of one
+//     head (D = 80 / 160) are summed with lane shuffles, softmax in registers, then P·V for the thread's own
+//     40-dim slice and five 16-byte stores.
+// Every token byte is read from HBM exactly once (the first version re-read K/V F times through L1).
 #include "common.h"
 
 namespace {
+
+constexpr int SLAB = 320;            // channels per workgroup (one 640-byte row segment)
+constexpr int SL = 40;               // dims per thread slice
+constexpr int NSL = SLAB / SL;       // 8 slices per pixel
 
 struct TAParams {
   const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ld;
   uint16_t* O; int64_t ldo;
   int videos, frames; int64_t L; int heads; float scale_log2;
-  int64_t total;   // videos * L * frames
+  int64_t npix;      // videos * L
 };
 
-template <int FMAX, int D>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(const TAParams p) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.total) return;
-  const int F = p.frames;
-  const int i = (int)(idx % F);
-  const int64_t pix = idx / F;           // v * L + l
-  const int64_t v = pix / p.L, l = pix % p.L;
-  const int head = blockIdx.y;
-  const int64_t row0 = (v * F) * p.L + l;             // frame 0 of this pixel
-  const int64_t fstride = p.L * p.ld;                 // elements between frames
-  const uint16_t* qp = p.Q + (row0 + (int64_t)i * p.L) * p.ld + head * D;
-  const uint16_t* kp = p.K + row0 * p.ld + head * D;
-  const uint16_t* vp = p.V + row0 * p.ld + head * D;
+A3D_DEV float dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
 
-  float s[FMAX];
+// FP = frames padded to 16 or 32 (register array size), PIX = pixels per workgroup, DP = 40-dim slices per head
+template <int FP, int PIX, int DP>
+__global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAParams p) {
+  constexpr int ROWB = PIX * SLAB + 8;               // LDS elements per frame (+16 B: de-alias the frame stride)
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];   // [3][F][ROWB]
+  const int F = p.frames;
+  const int tid = threadIdx.x;
+  const int64_t pix0 = (int64_t)blockIdx.x * PIX;
+  const int c0 = blockIdx.y * SLAB;
+
+  // ---- stage Q, K, V slabs: item = (tensor, frame, pixel, 16-byte chunk)
+  const int chunks = SLAB / 8;                         // 40 chunks per row segment
+  const int items = 3 * F * PIX * chunks;
+  for (int it = tid; it < items; it += blockDim.x) {
+    const int ch = it % chunks;
+    const int px = (it / chunks) % PIX;
+    const int f = (it / (chunks * PIX)) % F;
+    const int ten = it / (chunks * PIX * F);
+    int64_t pix = pix0 + px;
+    if (pix >= p.npix) pix = p.npix - 1;
+    const int64_t v = pix / p.L, l = pix % p.L;
+    const uint16_t* src = (ten == 0 ? p.Q : (ten == 1 ? p.K : p.V)) + ((v * F + f) * p.L + l) * p.ld + c0 + ch * 8;
+    *reinterpret_cast<u32x4_t*>(smem + ((size_t)ten * F + f) * ROWB + px * SLAB + ch * 8) = *reinterpret_cast<const u32x4_t*>(src);
+  }
+  __syncthreads();
+
+  // ---- one thread = one query (pixel px, slice sl, frame i)
+  const int sl = tid % NSL;            // slices of one head are adjacent lanes (shuffle partners xor 1, xor 2)
+  const int i = (tid / NSL) % FP;
+  const int px = tid / (FP * NSL);
+  const bool active = i < F && pix0 + px < p.npix;
+  const int fi = i < F ? i : F - 1;
+  const uint16_t* qrow = smem + ((size_t)0 * F + fi) * ROWB + px * SLAB + sl * SL;
+  const uint16_t* kbase = smem + ((size_t)1 * F) * ROWB + px * SLAB + sl * SL;
+  const uint16_t* vbase = smem + ((size_t)2 * F) * ROWB + px * SLAB + sl * SL;
+  uint32_t q[SL / 2];
 #pragma unroll
-  for (int j = 0; j < FMAX; ++j) s[j] = 0.f;
-#pragma unroll 1
-  for (int c = 0; c < D / 8; ++c) {
-    const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(qp + c * 8);
-    float qf[8];
+  for (int c = 0; c < SL / 8; ++c) {
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(qrow + c * 8);
+    q[4 * c] = w[0]; q[4 * c + 1] = w[1]; q[4 * c + 2] = w[2]; q[4 * c + 3] = w[3];
+  }
+  float s[FP];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qf[e] = (e & 1) ? hi_bf(qv[e >> 1]) : lo_bf(qv[e >> 1]);
+  for (int j = 0; j < FP; ++j) {
+    float acc = 0.f;
+    if (j < F) {
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) {
-      if (j < F) {
-        const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(kp + j * fstride + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s[j] = fmaf(qf[e], (e & 1) ? hi_bf(kv[e >> 1]) : lo_bf(kv[e >> 1]), s[j]);
+      for (int c = 0; c < SL / 8; ++c) {
+        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(kbase + (size_t)j * ROWB + c * 8);
+        acc = dot2(q[4 * c], w[0], acc); acc = dot2(q[4 * c + 1], w[1], acc);
+        acc = dot2(q[4 * c + 2], w[2], acc); acc = dot2(q[4 * c + 3], w[3], acc);
       }
     }
+    s[j] = acc;
+  }
+  // slices of the same head are adjacent lanes: sum the partial dot products
+  if constexpr (DP >= 2) {
+#pragma unroll
+    for (int j = 0; j < FP; ++j) s[j] += __shfl_xor(s[j], 1);
+  }
+  if constexpr (DP >= 4) {
+#pragma unroll
+    for (int j = 0; j < FP; ++j) s[j] += __shfl_xor(s[j], 2);
   }
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < FMAX; ++j) if (j < F) mx = fmaxf(mx, s[j]);
+  for (int j = 0; j < FP; ++j) if (j < F) mx = fmaxf(mx, s[j]);
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < FMAX; ++j) {
+  for (int j = 0; j < FP; ++j) {
     s[j] = (j < F) ? __builtin_amdgcn_exp2f((s[j] - mx) * p.scale_log2) : 0.f;
     sum += s[j];
   }
   const float inv = 1.f / sum;
-  uint16_t* op = p.O + (row0 + (int64_t)i * p.L) * p.ldo + head * D;
-#pragma unroll 1
-  for (int c = 0; c < D / 8; ++c) {
-    float o[8];
+  float o[SL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int d = 0; d < SL; ++d) o[d] = 0.f;
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) {
-      if (j < F) {
-        const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vp + j * fstride + c * 8);
+  for (int j = 0; j < FP; ++j) {
+    if (j < F) {
+      const float pj = s[j];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(s[j], (e & 1) ? hi_bf(vv[e >> 1]) : lo_bf(vv[e >> 1]), o[e]);
+      for (int c = 0; c < SL / 8; ++c) {
+        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(vbase + (size_t)j * ROWB + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[8 * c + 2 * e] = fmaf(pj, lo_bf(w[e]), o[8 * c + 2 * e]);
+          o[8 * c + 2 * e + 1] = fmaf(pj, hi_bf(w[e]), o[8 * c + 2 * e + 1]);
+        }
       }
     }
-    u32x4_t ov;
+  }
+  if (active) {
+    const int64_t pix = pix0 + px;
+    const int64_t v = pix / p.L, l = pix % p.L;
+    uint16_t* dst = p.O + ((v * F + i) * p.L + l) * p.ldo + c0 + sl * SL;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ov[e] = pack2bf(o[2 * e] * inv, o[2 * e + 1] * inv);
-    *reinterpret_cast<u32x4_t*>(op + c * 8) = ov;
+    for (int c = 0; c < SL / 8; ++c) {
+      u32x4_t ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = pack2bf(o[8 * c + 2 * e] * inv, o[8 * c + 2 * e + 1] * inv);
+      *reinterpret_cast<u32x4_t*>(dst + c * 8) = ov;
+    }
   }
 }
 
-template <int D>
-int launch_d(hipStream_t s, const TAParams& p) {
-  const int64_t nblk = (p.total + 255) / 256;
-  if (nblk > 0x7fffffffLL || p.heads > 65535) return A3D_EINVAL;
-  const dim3 grid((unsigned)nblk, (unsigned)p.heads), block(256);
-  if (p.frames <= 4) temporal_attn_kernel<4, D><<<grid, block, 0, s>>>(p);
-  else if (p.frames <= 8) temporal_attn_kernel<8, D><<<grid, block, 0, s>>>(p);
-  else if (p.frames <= 16) temporal_attn_kernel<16, D><<<grid, block, 0, s>>>(p);
-  else temporal_attn_kernel<32, D><<<grid, block, 0, s>>>(p);
+template <int FP, int PIX, int DP>
+int launch(hipStream_t s, const TAParams& p, int C) {
+  const int64_t nblk = (p.npix + PIX - 1) / PIX;
+  if (nblk > 0x7fffffffLL) return A3D_EINVAL;
+  const size_t lds = (size_t)3 * p.frames * (PIX * SLAB + 8) * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<FP, PIX, DP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP * (PIX * SLAB + 8) * 2);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  temporal_attn_kernel<FP, PIX, DP><<<dim3((unsigned)nblk, (unsigned)(C / SLAB)), dim3(PIX * NSL * FP), lds, s>>>(p);
   return a3d_launch_status();
+}
+
+template <int DP>
+int launch_dp(hipStream_t s, const TAParams& p, int C) {
+  if (p.frames <= 16) return launch<16, 2, DP>(s, p, C);     // 256 threads, <= 62 KB LDS
+  return launch<32, 1, DP>(s, p, C);                          // 256 threads, <= 62 KB LDS
 }
 
 }  // namespace
@@ -102,16 +166,18 @@ extern "C" int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const 
   if (ldqkv % 8 || ldo % 8) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
        reinterpret_cast<uintptr_t>(O)) & 15u) return A3D_EINVAL;
+  const int C = heads * head_dim;
+  if (C % SLAB != 0) return A3D_EUNSUPPORTED;
   TAParams p{};
   p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.ld = ldqkv;
   p.O = (uint16_t*)O; p.ldo = ldo; p.videos = videos; p.frames = frames; p.L = L; p.heads = heads;
   p.scale_log2 = scale * 1.4426950408889634f;
-  p.total = (int64_t)videos * L * frames;
+  p.npix = (int64_t)videos * L;
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
-    case 40: return launch_d<40>(s, p);
-    case 80: return launch_d<80>(s, p);
-    case 160: return launch_d<160>(s, p);
+    case 40: return launch_dp<1>(s, p, C);
+    case 80: return launch_dp<2>(s, p, C);
+    case 160: return launch_dp<4>(s, p, C);
     default: return A3D_EUNSUPPORTED;
   }
 }

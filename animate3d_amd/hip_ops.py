@@ -42,6 +42,7 @@ class RowMap:
 _SIGNATURES = {
     "a3d_version": (ctypes.c_char_p, []),
     "a3d_gemm_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32]),
+    "a3d_gemm_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64]),
     "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                     c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
@@ -136,6 +137,24 @@ class HipOps:
                                     _p(residual), residual.stride(0) if residual is not None else 0, _p(y), y.stride(0),
                                     M, N, K, alpha, beta)
         _check(rc, f"a3d_gemm_bf16 M={M} N={N} K={K}")
+        return y
+
+    @staticmethod
+    def interleave_geglu(w: torch.Tensor) -> torch.Tensor:
+        """[2N, ...] = [h rows | gate rows] -> rows interleaved in blocks of 32 (layout a3d_gemm_geglu_bf16 expects)."""
+        n = w.shape[0] // 2
+        assert n % 32 == 0
+        h, g = w[:n].reshape(n // 32, 32, *w.shape[1:]), w[n:].reshape(n // 32, 32, *w.shape[1:])
+        return torch.stack([h, g], dim=1).reshape(w.shape).contiguous()
+
+    def gemm_geglu(self, x, w_il, bias_il):
+        """GEGLU(x) = (x Wh^T + bh) * gelu(x Wg^T + bg) with interleaved weights (see interleave_geglu)."""
+        x, w_il = self._act(x, "geglu.x"), self._act(w_il, "geglu.w")
+        M, K = x.shape
+        N2 = w_il.shape[0]
+        y = self.empty(M, N2 // 2)
+        rc = self.lib.a3d_gemm_geglu_bf16(self._stream(), _p(x), x.stride(0), _p(w_il), w_il.stride(0), _p(bias_il), _p(y), y.stride(0), M, N2, K)
+        _check(rc, f"a3d_gemm_geglu_bf16 M={M} N2={N2} K={K}")
         return y
 
     def conv3x3(self, x, B: int, H: int, W: int, w, bias, *, stride: int = 1, up2x: bool = False, rowbias=None, rb_div: int = 1, residual=None):

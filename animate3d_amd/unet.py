@@ -270,7 +270,9 @@ class MVUNetMotionModel(nn.Module):
 
     def _pack_ff(self, tb):
         return SimpleNamespace(n3=(self._f(tb.norm3.weight), self._f(tb.norm3.bias)),
-                               ff1=(self._w(tb.ff.net[0].proj.weight), self._f(tb.ff.net[0].proj.bias)),
+                               # GEGLU projection rows interleaved (h | gate in blocks of 32) for the fused GEMM epilogue
+                               ff1=(self._w(self.ops.interleave_geglu(tb.ff.net[0].proj.weight.detach())),
+                                    self._f(self.ops.interleave_geglu(tb.ff.net[0].proj.bias.detach()))),
                                ff2=(self._w(tb.ff.net[2].weight), self._f(tb.ff.net[2].bias)))
 
     def _pack_t2d(self, t: M.Transformer2DModel):
@@ -393,8 +395,7 @@ class MVUNetMotionModel(nn.Module):
     def _ff(self, h, pk):
         ops = self.ops
         n3 = ops.layer_norm(h, pk.n3[0], pk.n3[1], 1e-5)
-        u = ops.gemm(n3, pk.ff1[0], pk.ff1[1])
-        u = ops.geglu(u)
+        u = ops.gemm_geglu(n3, pk.ff1[0], pk.ff1[1])           # proj + h * gelu(gate) in one kernel
         return ops.gemm(u, pk.ff2[0], pk.ff2[1], residual=h)
 
     def _mv_maps(self, n, F, L):

@@ -67,6 +67,14 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
 
+/* Fused feed-forward input projection + GEGLU (diffusers FeedForward.net[0] = GEGLU: proj, chunk(2), h * gelu(gate)):
+ *   Y[M, N2/2][m, j] = (X·Wh^T + bh)[m, j] * gelu_erf((X·Wg^T + bg)[m, j])
+ * W / bias rows must be INTERLEAVED in blocks of 32: rows [64b, 64b+32) = h rows [32b, 32b+32),
+ * rows [64b+32, 64b+64) = gate rows [32b, 32b+32), so h and gate of one output column land in the same
+ * wave tile and the 2x wider intermediate never goes to HBM.  N2 % 64 == 0, K % 64 == 0. */
+int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                        const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K);
+
 /* 3x3 convolution, padding 1, NHWC, as an implicit GEMM (K = 9*Cin):
  *   Y[b, yo, xo, co] = bias[co] + rowbias[(row) / rb_div][co] + R[...]
  *                      + sum_{ky,kx,ci} X[b, yo*stride+ky-1, xo*stride+kx-1, ci] * Wp[co][ky][kx][ci]

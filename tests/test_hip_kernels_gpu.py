@@ -77,6 +77,16 @@ def test_gemm_epilogues_and_strides(ops, ref):
     assert (out[:, :N] == 0).all()
 
 
+@pytest.mark.parametrize("M,N2,K", [(300, 2560, 320), (1000, 5120, 640), (64, 10240, 1280), (5, 64, 64)])
+def test_gemm_geglu_fused(ops, ref, M, N2, K):
+    x, w = rnd(M, K, seed=1), rnd(N2, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N2, seed=3, dtype=torch.float32)
+    w_il, b_il = ops.interleave_geglu(w), ops.interleave_geglu(bias)
+    want = ref.geglu(ref.gemm(x, w, bias))                    # un-fused fp32 reference with the original row order
+    check(f"gemm_geglu {M}x{N2}x{K}", ops.gemm_geglu(x, w_il, b_il), want)
+    check(f"gemm_geglu ref-op {M}x{N2}x{K}", ref.gemm_geglu(x, w_il, b_il), want, tol=1e-6)
+
+
 def test_gemm_layout_asymmetric(ops):
     """A = I (padded) with an asymmetric W catches operand / output transposes."""
     K = N = 64
@@ -156,7 +166,7 @@ def test_flash_attn_rescale_branch(ops, ref):
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])
-@pytest.mark.parametrize("V,F,L", [(2, 3, 16), (1, 4, 64), (2, 16, 64), (1, 32, 8)])
+@pytest.mark.parametrize("V,F,L", [(2, 3, 16), (1, 4, 64), (2, 16, 64), (1, 32, 8), (1, 3, 5), (3, 16, 7)])
 def test_temporal_attn(ops, ref, D, V, F, L):
     heads = 8
     C = heads * D

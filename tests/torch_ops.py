@@ -48,6 +48,24 @@ class TorchRefOps:
             return out
         return y
 
+    @staticmethod
+    def interleave_geglu(w):
+        n = w.shape[0] // 2
+        h, g = w[:n].reshape(n // 32, 32, *w.shape[1:]), w[n:].reshape(n // 32, 32, *w.shape[1:])
+        return torch.stack([h, g], dim=1).reshape(w.shape).contiguous()
+
+    @staticmethod
+    def deinterleave_geglu(w):
+        n = w.shape[0] // 2
+        blk = w.reshape(n // 32, 2, 32, *w.shape[1:])
+        return torch.cat([blk[:, 0].reshape(n, *w.shape[1:]), blk[:, 1].reshape(n, *w.shape[1:])], 0)
+
+    def gemm_geglu(self, x, w_il, bias_il):
+        w = self.deinterleave_geglu(w_il.float())
+        b = self.deinterleave_geglu(bias_il.float())
+        h, gate = (x.float() @ w.t() + b).chunk(2, dim=-1)
+        return self._o(h * F.gelu(gate))
+
     def conv3x3(self, x, B, H, W, w, bias, *, stride=1, up2x=False, rowbias=None, rb_div=1, residual=None):
         Cin, Cout = x.shape[1], w.shape[0]
         img = x.float().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
