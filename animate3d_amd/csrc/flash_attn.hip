@@ -456,6 +456,254 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   }
 }
 
+// =====================================================================================================
+// Ping-pong variant for the level-0 multi-view attentions (D = 40, long aligned K/V).
+//
+// PMC profile of the kernel above (QT = 2): matrix pipe busy 50 %, VALU issue 58 %, and the two nearly
+// serialised — the two resident waves of a SIMD come from different workgroups and drift into the same phase.
+// Here one 512-thread workgroup puts TWO of its waves on every SIMD (wave w and w+4) and keeps them half a
+// tile apart with workgroup barriers, so that at any time one of them is in its matrix block
+// [PV(t-1), QK^T(t)] and the other in its vector block [softmax(t), K/V staging]:
+//
+//     barrier interval      group A (waves 0-3)            group B (waves 4-7)
+//        (#1,#2)             softmax(0), stage tile 1        PV(-), QK(0)
+//        (#2,#3)             PV(0), QK(1)                    softmax(0), stage tile 2
+//        (#3,#4)             softmax(1), stage tile 2        PV(0), QK(1)          ...
+//
+// Each group stages half of every K/V tile (A: tile t+1, B: tile t+2 during the vector block of tile t), K is
+// double- and V triple-buffered in LDS; all 8 waves (512 queries) share one staged copy, which also halves the
+// LDS write traffic and staging VALU per FLOP again.  Per-query arithmetic is identical to the kernel above.
+template <int D>
+__global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams p) {
+  static_assert(D == 40, "ping-pong variant is instantiated for head_dim 40");
+  constexpr int BKV = 64, NU = 2, QT = 2, VROW = BKV + 8;
+  constexpr int DK = 48, KS = 3, MT = 2, KROW = DK + 8, DCH = D / 8;
+  constexpr int KS_ELEMS = BKV * KROW, VT_ELEMS = MT * 32 * VROW;
+  constexpr int KSHARE = BKV * DCH / 2, VSHARE = (BKV / 4) * DCH / 2;      // 160 K chunks, 40 V items per group
+  constexpr int KS_PAD = D / 16, G_PAD = (D % 16) / 8;
+  constexpr int BQ = 512;
+
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * KS_ELEMS + 3 * VT_ELEMS];
+  uint16_t* const Ks0 = smem;
+  uint16_t* const Vt0 = smem + 2 * KS_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int grp_w = wid >> 2, wq = wid & 3, gt = tid & 255;
+  const int l31 = lane & 31, g = lane >> 5;
+  const int head = blockIdx.x % p.heads;
+  const int qt = blockIdx.x / p.heads;
+  const int64_t grp = blockIdx.y;
+  const int64_t hoff = (int64_t)head * D;
+
+  for (int i = tid; i < 2 * BKV * (DK - D); i += 512) {
+    const int b = i / (BKV * (DK - D)), rem = i % (BKV * (DK - D));
+    const int c = rem % (DK - D);
+    Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + c] = (c == 0) ? 0x3F80 : 0;
+  }
+  for (int i = tid; i < 3 * BKV; i += 512) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = 0x3F80;
+
+  // ---- Q^T fragments (pre-scaled), two 32-query sub-tiles per wave
+  int q_idx[QT];
+  bool q_ok[QT];
+  u32x4_t qf[QT][KS];
+#pragma unroll
+  for (int qs = 0; qs < QT; ++qs) {
+    q_idx[qs] = qt * BQ + grp_w * 256 + wq * 64 + qs * 32 + l31;
+    q_ok[qs] = q_idx[qs] < p.q_len;
+    const int64_t q_row = map_row(p.qm, grp, q_ok[qs] ? q_idx[qs] : p.q_len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 16 * ks + 8 * g;
+      if (d0 < D) {
+        u32x4_t w = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + d0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pack2bf(lo_bf(w[j]) * p.scale_log2, hi_bf(w[j]) * p.scale_log2);
+        qf[qs][ks] = w;
+      } else {
+        qf[qs][ks] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+
+  // ---- this thread's share of every K/V tile
+  const int64_t ld = p.km.ld;
+  const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
+  const uint32_t seg_len = (uint32_t)p.km.seg_len;
+  const int64_t tile_step = (int64_t)BKV * ld;
+  const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;
+  const bool has_k = gt < KSHARE, has_v = gt < VSHARE;
+  const int kci = grp_w * KSHARE + (has_k ? gt : 0), vit = grp_w * VSHARE + (has_v ? gt : 0);
+  const int kr = kci / DCH, kc = kci % DCH, vq = vit / DCH, vc = vit % DCH;
+  const uint16_t* kptr = p.K + hoff + (kgbase + kr) * ld + kc * 8;
+  const uint16_t* vptr = p.V + hoff + (kgbase + vq * 4) * ld + vc * 8;
+  uint32_t seg_off = 0;
+  u32x4_t kreg, vreg[4];
+  auto load_share = [&]() {            // reads the tile the pointers stand on, then advances them by one tile
+    if (has_k) kreg = *reinterpret_cast<const u32x4_t*>(kptr);
+    if (has_v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vreg[r] = *reinterpret_cast<const u32x4_t*>(vptr + r * ld);
+    }
+    seg_off += BKV;
+    int64_t step = tile_step;
+    if (seg_off >= seg_len) { step += wrap_step; seg_off = 0; }
+    kptr += step; vptr += step;
+  };
+  auto store_share = [&](int tile) {
+    uint16_t* const Ks = Ks0 + (tile & 1) * KS_ELEMS;
+    uint16_t* const Vt = Vt0 + (tile % 3) * VT_ELEMS;
+    if (has_k) *reinterpret_cast<u32x4_t*>(Ks + kr * KROW + kc * 8) = kreg;
+    if (has_v) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w0 = vreg[0][j], w1 = vreg[1][j], w2 = vreg[2][j], w3 = vreg[3][j];
+        u32x2_t even, odd;
+        even[0] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+        even[1] = __builtin_amdgcn_perm(w3, w2, 0x05040100u);
+        odd[0] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+        odd[1] = __builtin_amdgcn_perm(w3, w2, 0x07060302u);
+        *reinterpret_cast<u32x2_t*>(Vt + (vc * 8 + 2 * j) * VROW + vq * 4) = even;
+        *reinterpret_cast<u32x2_t*>(Vt + (vc * 8 + 2 * j + 1) * VROW + vq * 4) = odd;
+      }
+    }
+  };
+
+  f32x16_t oacc[QT][MT];
+#pragma unroll
+  for (int qs = 0; qs < QT; ++qs)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qs][mt][r] = 0.f;
+  float m_off[QT] = {0.f, 0.f};
+  const int krow_off = kperm(l31) * KROW + 8 * g;
+  const int vrow_off = l31 * VROW + 8 * g;
+  f32x16_t sacc[QT][NU];
+  u32x4_t pf[QT][NU][2];
+
+  auto qk = [&](int tile) {
+    const uint16_t* const Ks = Ks0 + (tile & 1) * KS_ELEMS + krow_off;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[qs][u][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
+#pragma unroll
+        for (int qs = 0; qs < QT; ++qs) sacc[qs][u] = mfma32(kf, qf[qs][ks], sacc[qs][u]);
+      }
+    }
+  };
+  auto pv = [&](int tile) {
+    const uint16_t* const Vt = Vt0 + (tile % 3) * VT_ELEMS + vrow_off;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+#pragma unroll
+          for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vf, pf[qs][u][h], oacc[qs][mt]);
+        }
+  };
+  auto softmax = [&](bool first) {
+#pragma unroll
+    for (int qs = 0; qs < QT; ++qs) {
+      float mx = sacc[qs][0][0];
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
+      if (__any(first || mx > LAZY_THR)) {
+        const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
+        float delta = first ? mxp : fmaxf(mxp, 0.f);
+        const float new_off = bf16_round(m_off[qs] + delta);
+        delta = new_off - m_off[qs];
+        m_off[qs] = new_off;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[qs][u][r] -= delta;
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
+        }
+        if (g == G_PAD) qf[qs][KS_PAD][0] = pack2bf(-new_off, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sacc[qs][u][r]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf[qs][u][h][j] = pack2bf(e[8 * h + 2 * j], e[8 * h + 2 * j + 1]);
+      }
+    }
+  };
+
+  const int nt = p.kv_len / BKV;              // launcher guarantees kv_len % BKV == 0 and nt >= 2
+  // ---- prologue: both groups stage their share of tile 0; B also stages its share of tile 1
+  load_share();
+  store_share(0);
+  if (grp_w == 1) { load_share(); store_share(1); }
+  __syncthreads();                            // #0: tile 0 complete
+  if (grp_w == 1) __syncthreads();            // #1: B idles through A's first matrix block
+
+  for (int t = 0; t < nt; ++t) {
+    const int nxt = t + 1 + grp_w;            // tile this group stages during the vector block of tile t
+    // ---- matrix block
+    if (nxt < nt) load_share();
+    if (t > 0) pv(t - 1);
+    qk(t);
+    __syncthreads();
+    // ---- vector block
+    softmax(t == 0);
+    if (nxt < nt) store_share(nxt);
+    __syncthreads();
+  }
+  if (grp_w == 0) __syncthreads();            // balance B's idle barrier
+  pv(nt - 1);
+
+  // ---- finalize
+#pragma unroll
+  for (int qs = 0; qs < QT; ++qs) {
+    constexpr int LM = D / 32, LR = ((D % 32) / 8) * 4;
+    const float l_tot = __shfl(oacc[qs][LM][LR], l31);
+    const float inv = p.out_scale / l_tot;
+    if (q_ok[qs]) {
+      uint16_t* orow = p.O + map_row(p.om, grp, q_idx[qs]) * p.om.ld + hoff;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d = 32 * mt + 8 * qd + 4 * g;
+          if (d < D) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv;
+            if (p.accumulate) {
+              const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
+              v[0] += lo_bf(prev[0]); v[1] += hi_bf(prev[0]); v[2] += lo_bf(prev[1]); v[3] += hi_bf(prev[1]);
+            }
+            u32x2_t o;
+            o[0] = pack2bf(v[0], v[1]);
+            o[1] = pack2bf(v[2], v[3]);
+            *reinterpret_cast<u32x2_t*>(orow + d) = o;
+          }
+        }
+    }
+  }
+}
+
 bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
@@ -498,12 +746,17 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
   switch (head_dim) {
     case 40:
       if (q_len <= 128) { launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p); break; }
+      if (g_flash_variant != 5 && aligned && kv_len % 64 == 0 && kv_len >= 128 && q_len >= 512) {
+        const int q_tiles = (int)((q_len + 511) / 512);
+        flash_attn_pp_kernel<40><<<dim3((unsigned)(heads * q_tiles), (unsigned)groups), dim3(512), 0, s>>>(p);
+        break;
+      }
       switch (g_flash_variant) {
         case 1: launch<40, 64, 2, OFS_PAD, 1>(aligned, groups, s, p); break;
         case 2: launch<40, 64, 2, OFS_PAD, 2>(aligned, groups, s, p); break;
         case 3: launch<40, 64, 2, OFS_PAD, 4>(aligned, groups, s, p); break;
         case 4: launch<40, 64, 2, OFS_PAD, 5>(aligned, groups, s, p); break;
-        case 5: launch<40, 64, 1, OFS_PAD, 5>(aligned, groups, s, p); break;
+        case 5: launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p); break;     // previous default (no ping-pong)
         default: launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p); break;
       }
       break;
