@@ -581,21 +581,61 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
   f32x16_t sacc[QT][NU];
   u32x4_t pf[QT][NU][2];
 
-  auto qk = [&](int tile) {
-    const uint16_t* const Ks = Ks0 + (tile & 1) * KS_ELEMS + krow_off;
+  // Matrix block of tile t: PV(t-1) then QK^T(t).  LDS fragment reads are software-pipelined by hand (the
+  // compiler otherwise sinks every ds_read next to its MFMA and exposes ~150 cycles of LDS latency per fragment):
+  // two batches of V fragments are in flight before the first MFMA, each K batch is requested one MFMA batch early;
+  // sched_barrier(0) pins the read groups above the MFMA groups.
+  auto matrix_block = [&](int t, auto with_pv_c) {
+    constexpr bool WITH_PV = decltype(with_pv_c)::value;
+    const uint16_t* const Ks = Ks0 + (t & 1) * KS_ELEMS + krow_off;
+    const uint16_t* const Vt = Vt0 + ((t + 2) % 3) * VT_ELEMS + vrow_off;      // tile t-1
+    u32x4_t va[4], vb[4], ka[KS], kb[KS];
+    auto load_k = [&](u32x4_t (&kk)[KS], int u) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+      for (int ks = 0; ks < KS; ++ks) kk[ks] = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
+    };
+    auto load_v = [&](u32x4_t (&vv)[4], int u) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) vv[mt * 2 + h] = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
+    };
+    auto pv_batch = [&](u32x4_t (&vv)[4], int u) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vv[mt * 2 + h], pf[qs][u][h], oacc[qs][mt]);
+    };
+    auto qk_batch = [&](u32x4_t (&kk)[KS], int u) {
 #pragma unroll
       for (int qs = 0; qs < QT; ++qs)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[qs][u][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int qs = 0; qs < QT; ++qs) sacc[qs][u] = mfma32(kf, qf[qs][ks], sacc[qs][u]);
-      }
+        for (int qs = 0; qs < QT; ++qs) sacc[qs][u] = mfma32(kk[ks], qf[qs][ks], sacc[qs][u]);
+    };
+    if constexpr (WITH_PV) {
+      load_v(va, 0);
+      load_v(vb, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_batch(va, 0);
+      load_k(ka, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_batch(vb, 1);
+      load_k(kb, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load_k(ka, 0);
+      load_k(kb, 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    qk_batch(ka, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    qk_batch(kb, 1);
   };
   auto pv = [&](int tile) {
     const uint16_t* const Vt = Vt0 + (tile % 3) * VT_ELEMS + vrow_off;
@@ -662,8 +702,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
     const int nxt = t + 1 + grp_w;            // tile this group stages during the vector block of tile t
     // ---- matrix block
     if (nxt < nt) load_share();
-    if (t > 0) pv(t - 1);
-    qk(t);
+    if (t > 0) matrix_block(t, std::true_type{}); else matrix_block(t, std::false_type{});
     __syncthreads();
     // ---- vector block
     softmax(t == 0);
