@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 // Each group stages half of every K/V tile (A: tile t+1, B: tile t+2 during the vector block of tile t), K is
 // double- and V triple-buffered in LDS; all 8 waves (512 queries) share one staged copy, which also halves the
 // LDS write traffic and staging VALU per FLOP again.  Per-query arithmetic is identical to the kernel above.
-template <int D>
+// ABL (timing ablations only, results are wrong): 1 = no exp, 2 = no max / lazy check, 4 = no K/V staging after the
+// prologue, 8 = no QK^T MFMAs, 16 = no PV MFMAs.
+template <int D, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams p) {
   static_assert(D == 40, "ping-pong variant is instantiated for head_dim 40");
   constexpr int BKV = 64, NU = 2, QT = 2, VROW = BKV + 8;
@@ -606,7 +608,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vv[mt * 2 + h], pf[qs][u][h], oacc[qs][mt]);
+          for (int qs = 0; qs < QT; ++qs) {
+            if constexpr ((ABL & 16) == 0) oacc[qs][mt] = mfma32(vv[mt * 2 + h], pf[qs][u][h], oacc[qs][mt]);
+            else { oacc[qs][mt][0] += __uint_as_float(vv[mt * 2 + h][0] ^ pf[qs][u][h][0]); }
+          }
     };
     auto qk_batch = [&](u32x4_t (&kk)[KS], int u) {
 #pragma unroll
@@ -616,7 +621,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int qs = 0; qs < QT; ++qs) sacc[qs][u] = mfma32(kk[ks], qf[qs][ks], sacc[qs][u]);
+        for (int qs = 0; qs < QT; ++qs) {
+          if constexpr ((ABL & 8) == 0) sacc[qs][u] = mfma32(kk[ks], qf[qs][ks], sacc[qs][u]);
+          else { sacc[qs][u][ks] += __uint_as_float(kk[ks][0] ^ qf[qs][ks][0]) * 1e-30f; }
+        }
     };
     if constexpr (WITH_PV) {
       load_v(va, 0);
@@ -654,11 +662,13 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 #pragma unroll
     for (int qs = 0; qs < QT; ++qs) {
       float mx = sacc[qs][0][0];
+      if constexpr ((ABL & 2) == 0) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
-      if (__any(first || mx > LAZY_THR)) {
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
+      }
+      if (__any(first || ((ABL & 2) == 0 && mx > LAZY_THR))) {
         const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
         float delta = first ? mxp : fmaxf(mxp, 0.f);
         const float new_off = bf16_round(m_off[qs] + delta);
@@ -681,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
       for (int u = 0; u < NU; ++u) {
         float e[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(sacc[qs][u][r]);
+        for (int r = 0; r < 16; ++r) e[r] = (ABL & 1) ? sacc[qs][u][r] : __builtin_amdgcn_exp2f(sacc[qs][u][r]);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -701,12 +711,12 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
   for (int t = 0; t < nt; ++t) {
     const int nxt = t + 1 + grp_w;            // tile this group stages during the vector block of tile t
     // ---- matrix block
-    if (nxt < nt) load_share();
+    if (nxt < nt && (ABL & 4) == 0) load_share();
     if (t > 0) matrix_block(t, std::true_type{}); else matrix_block(t, std::false_type{});
     __syncthreads();
     // ---- vector block
     softmax(t == 0);
-    if (nxt < nt) store_share(nxt);
+    if (nxt < nt && (ABL & 4) == 0) store_share(nxt);
     __syncthreads();
   }
   if (grp_w == 0) __syncthreads();            // balance B's idle barrier
@@ -787,7 +797,14 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
       if (q_len <= 128) { launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p); break; }
       if (g_flash_variant != 5 && aligned && kv_len % 64 == 0 && kv_len >= 128 && q_len >= 512) {
         const int q_tiles = (int)((q_len + 511) / 512);
-        flash_attn_pp_kernel<40><<<dim3((unsigned)(heads * q_tiles), (unsigned)groups), dim3(512), 0, s>>>(p);
+        const dim3 grid((unsigned)(heads * q_tiles), (unsigned)groups);
+        switch (g_flash_variant) {
+          case 1: flash_attn_pp_kernel<40, 1><<<grid, dim3(512), 0, s>>>(p); break;     // ablations (timing only)
+          case 2: flash_attn_pp_kernel<40, 3><<<grid, dim3(512), 0, s>>>(p); break;
+          case 3: flash_attn_pp_kernel<40, 4><<<grid, dim3(512), 0, s>>>(p); break;
+          case 4: flash_attn_pp_kernel<40, 24><<<grid, dim3(512), 0, s>>>(p); break;
+          default: flash_attn_pp_kernel<40, 0><<<grid, dim3(512), 0, s>>>(p); break;
+        }
         break;
       }
       switch (g_flash_variant) {
