@@ -533,9 +533,13 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
   const uint32_t seg_len = (uint32_t)p.km.seg_len;
   const int64_t tile_step = (int64_t)BKV * ld;
   const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;
-  const bool has_k = gt < KSHARE, has_v = gt < VSHARE;
-  const int kci = grp_w * KSHARE + (has_k ? gt : 0), vit = grp_w * VSHARE + (has_v ? gt : 0);
-  const int kr = kci / DCH, kc = kci % DCH, vq = vit / DCH, vc = vit % DCH;
+  // K chunks on the group's first 160 threads; V items on its last wave, key-quad fastest across lanes so that the
+  // 8-byte V^T writes of a 16-lane group fall on 16 different key columns (conflict-free; dim-fastest was 5-way)
+  const bool has_k = gt < KSHARE, has_v = gt >= 192 && gt < 192 + VSHARE;
+  const int kci = grp_w * KSHARE + (has_k ? gt : 0);
+  const int vit = has_v ? gt - 192 : 0;                       // 0..39 within the group
+  const int kr = kci / DCH, kc = kci % DCH;
+  const int vq = grp_w * (VSHARE / DCH) + vit % (VSHARE / DCH), vc = vit / (VSHARE / DCH);
   const uint16_t* kptr = p.K + hoff + (kgbase + kr) * ld + kc * 8;
   const uint16_t* vptr = p.V + hoff + (kgbase + vq * 4) * ld + vc * 8;
   uint32_t seg_off = 0;
@@ -583,6 +587,17 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
   f32x16_t sacc[QT][NU];
   u32x4_t pf[QT][NU][2];
 
+  u32x4_t va[4], vb[4];
+  auto prefetch_v = [&](int tile) {          // V^T fragments of `tile` (complete in LDS two phases before they are used)
+    const uint16_t* const Vt = Vt0 + (tile % 3) * VT_ELEMS + vrow_off;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        va[mt * 2 + h] = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 16 * h);
+        vb[mt * 2 + h] = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 + 16 * h);
+      }
+  };
   // Matrix block of tile t: PV(t-1) then QK^T(t).  LDS fragment reads are software-pipelined by hand (the
   // compiler otherwise sinks every ds_read next to its MFMA and exposes ~150 cycles of LDS latency per fragment):
   // two batches of V fragments are in flight before the first MFMA, each K batch is requested one MFMA batch early;
@@ -590,17 +605,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
   auto matrix_block = [&](int t, auto with_pv_c) {
     constexpr bool WITH_PV = decltype(with_pv_c)::value;
     const uint16_t* const Ks = Ks0 + (t & 1) * KS_ELEMS + krow_off;
-    const uint16_t* const Vt = Vt0 + ((t + 2) % 3) * VT_ELEMS + vrow_off;      // tile t-1
-    u32x4_t va[4], vb[4], ka[KS], kb[KS];
+    u32x4_t ka[KS], kb[KS];
     auto load_k = [&](u32x4_t (&kk)[KS], int u) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) kk[ks] = *reinterpret_cast<const u32x4_t*>(Ks + 32 * u * KROW + 16 * ks);
-    };
-    auto load_v = [&](u32x4_t (&vv)[4], int u) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) vv[mt * 2 + h] = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
     };
     auto pv_batch = [&](u32x4_t (&vv)[4], int u) {
 #pragma unroll
@@ -626,10 +634,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
           else { sacc[qs][u][ks] += __uint_as_float(kk[ks][0] ^ qf[qs][ks][0]) * 1e-30f; }
         }
     };
-    if constexpr (WITH_PV) {
-      load_v(va, 0);
-      load_v(vb, 1);
-      __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WITH_PV) {       // va / vb were requested at the end of the previous vector block (before the barrier)
       pv_batch(va, 0);
       load_k(ka, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -645,28 +650,19 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
     __builtin_amdgcn_sched_barrier(0);
     qk_batch(kb, 1);
   };
-  auto pv = [&](int tile) {
-    const uint16_t* const Vt = Vt0 + (tile % 3) * VT_ELEMS + vrow_off;
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vt + 32 * mt * VROW + 32 * u + 16 * h);
-#pragma unroll
-          for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vf, pf[qs][u][h], oacc[qs][mt]);
-        }
-  };
   auto softmax = [&](bool first) {
 #pragma unroll
     for (int qs = 0; qs < QT; ++qs) {
       float mx = sacc[qs][0][0];
-      if constexpr ((ABL & 2) == 0) {
+      if constexpr ((ABL & 2) == 0) {       // four independent max chains (a single chain is latency-bound)
+        float m4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m4[c] = sacc[qs][c & 1][c >> 1];
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
+          for (int r = 0; r < 16; ++r) m4[(r & 1) * 2 + u] = fmaxf(m4[(r & 1) * 2 + u], sacc[qs][u][r]);
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       }
       if (__any(first || ((ABL & 2) == 0 && mx > LAZY_THR))) {
         const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
@@ -717,10 +713,19 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
     // ---- vector block
     softmax(t == 0);
     if (nxt < nt && (ABL & 4) == 0) store_share(nxt);
+    prefetch_v(t);                              // for PV(t) right after the barrier
     __syncthreads();
   }
   if (grp_w == 0) __syncthreads();            // balance B's idle barrier
-  pv(nt - 1);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs) {
+        oacc[qs][mt] = mfma32(va[mt * 2 + h], pf[qs][0][h], oacc[qs][mt]);
+        oacc[qs][mt] = mfma32(vb[mt * 2 + h], pf[qs][1][h], oacc[qs][mt]);
+      }
 
   // ---- finalize
 #pragma unroll
