@@ -692,6 +692,13 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int j = 0; j < 4; ++j) pf[qs][u][h][j] = pack2bf(e[8 * h + 2 * j], e[8 * h + 2 * j + 1]);
+        if constexpr ((ABL & 32) != 0) {     // experiment: pair every two v_exp with the v_cvt_pk of the previous pair
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+        }
       }
     }
   };
@@ -807,7 +814,7 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
           case 1: flash_attn_pp_kernel<40, 1><<<grid, dim3(512), 0, s>>>(p); break;     // ablations (timing only)
           case 2: flash_attn_pp_kernel<40, 3><<<grid, dim3(512), 0, s>>>(p); break;
           case 3: flash_attn_pp_kernel<40, 4><<<grid, dim3(512), 0, s>>>(p); break;
-          case 4: flash_attn_pp_kernel<40, 24><<<grid, dim3(512), 0, s>>>(p); break;
+          case 4: flash_attn_pp_kernel<40, 32><<<grid, dim3(512), 0, s>>>(p); break;     // exp/cvt interleave experiment
           default: flash_attn_pp_kernel<40, 0><<<grid, dim3(512), 0, s>>>(p); break;
         }
         break;
