@@ -16,10 +16,19 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LROW = BK + 8;                 // LDS row stride in elements (144 B)
-constexpr int TILE_ELEMS = 128 * LROW;       // one operand tile
-constexpr int SMEM_BYTES = 2 * 2 * TILE_ELEMS * 2;   // [buf][A|W]
+constexpr int BM = 128, BN = 128;
+// K-step BKT = 64 (two LDS stages = 72 KB, 2 workgroups per CU) for long contractions, BKT = 32 (40 KB, 3 per CU:
+// more independent workgroups to cover the per-tile load latency and epilogue) for the short K = 320 / 640 GEMMs.
+template <int BKT> struct TileCfg {
+  static constexpr int LROW = BKT + 8;                  // LDS row stride in elements: odd number of 16-B slots
+  static constexpr int TILE_ELEMS = 128 * LROW;         // one operand tile
+  static constexpr int STAGE_BYTES = 2 * 2 * TILE_ELEMS * 2;   // [buf][A|W]
+  static constexpr int EPI_BYTES = 4 * 32 * 68 * 4;     // epilogue staging, one 32-row half per wave at a time
+  static constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int CPR = BKT / 8;                   // 16-byte chunks per tile row
+  static constexpr int RPT = 256 / CPR;                 // rows covered by one pass of the 256 threads
+  static constexpr int NPASS = 128 / RPT;               // chunks per thread per operand
+};
 
 struct GemmParams {
   const uint16_t* X; int64_t ldx;
@@ -54,8 +63,10 @@ A3D_DEV float gelu_erf(float gte) {
   return 0.5f * gte * (1.0f + erfs);
 }
 
-template <bool CONV, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+template <bool CONV, int EPI, int BKT>
+__global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const GemmParams p) {
+  using TC = TileCfg<BKT>;
+  constexpr int LROW = TC::LROW, TILE_ELEMS = TC::TILE_ELEMS, NPASS = TC::NPASS, RPT = TC::RPT, BK = BKT;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -68,16 +79,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- staging assignment: thread owns 16-byte chunk column kc of rows srow + 32*i
-  const int kc = tid & 7;
-  const int srow = tid >> 3;
+  const int kc = tid % TC::CPR;
+  const int srow = tid / TC::CPR;
 
   // per-row source bookkeeping for A
-  const uint16_t* a_ptr[4];   // dense: row pointer (+kc*8); conv: unused
-  int a_b[4], a_y[4], a_x[4]; // conv: output pixel coordinates
-  bool a_ok[4];
+  const uint16_t* a_ptr[NPASS];   // dense: row pointer (+kc*8); conv: unused
+  int a_b[NPASS], a_y[NPASS], a_x[NPASS]; // conv: output pixel coordinates
+  bool a_ok[NPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t m = m0 + srow + 32 * i;
+  for (int i = 0; i < NPASS; ++i) {
+    int64_t m = m0 + srow + RPT * i;
     a_ok[i] = m < p.M;
     if (m >= p.M) m = p.M - 1;
     if constexpr (CONV) {
@@ -91,15 +102,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       a_b[i] = a_y[i] = a_x[i] = 0;
     }
   }
-  const uint16_t* w_ptr[4];
+  const uint16_t* w_ptr[NPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t n = n0 + srow + 32 * i;
+  for (int i = 0; i < NPASS; ++i) {
+    int64_t n = n0 + srow + RPT * i;
     if (n >= p.N) n = p.N - 1;
     w_ptr[i] = p.W + n * p.ldw + kc * 8;
   }
 
-  u32x4_t ra[4], rw[4];
+  u32x4_t ra[NPASS], rw[NPASS];
   auto load_tile = [&](int64_t k0) {
     if constexpr (CONV) {
       const int tap = (int)(k0 / p.Cin);
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       const int ky = tap / 3, kx = tap - ky * 3;
       const int He = p.up ? 2 * p.H : p.H, We = p.up ? 2 * p.Wd : p.Wd;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NPASS; ++i) {
         const int yy = a_y[i] * p.stride + ky - 1;
         const int xx = a_x[i] * p.stride + kx - 1;
         const bool ok = a_ok[i] && yy >= 0 && yy < He && xx >= 0 && xx < We;
@@ -121,18 +132,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + k0);
+      for (int i = 0; i < NPASS; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + k0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(w_ptr[i] + k0);
+    for (int i = 0; i < NPASS; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(w_ptr[i] + k0);
   };
   auto store_tile = [&](int buf) {
     uint16_t* As = smem + (buf * 2 + 0) * TILE_ELEMS;
     uint16_t* Ws = smem + (buf * 2 + 1) * TILE_ELEMS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4_t*>(As + (srow + 32 * i) * LROW + kc * 8) = ra[i];
-      *reinterpret_cast<u32x4_t*>(Ws + (srow + 32 * i) * LROW + kc * 8) = rw[i];
+    for (int i = 0; i < NPASS; ++i) {
+      *reinterpret_cast<u32x4_t*>(As + (srow + RPT * i) * LROW + kc * 8) = ra[i];
+      *reinterpret_cast<u32x4_t*>(Ws + (srow + RPT * i) * LROW + kc * 8) = rw[i];
     }
   };
 
@@ -178,18 +189,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   //      instruction touches 8 full 128-byte row segments (the direct MFMA-layout epilogue issued 8-byte stores
   //      to 32 different rows per instruction and was store-issue bound at K = 320).
   constexpr int SROW = 68;
-  float* const stg = reinterpret_cast<float*>(smem) + wid * (64 * SROW);
+  float* const stg = reinterpret_cast<float*>(smem) + wid * (32 * SROW);     // one 32-row half (tm) at a time
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
+  for (int tm = 0; tm < 2; ++tm) {
+  if (tm == 1) __syncthreads();                                              // half 0 fully read before it is overwritten
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+  for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v;
-        v.x = acc[tn][tm][4 * q]; v.y = acc[tn][tm][4 * q + 1]; v.z = acc[tn][tm][4 * q + 2]; v.w = acc[tn][tm][4 * q + 3];
-        *reinterpret_cast<float4*>(stg + (tm * 32 + l31) * SROW + tn * 32 + 8 * q + 4 * g) = v;
-      }
+    for (int q = 0; q < 4; ++q) {
+      float4 v;
+      v.x = acc[tn][tm][4 * q]; v.y = acc[tn][tm][4 * q + 1]; v.z = acc[tn][tm][4 * q + 2]; v.w = acc[tn][tm][4 * q + 3];
+      *reinterpret_cast<float4*>(stg + l31 * SROW + tn * 32 + 8 * q + 4 * g) = v;
+    }
   __syncthreads();
+  const int64_t mbase = m0 + wm * 64 + tm * 32;
 
   if constexpr (EPI == EPI_GEGLU) {
     // columns [0,32) of the wave's sub-tile are h, [32,64) the matching gates (weight rows are interleaved on
@@ -202,9 +215,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? p.bias[nh + e] : 0.f; bg[e] = p.bias ? p.bias[nh + 32 + e] : 0.f; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const int row = 16 * j + (lane >> 2);
-        const int64_t m = m0 + wm * 64 + row;
+        const int64_t m = mbase + row;
         if (m >= p.M) continue;
         const float4 h0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
         const float4 h1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
@@ -230,9 +243,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const int row = 8 * j + (lane >> 3);
-        const int64_t m = m0 + wm * 64 + row;
+        const int64_t m = mbase + row;
         if (m >= p.M) continue;
         const float4 a0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
         const float4 a1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
@@ -283,6 +296,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       }
     }
   }
+  }   // tm halves
+}
+
+int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
+
+template <bool CONV, int EPI, int BKT>
+int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
+  using TC = TileCfg<BKT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI, BKT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TC::SMEM_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  gemm_kernel<CONV, EPI, BKT><<<dim3((unsigned)nblk), dim3(256), TC::SMEM_BYTES, stream>>>(p);
+  return a3d_launch_status();
 }
 
 template <bool CONV, int EPI = EPI_LINEAR>
@@ -291,15 +321,9 @@ int launch(hipStream_t stream, GemmParams& p) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t nblk = p.tiles_m * p.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  gemm_kernel<CONV, EPI><<<dim3((unsigned)nblk), dim3(256), SMEM_BYTES, stream>>>(p);
-  return a3d_launch_status();
+  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && p.K <= 640);
+  if (small) return launch_bk<CONV, EPI, 32>(stream, p, nblk);
+  return launch_bk<CONV, EPI, 64>(stream, p, nblk);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -310,7 +334,7 @@ extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, co
                              const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                              void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
-  if (K % BK != 0 || N % 4 != 0) return A3D_EINVAL;
+  if (K % 64 != 0 || N % 4 != 0) return A3D_EINVAL;
   if (ldx % 8 != 0 || ldw % 8 != 0 || ldy % 4 != 0 || (R && ldr % 4 != 0)) return A3D_EINVAL;
   if (!aligned16(X) || !aligned16(W) || (reinterpret_cast<uintptr_t>(Y) & 7u) || (R && (reinterpret_cast<uintptr_t>(R) & 7u)))
     return A3D_EINVAL;
@@ -329,7 +353,7 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
                                 const void* rowbias, int64_t rb_div, const void* R, void* Y,
                                 int B, int H, int W, int Cin, int Cout, int stride, int up2x) {
   if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
-  if (Cin % BK != 0 || Cout % 4 != 0 || (stride != 1 && stride != 2)) return A3D_EINVAL;
+  if (Cin % 64 != 0 || Cout % 4 != 0 || (stride != 1 && stride != 2)) return A3D_EINVAL;
   if (up2x && stride != 1) return A3D_EINVAL;
   if (!aligned16(X) || !aligned16(Wp) || (reinterpret_cast<uintptr_t>(Y) & 7u)) return A3D_EINVAL;
   if (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)) return A3D_EINVAL;
@@ -350,11 +374,17 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
 extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                                    const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K) {
   if (!X || !W || !Y || M <= 0 || N2 <= 0 || K <= 0) return A3D_EINVAL;
-  if (K % BK != 0 || N2 % 64 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 8 != 0) return A3D_EINVAL;
+  if (K % 64 != 0 || N2 % 64 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 8 != 0) return A3D_EINVAL;
   if (!aligned16(X) || !aligned16(W) || !aligned16(Y)) return A3D_EINVAL;
   GemmParams p{};
   p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
   p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N2; p.K = K; p.alpha = 1.f; p.beta = 0.f; p.vec16 = 1;
   return launch<false, EPI_GEGLU>((hipStream_t)stream, p);
+}
+
+extern "C" int a3d_tune_gemm(int bk) {
+  if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
+  g_gemm_bk = bk;
+  return A3D_OK;
 }

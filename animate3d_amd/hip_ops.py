@@ -47,6 +47,7 @@ _SIGNATURES = {
     "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                     c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
     "a3d_tune_flash": (c_int, [c_int]),
+    "a3d_tune_gemm": (c_int, [c_int]),
     "a3d_temporal_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
     "a3d_group_norm_ws_floats": (c_i64, [c_int, c_i64, c_int]),
     "a3d_group_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_f32, c_int]),

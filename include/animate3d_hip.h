@@ -67,6 +67,9 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
 
+/* Tuning knob (diagnostics): force the GEMM / conv K-step, 32 or 64; 0 = automatic (32 when K <= 640). */
+int a3d_tune_gemm(int bk);
+
 /* Fused feed-forward input projection + GEGLU (diffusers FeedForward.net[0] = GEGLU: proj, chunk(2), h * gelu(gate)):
  *   Y[M, N2/2][m, j] = (X·Wh^T + bh)[m, j] * gelu_erf((X·Wg^T + bg)[m, j])
  * W / bias rows must be INTERLEAVED in blocks of 32: rows [64b, 64b+32) = h rows [32b, 32b+32),

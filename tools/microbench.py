@@ -60,9 +60,15 @@ def bench_gemm(ops):
         x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
         bias = torch.randn(N, device="cuda")
         res = rnd(M, N)
-        med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res), reps=7)
         fl = 2.0 * M * N * K
-        print(f"M={M:7d} N={N:5d} K={K:5d}: {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s (best {fl / mn / 1e9:7.1f})")
+        out = []
+        for bk in (64, 32):
+            ops.lib.a3d_tune_gemm(bk)
+            med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res), reps=7)
+            med2, _ = timeit(lambda: ops.gemm(x, w, bias), reps=7)
+            out.append(f"bk{bk}: {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s | no-residual {med2:7.3f} ms {fl / med2 / 1e9:6.1f} TF/s")
+        ops.lib.a3d_tune_gemm(0)
+        print(f"M={M:7d} N={N:5d} K={K:5d}: " + "  ||  ".join(out))
 
 
 def bench_conv(ops):
@@ -74,11 +80,16 @@ def bench_conv(ops):
     for (B, H, W, Cin, Cout, st, up) in shapes:
         x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
         bias = torch.randn(Cout, device="cuda")
-        med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
         He, We = (2 * H, 2 * W) if up else (H, W)
         Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
         fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
-        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: {med:8.3f} ms  {fl / med / 1e9:7.1f} TF/s (best {fl / mn / 1e9:7.1f})")
+        out = []
+        for bk in (64, 32):
+            ops.lib.a3d_tune_gemm(bk)
+            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
+            out.append(f"bk{bk}: {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s")
+        ops.lib.a3d_tune_gemm(0)
+        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + "  ||  ".join(out))
 
 
 def bench_misc(ops):
