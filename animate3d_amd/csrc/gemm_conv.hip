@@ -155,6 +155,21 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // residual rows this lane will need in the epilogue (row = 8*j + lane/8 of each 32-row half, 8 columns at
+  // 8*(lane&7)): requested during the LAST K-step so their HBM latency hides under its MFMAs
+  u32x4_t rres[4];
+  const int ecc = lane & 7;
+  const int64_t en = n0 + wn * 64 + 8 * ecc;
+  const bool epf = (EPI == EPI_LINEAR) && p.R != nullptr && p.vec16 && en + 8 <= p.N;
+  auto prefetch_residual = [&](int tm) {      // half tm = 0 during the last K-step, half 1 while half 0 is written out
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t m = m0 + wm * 64 + tm * 32 + 8 * j + (lane >> 3);
+      if (m >= p.M) m = p.M - 1;
+      rres[j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + en);
+    }
+  };
+
   const int64_t nk = p.K / BK;
   load_tile(0);
   store_tile(0);
@@ -164,6 +179,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
     const int cur = (int)(kt & 1);
     const bool more = kt + 1 < nk;
     if (more) load_tile((kt + 1) * BK);
+    else if (epf) prefetch_residual(0);
     const uint16_t* As = smem + (cur * 2 + 0) * TILE_ELEMS;
     const uint16_t* Ws = smem + (cur * 2 + 1) * TILE_ELEMS;
 #pragma unroll
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
           if (rr) {
-            const u32x4_t t = *reinterpret_cast<const u32x4_t*>(rr);
+            const u32x4_t t = rres[j];              // prefetched (epf is true whenever this branch is taken)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(t[e]); v[2 * e + 1] += p.beta * hi_bf(t[e]); }
           }
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
       }
     }
   }
+  if (tm == 0 && epf) prefetch_residual(1);
   }   // tm halves
 }
 
@@ -321,7 +338,9 @@ int launch(hipStream_t stream, GemmParams& p) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t nblk = p.tiles_m * p.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
-  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && p.K <= 640);
+  // measured on MI355X (profiles/r1_microbench_gemm_bk.log): K-step 32 wins for K <= 640, for 3x3 convs with
+  // Cin <= 640 and whenever the grid is under ~3 workgroups per CU; K-step 64 wins for long contractions
+  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && (p.K <= 640 || (CONV && p.Cin <= 640) || nblk < 768));
   if (small) return launch_bk<CONV, EPI, 32>(stream, p, nblk);
   return launch_bk<CONV, EPI, 64>(stream, p, nblk);
 }
