@@ -63,7 +63,7 @@ A3D_DEV float gelu_erf(float gte) {
   return 0.5f * gte * (1.0f + erfs);
 }
 
-template <bool CONV, int EPI, int BKT>
+template <bool CONV, int EPI, int BKT, bool RES>
 __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const GemmParams p) {
   using TC = TileCfg<BKT>;
   constexpr int LROW = TC::LROW, TILE_ELEMS = TC::TILE_ELEMS, NPASS = TC::NPASS, RPT = TC::RPT, BK = BKT;
@@ -157,16 +157,18 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 
   // residual rows this lane will need in the epilogue (row = 8*j + lane/8 of each 32-row half, 8 columns at
   // 8*(lane&7)): requested during the LAST K-step so their HBM latency hides under its MFMAs
-  u32x4_t rres[4];
+  u32x4_t rres[RES ? 4 : 1];
   const int ecc = lane & 7;
   const int64_t en = n0 + wn * 64 + 8 * ecc;
-  const bool epf = (EPI == EPI_LINEAR) && p.R != nullptr && p.vec16 && en + 8 <= p.N;
+  const bool epf = RES && (EPI == EPI_LINEAR) && p.R != nullptr && p.vec16 && en + 8 <= p.N;
   auto prefetch_residual = [&](int tm) {      // half tm = 0 during the last K-step, half 1 while half 0 is written out
+    if constexpr (RES) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int64_t m = m0 + wm * 64 + tm * 32 + 8 * j + (lane >> 3);
-      if (m >= p.M) m = p.M - 1;
-      rres[j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + en);
+      for (int j = 0; j < 4; ++j) {
+        int64_t m = m0 + wm * 64 + tm * 32 + 8 * j + (lane >> 3);
+        if (m >= p.M) m = p.M - 1;
+        rres[j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + en);
+      }
     }
   };
 
@@ -279,10 +281,12 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-          if (rr) {
-            const u32x4_t t = rres[j];              // prefetched (epf is true whenever this branch is taken)
+          if constexpr (RES) {
+            if (rr) {
+              const u32x4_t t = rres[j];            // prefetched (epf is true whenever this branch is taken)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(t[e]); v[2 * e + 1] += p.beta * hi_bf(t[e]); }
+              for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(t[e]); v[2 * e + 1] += p.beta * hi_bf(t[e]); }
+            }
           }
           u32x4_t o;
 #pragma unroll
@@ -318,18 +322,26 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 
 int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
 
-template <bool CONV, int EPI, int BKT>
-int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
+template <bool CONV, int EPI, int BKT, bool RES>
+int launch_res(hipStream_t stream, GemmParams& p, int64_t nblk) {
   using TC = TileCfg<BKT>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI, BKT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI, BKT, RES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, TC::SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  gemm_kernel<CONV, EPI, BKT><<<dim3((unsigned)nblk), dim3(256), TC::SMEM_BYTES, stream>>>(p);
+  gemm_kernel<CONV, EPI, BKT, RES><<<dim3((unsigned)nblk), dim3(256), TC::SMEM_BYTES, stream>>>(p);
   return a3d_launch_status();
+}
+
+template <bool CONV, int EPI, int BKT>
+int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
+  if constexpr (EPI == EPI_LINEAR) {
+    if (p.R != nullptr) return launch_res<CONV, EPI, BKT, true>(stream, p, nblk);
+  }
+  return launch_res<CONV, EPI, BKT, false>(stream, p, nblk);
 }
 
 template <bool CONV, int EPI = EPI_LINEAR>
