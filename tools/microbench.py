@@ -118,4 +118,6 @@ if __name__ == "__main__":
     for w in which:
         {"flash": bench_flash, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
-         "gemm1": lambda o: [o.gemm(rnd(131072, 640), rnd(2560, 640)) for _ in range(3)]}[w](ops)
+         "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
+                             [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
+                             [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)])}[w](ops)
