@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   const uint16_t* a_ptr[NPASS];   // dense: row pointer (+kc*8); conv: unused
   int a_b[NPASS], a_y[NPASS], a_x[NPASS]; // conv: output pixel coordinates
   bool a_ok[NPASS];
+  int a_mask[NPASS];
 #pragma unroll
   for (int i = 0; i < NPASS; ++i) {
     int64_t m = m0 + srow + RPT * i;
@@ -96,10 +97,19 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
       const int b = (int)(m / hw);
       const int rem = (int)(m - (int64_t)b * hw);
       a_b[i] = b; a_y[i] = rem / p.Wo; a_x[i] = rem - a_y[i] * p.Wo;
-      a_ptr[i] = nullptr;
+      // tap (0,0) source position and a 9-bit in-bounds mask: per K-tile only a uniform tap offset is added
+      const int y0 = a_y[i] * p.stride - 1, x0 = a_x[i] * p.stride - 1;
+      a_ptr[i] = p.X + (((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + kc * 8;
+      int mask = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y0 + t / 3, xx = x0 + t % 3;
+        if (a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1 << t;
+      }
+      a_mask[i] = mask;
     } else {
       a_ptr[i] = p.X + m * p.ldx + kc * 8;
-      a_b[i] = a_y[i] = a_x[i] = 0;
+      a_b[i] = a_y[i] = a_x[i] = 0; a_mask[i] = 0;
     }
   }
   const uint16_t* w_ptr[NPASS];
@@ -116,7 +126,15 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
       const int ky = tap / 3, kx = tap - ky * 3;
-      const int He = p.up ? 2 * p.H : p.H, We = p.up ? 2 * p.Wd : p.Wd;
+      if (!p.up) {       // common path: uniform tap offset + per-row bit test
+        const int64_t toff = ((int64_t)ky * p.Wd + kx) * p.Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+          if ((a_mask[i] >> tap) & 1) ra[i] = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + toff);
+          else ra[i] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+      } else {
+      const int He = 2 * p.H, We = 2 * p.Wd;
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         const int yy = a_y[i] * p.stride + ky - 1;
@@ -129,6 +147,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
         } else {
           ra[i] = u32x4_t{0u, 0u, 0u, 0u};
         }
+      }
       }
     } else {
 #pragma unroll
@@ -184,18 +203,23 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
     else if (epf) prefetch_residual(0);
     const uint16_t* As = smem + (cur * 2 + 0) * TILE_ELEMS;
     const uint16_t* Ws = smem + (cur * 2 + 1) * TILE_ELEMS;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      u32x4_t fw[2], fa[2];
+    // fragments of k-step ks+1 are requested before the MFMAs of k-step ks are issued (register double buffer)
+    u32x4_t fw[2][2], fa[2][2];
+    auto load_frags = [&](int slot, int ks) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        fw[t] = *reinterpret_cast<const u32x4_t*>(Ws + (wn * 64 + t * 32 + l31) * LROW + ks * 16 + g * 8);
-        fa[t] = *reinterpret_cast<const u32x4_t*>(As + (wm * 64 + t * 32 + l31) * LROW + ks * 16 + g * 8);
+        fw[slot][t] = *reinterpret_cast<const u32x4_t*>(Ws + (wn * 64 + t * 32 + l31) * LROW + ks * 16 + g * 8);
+        fa[slot][t] = *reinterpret_cast<const u32x4_t*>(As + (wm * 64 + t * 32 + l31) * LROW + ks * 16 + g * 8);
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks + 1 < BK / 16) load_frags((ks + 1) & 1, ks + 1);
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[tn], fa[tm], acc[tn][tm]);
+        for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[ks & 1][tn], fa[ks & 1][tm], acc[tn][tm]);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
