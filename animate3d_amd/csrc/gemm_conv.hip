@@ -63,7 +63,8 @@ A3D_DEV float gelu_erf(float gte) {
   return 0.5f * gte * (1.0f + erfs);
 }
 
-template <bool CONV, int EPI, int BKT, bool RES>
+// CONV: 0 = dense A, 1 = 3x3 conv gather (pad 1, stride 1|2), 2 = 3x3 conv over a nearest-2x upsampled input
+template <int CONV, int EPI, int BKT, bool RES>
 __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const GemmParams p) {
   using TC = TileCfg<BKT>;
   constexpr int LROW = TC::LROW, TILE_ELEMS = TC::TILE_ELEMS, NPASS = TC::NPASS, RPT = TC::RPT, BK = BKT;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 
   // per-row source bookkeeping for A
   const uint16_t* a_ptr[NPASS];   // dense: row pointer (+kc*8); conv: unused
-  int a_b[NPASS], a_y[NPASS], a_x[NPASS]; // conv: output pixel coordinates
+  int a_b[CONV == 2 ? NPASS : 1], a_y[CONV == 2 ? NPASS : 1], a_x[CONV == 2 ? NPASS : 1];   // up2x conv: output pixel coordinates
   bool a_ok[NPASS];
   int a_mask[NPASS];
 #pragma unroll
@@ -92,24 +93,29 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
     int64_t m = m0 + srow + RPT * i;
     a_ok[i] = m < p.M;
     if (m >= p.M) m = p.M - 1;
-    if constexpr (CONV) {
+    if constexpr (CONV != 0) {
       const int hw = p.Ho * p.Wo;
       const int b = (int)(m / hw);
       const int rem = (int)(m - (int64_t)b * hw);
-      a_b[i] = b; a_y[i] = rem / p.Wo; a_x[i] = rem - a_y[i] * p.Wo;
-      // tap (0,0) source position and a 9-bit in-bounds mask: per K-tile only a uniform tap offset is added
-      const int y0 = a_y[i] * p.stride - 1, x0 = a_x[i] * p.stride - 1;
-      a_ptr[i] = p.X + (((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + kc * 8;
-      int mask = 0;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      if constexpr (CONV == 2) {
+        a_b[i] = b; a_y[i] = oy; a_x[i] = ox;
+        a_ptr[i] = nullptr; a_mask[i] = 0;
+      } else {
+        // tap (0,0) source position and a 9-bit in-bounds mask: per K-tile only a uniform tap offset is added
+        const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+        a_ptr[i] = p.X + (((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + kc * 8;
+        int mask = 0;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int yy = y0 + t / 3, xx = x0 + t % 3;
-        if (a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1 << t;
+        for (int t = 0; t < 9; ++t) {
+          const int yy = y0 + t / 3, xx = x0 + t % 3;
+          if (a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1 << t;
+        }
+        a_mask[i] = mask;
       }
-      a_mask[i] = mask;
     } else {
       a_ptr[i] = p.X + m * p.ldx + kc * 8;
-      a_b[i] = a_y[i] = a_x[i] = 0; a_mask[i] = 0;
+      a_mask[i] = 0;
     }
   }
   const uint16_t* w_ptr[NPASS];
@@ -120,34 +126,34 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
     w_ptr[i] = p.W + n * p.ldw + kc * 8;
   }
 
-  u32x4_t ra[NPASS], rw[NPASS];
-  auto load_tile = [&](int64_t k0) {
-    if constexpr (CONV) {
+  struct RegTile { u32x4_t a[NPASS], w[NPASS]; };
+  RegTile rt0, rt1;     // two K-tiles in flight (prefetch distance 2)
+  auto load_tile = [&](int64_t k0, RegTile& rt) {
+    u32x4_t (&ra)[NPASS] = rt.a; u32x4_t (&rw)[NPASS] = rt.w;
+    if constexpr (CONV != 0) {
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
       const int ky = tap / 3, kx = tap - ky * 3;
-      if (!p.up) {       // common path: uniform tap offset + per-row bit test
+      if constexpr (CONV == 1) {       // uniform tap offset + per-row bit test
         const int64_t toff = ((int64_t)ky * p.Wd + kx) * p.Cin + ci0;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
           if ((a_mask[i] >> tap) & 1) ra[i] = *reinterpret_cast<const u32x4_t*>(a_ptr[i] + toff);
           else ra[i] = u32x4_t{0u, 0u, 0u, 0u};
         }
-      } else {
-      const int He = 2 * p.H, We = 2 * p.Wd;
+      } else {                         // nearest-2x upsample folded into the address (3 convs per step)
+        const int He = 2 * p.H, We = 2 * p.Wd;
 #pragma unroll
-      for (int i = 0; i < NPASS; ++i) {
-        const int yy = a_y[i] * p.stride + ky - 1;
-        const int xx = a_x[i] * p.stride + kx - 1;
-        const bool ok = a_ok[i] && yy >= 0 && yy < He && xx >= 0 && xx < We;
-        const int sy = p.up ? (yy >> 1) : yy, sx = p.up ? (xx >> 1) : xx;
-        if (ok) {
-          const uint16_t* src = p.X + (((int64_t)a_b[i] * p.H + sy) * p.Wd + sx) * p.Cin + ci0 + kc * 8;
-          ra[i] = *reinterpret_cast<const u32x4_t*>(src);
-        } else {
-          ra[i] = u32x4_t{0u, 0u, 0u, 0u};
+        for (int i = 0; i < NPASS; ++i) {
+          const int yy = a_y[i] + ky - 1, xx = a_x[i] + kx - 1;
+          const bool ok = a_ok[i] && yy >= 0 && yy < He && xx >= 0 && xx < We;
+          if (ok) {
+            const uint16_t* src = p.X + (((int64_t)a_b[i] * p.H + (yy >> 1)) * p.Wd + (xx >> 1)) * p.Cin + ci0 + kc * 8;
+            ra[i] = *reinterpret_cast<const u32x4_t*>(src);
+          } else {
+            ra[i] = u32x4_t{0u, 0u, 0u, 0u};
+          }
         }
-      }
       }
     } else {
 #pragma unroll
@@ -156,7 +162,8 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(w_ptr[i] + k0);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const RegTile& rt) {
+    const u32x4_t (&ra)[NPASS] = rt.a; const u32x4_t (&rw)[NPASS] = rt.w;
     uint16_t* As = smem + (buf * 2 + 0) * TILE_ELEMS;
     uint16_t* Ws = smem + (buf * 2 + 1) * TILE_ELEMS;
 #pragma unroll
@@ -192,15 +199,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   };
 
   const int64_t nk = p.K / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int cur = (int)(kt & 1);
-    const bool more = kt + 1 < nk;
-    if (more) load_tile((kt + 1) * BK);
-    else if (epf) prefetch_residual(0);
+  auto compute = [&](int cur) {
     const uint16_t* As = smem + (cur * 2 + 0) * TILE_ELEMS;
     const uint16_t* Ws = smem + (cur * 2 + 1) * TILE_ELEMS;
     // fragments of k-step ks+1 are requested before the MFMAs of k-step ks are issued (register double buffer)
@@ -221,8 +220,30 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[ks & 1][tn], fa[ks & 1][tm], acc[tn][tm]);
     }
-    if (more) store_tile(cur ^ 1);
+  };
+
+  // K pipeline: LDS is double-buffered, and TWO further K-tiles are in flight in registers (rt0 / rt1), so a
+  // tile's global loads have two K-steps of MFMA time to land (one step was shorter than the HBM/L2 latency).
+  load_tile(0, rt0);
+  store_tile(0, rt0);
+  if (nk > 1) load_tile(1 * BK, rt0);
+  if (nk > 2) load_tile(2 * BK, rt1);
+  __syncthreads();
+  for (int64_t kt = 0;;) {
+    // even step: LDS[0] = tile kt, rt0 = tile kt+1, rt1 = tile kt+2 (in flight)
+    if (kt + 1 >= nk && epf) prefetch_residual(0);
+    compute(0);
+    if (kt + 1 < nk) store_tile(1, rt0);
+    if (kt + 3 < nk) load_tile((kt + 3) * BK, rt0);
     __syncthreads();
+    if (++kt >= nk) break;
+    // odd step: LDS[1] = tile kt, rt1 = tile kt+1, rt0 = tile kt+2 (in flight)
+    if (kt + 1 >= nk && epf) prefetch_residual(0);
+    compute(1);
+    if (kt + 1 < nk) store_tile(0, rt1);
+    if (kt + 3 < nk) load_tile((kt + 3) * BK, rt1);
+    __syncthreads();
+    if (++kt >= nk) break;
   }
 
   // ---- epilogue.  Each wave transposes its 64x64 fp32 sub-tile through a private LDS region (row stride 68
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 
 int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
 
-template <bool CONV, int EPI, int BKT, bool RES>
+template <int CONV, int EPI, int BKT, bool RES>
 int launch_res(hipStream_t stream, GemmParams& p, int64_t nblk) {
   using TC = TileCfg<BKT>;
   static bool attr_set = false;
@@ -360,7 +381,7 @@ int launch_res(hipStream_t stream, GemmParams& p, int64_t nblk) {
   return a3d_launch_status();
 }
 
-template <bool CONV, int EPI, int BKT>
+template <int CONV, int EPI, int BKT>
 int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
   if constexpr (EPI == EPI_LINEAR) {
     if (p.R != nullptr) return launch_res<CONV, EPI, BKT, true>(stream, p, nblk);
@@ -368,7 +389,7 @@ int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
   return launch_res<CONV, EPI, BKT, false>(stream, p, nblk);
 }
 
-template <bool CONV, int EPI = EPI_LINEAR>
+template <int CONV, int EPI = EPI_LINEAR>
 int launch(hipStream_t stream, GemmParams& p) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
@@ -376,7 +397,7 @@ int launch(hipStream_t stream, GemmParams& p) {
   if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
   // measured on MI355X (profiles/r1_microbench_gemm_bk.log): K-step 32 wins for K <= 640, for 3x3 convs with
   // Cin <= 640 and whenever the grid is under ~3 workgroups per CU; K-step 64 wins for long contractions
-  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && (p.K <= 640 || (CONV && p.Cin <= 640) || nblk < 768));
+  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && (p.K <= 640 || (CONV != 0 && p.Cin <= 640) || nblk < 768));
   if (small) return launch_bk<CONV, EPI, 32>(stream, p, nblk);
   return launch_bk<CONV, EPI, 64>(stream, p, nblk);
 }
@@ -401,7 +422,7 @@ extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, co
   p.R = (const uint16_t*)R; p.ldr = ldr; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
   p.vec16 = (ldy % 8 == 0) && aligned16(Y) && (!R || (ldr % 8 == 0 && aligned16(R))) && (!rowbias || (N % 8 == 0 && aligned16(rowbias)));
-  return launch<false>((hipStream_t)stream, p);
+  return launch<0>((hipStream_t)stream, p);
 }
 
 extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
@@ -423,7 +444,7 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
   p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
-  return launch<true>((hipStream_t)stream, p);
+  return up2x ? launch<2>((hipStream_t)stream, p) : launch<1>((hipStream_t)stream, p);
 }
 
 extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
@@ -435,7 +456,7 @@ extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t l
   p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
   p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N2; p.K = K; p.alpha = 1.f; p.beta = 0.f; p.vec16 = 1;
-  return launch<false, EPI_GEGLU>((hipStream_t)stream, p);
+  return launch<0, EPI_GEGLU>((hipStream_t)stream, p);
 }
 
 extern "C" int a3d_tune_gemm(int bk) {
