@@ -395,9 +395,9 @@ int launch(hipStream_t stream, GemmParams& p) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t nblk = p.tiles_m * p.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
-  // measured on MI355X (profiles/r1_microbench_gemm_bk.log): K-step 32 wins for K <= 640, for 3x3 convs with
-  // Cin <= 640 and whenever the grid is under ~3 workgroups per CU; K-step 64 wins for long contractions
-  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && (p.K <= 640 || (CONV != 0 && p.Cin <= 640) || nblk < 768));
+  // measured on MI355X (profiles/r1_microbench_gemm_conv_v4.log): K-step 32 (3-4 workgroups per CU) wins for dense
+  // K <= 640 and whenever the grid is under ~3 workgroups per CU; K-step 64 wins elsewhere (all 3x3 convs)
+  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && ((CONV == 0 && p.K <= 640) || nblk < 768));
   if (small) return launch_bk<CONV, EPI, 32>(stream, p, nblk);
   return launch_bk<CONV, EPI, 64>(stream, p, nblk);
 }
