@@ -769,7 +769,7 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
 
-int g_flash_variant = 0;   // a3d_tune_flash(): D = 40 main-loop experiments, see the switch in a3d_flash_attn_bf16
+int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default dispatch, 5 = never use the ping-pong kernel (A/B timing)
 
 template <int D, int BKV, int QT, int OFS, int VAR = 0>
 void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
@@ -782,7 +782,11 @@ void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
 }  // namespace
 
 extern "C" int a3d_tune_flash(int variant) {
+#ifdef A3D_ABLATIONS
   if (variant < 0 || variant > 5) return A3D_EINVAL;
+#else
+  if (variant != 0 && variant != 5) return A3D_EINVAL;
+#endif
   g_flash_variant = variant;
   return A3D_OK;
 }
@@ -811,22 +815,17 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
         const int q_tiles = (int)((q_len + 511) / 512);
         const dim3 grid((unsigned)(heads * q_tiles), (unsigned)groups);
         switch (g_flash_variant) {
-          case 1: flash_attn_pp_kernel<40, 1><<<grid, dim3(512), 0, s>>>(p); break;     // ablations (timing only)
+#ifdef A3D_ABLATIONS   // timing ablations: WRONG results by construction; only in -DA3D_ABLATIONS builds (profiles/README.md)
+          case 1: flash_attn_pp_kernel<40, 1><<<grid, dim3(512), 0, s>>>(p); break;
           case 2: flash_attn_pp_kernel<40, 3><<<grid, dim3(512), 0, s>>>(p); break;
           case 3: flash_attn_pp_kernel<40, 4><<<grid, dim3(512), 0, s>>>(p); break;
-          case 4: flash_attn_pp_kernel<40, 32><<<grid, dim3(512), 0, s>>>(p); break;     // exp/cvt interleave experiment
+          case 4: flash_attn_pp_kernel<40, 32><<<grid, dim3(512), 0, s>>>(p); break;
+#endif
           default: flash_attn_pp_kernel<40, 0><<<grid, dim3(512), 0, s>>>(p); break;
         }
         break;
       }
-      switch (g_flash_variant) {
-        case 1: launch<40, 64, 2, OFS_PAD, 1>(aligned, groups, s, p); break;
-        case 2: launch<40, 64, 2, OFS_PAD, 2>(aligned, groups, s, p); break;
-        case 3: launch<40, 64, 2, OFS_PAD, 4>(aligned, groups, s, p); break;
-        case 4: launch<40, 64, 2, OFS_PAD, 5>(aligned, groups, s, p); break;
-        case 5: launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p); break;     // previous default (no ping-pong)
-        default: launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p); break;
-      }
+      launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p);
       break;
     case 80: launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p); break;
     case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;

@@ -97,8 +97,8 @@ int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
                         float scale, float out_scale, int accumulate);
 
-/* Tuning knob (diagnostics): select the flash-attention main-loop variant, 0..5 (see flash_attn.hip).
- * Results are identical up to rounding; used by tools/bench_flash.py for in-process A/B timing. */
+/* Tuning knob (diagnostics, used by tools/microbench.py for in-process A/B timing): 0 = default dispatch,
+ * 5 = never use the 8-wave ping-pong kernel for head_dim 40.  Results are identical for both. */
 int a3d_tune_flash(int variant);
 
 /* Temporal (AnimateDiff) self-attention over the F frames of every (video, pixel, head):

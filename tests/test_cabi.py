@@ -59,3 +59,23 @@ def test_product_never_imports_oracle_or_tests():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", src, flags=re.M), f
+
+
+def test_geglu_interleave_roundtrip_and_rowmap_reference():
+    """Host-side helpers of the boundary that need no GPU: the GEGLU weight interleave is a permutation that the
+    reference op set inverts, and the RowMap formula of include/animate3d_hip.h equals the einops regrouping
+    "(b n f) l -> (b f) (n l)" it replaces (attention_processor.py:54,340)."""
+    import torch
+    from animate3d_amd.hip_ops import HipOps, RowMap
+    from tests.torch_ops import TorchRefOps, rowmap_indices
+    w = torch.arange(128 * 3, dtype=torch.float32).reshape(128, 3)
+    il = HipOps.interleave_geglu(w)
+    assert torch.equal(TorchRefOps.deinterleave_geglu(il), w)
+    assert torch.equal(il[:32], w[:32]) and torch.equal(il[32:64], w[64:96])
+    b, n, f, L = 2, 3, 4, 5
+    rows = torch.arange(b * n * f * L).reshape(b, n, f, L)
+    want = rows.permute(0, 2, 1, 3).reshape(b * f, n * L)                     # "(b n f) l -> (b f) (n l)"
+    got = rowmap_indices(RowMap(f, n * f * L, L, L, f * L), b * f, n * L)
+    assert torch.equal(got, want)
+    first = rows[:, :, 0:1].expand(b, n, f, L).permute(0, 2, 1, 3).reshape(b * f, n * L)   # first-frame K/V, :389-397
+    assert torch.equal(rowmap_indices(RowMap(f, n * f * L, 0, L, f * L), b * f, n * L), first)
