@@ -19,6 +19,9 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libanimate3d_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# flash_attn: the running-max chains use v_max3_f32 directly instead of canonicalising every operand first (the
+# softmax path propagates a NaN score through exp2 regardless, so NaN inputs still give NaN outputs)
+EXTRA_FLAGS = {"flash_attn.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc() -> str:
@@ -37,7 +40,7 @@ def _digest(path: str) -> str:
     for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "animate3d_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
 
 
@@ -56,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj, stamp, dig = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[a3d build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

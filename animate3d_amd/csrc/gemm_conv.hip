@@ -365,6 +365,369 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   }   // tm halves
 }
 
+
+// =====================================================================================================================
+// Persistent 256 x (NB*64) variant for the big token matrices (levels 0-2 of the UNet: M = 32768 ... 524288).
+//
+// One 512-thread workgroup per CU (8 waves as 4(M) x 2(N), each wave owns 64 x NB*32 outputs = 2 x NB MFMA 32x32x16
+// tiles, NB = 5 => BN = 320: every channel count of the model is a multiple of 320, and a full-width N tile means A is
+// read from HBM exactly once at level 0) walks a strided list of output tiles.  Operand K-tiles (64 wide) go global ->
+// LDS directly with global_load_lds_dwordx4 (no staging registers, no ds_write: the ds_write_b128 path of the 128x128
+// kernel costs ~13 LDS cycles per instruction and was the co-limiter with the barrier), two LDS stages, ONE barrier per
+// K-tile.  The LDS image is lane-linear per DMA instruction (8 rows x 128 B), so the bank swizzle
+// (16-byte chunk index ^= (row >> 1) & 7, conflict-free for the 16-lane groups of ds_read_b128) is applied on the
+// per-lane SOURCE address and again on the fragment read address.  The K-tile stream runs across tile boundaries:
+// the first K-tile of the next tile is in flight while the epilogue of the current one drains through the LDS stage
+// that was just consumed, so prologue/epilogue latency is hidden even for the 5-step K = 320 contractions.
+// 3x3 convolutions use the same kernel: the A "row" pointer is the tap-(0,0) pixel, out-of-image taps read a zero page.
+constexpr int PBM = 256;
+template <int NB> struct PCfg {
+  static constexpr int BN = NB * 64;
+  static constexpr int XBYTES = PBM * 128;
+  static constexpr int WBYTES = BN * 128;
+  static constexpr int EPI_BYTES = 8 * 32 * 68 * 4;                    // per-wave 32 x 68 fp32 transposition buffers
+  static constexpr int STAGE = (XBYTES + WBYTES) > EPI_BYTES ? (XBYTES + WBYTES) : EPI_BYTES;
+  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int NPASS = (NB + 1) / 2;                           // epilogue passes of <= 64 columns per 32-row half
+};
+
+__device__ u32x4_t g_zero_page[4];      // 64 zero bytes: source of out-of-image conv taps (device globals are zero-filled)
+
+A3D_DEV uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// LDS-DMA: 64 lanes x 16 B -> LDS[lds_dst + 16 * lane]; the compiler does not count these (s_waitcnt vmcnt by hand)
+A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+A3D_DEV void wave_lds_fence() {          // orders this wave's LDS writes before its later LDS reads (LDS executes a wave's ops in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CONV, int EPI, int NB, bool RES, int VAR>
+__global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p) {
+  using PC = PCfg<NB>;
+  static_assert(CONV == 0 || CONV == 1, "up2x convs use the 128x128 kernel");
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  char* const smem_b = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, g = lane >> 5;
+  const int lr = lane >> 3, pos = lane & 7;            // DMA role: row within the 8-row piece, 16-byte slot
+  const uint32_t lds0 = lds_addr(smem);
+
+  const int64_t ntiles = p.tiles_m * p.tiles_n;
+  const int64_t G = gridDim.x;
+  int64_t t = xcd_remap(blockIdx.x, G);
+  if (t >= ntiles) return;
+  const int nk = (int)(p.K / 64);
+
+  // fragment reads: lane reads row (.. + l31), logical chunk 2*ks + g, stored at chunk ^ ((row >> 1) & 7); every block
+  // base row is a multiple of 16, so the swizzle term depends on the lane only: offset(ks) = koff0 ^ (ks << 5)
+  const uint32_t koff0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
+  const uint32_t xrd = (uint32_t)(wm * 64 + l31) * 128u;
+  const uint32_t wrd = (uint32_t)PC::XBYTES + (uint32_t)(wn * NB * 32 + l31) * 128u;
+
+  // ---- DMA sources.  A DMA piece is 8 consecutive tile rows; its rows are a uniform stride apart, so the piece
+  //      position goes into the scalar base address and the per-lane offset only depends on the piece parity
+  //      (through the swizzle): lane (lr, pos) fetches 16-byte chunk pos ^ ((row >> 1) & 7) of row lr of the piece.
+  // ldx, ldw are multiples of 64 elements here, so the row part has its low 7 bits clear and the odd-piece offset is
+  // the even-piece offset ^ 64 (slot ^ 4)
+  const uint32_t vx0 = (uint32_t)(lr * p.ldx * 2 + ((pos ^ (lr >> 1)) << 4));
+  const uint32_t vw0 = (uint32_t)(lr * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4));
+  // conv: byte offset of the row's tap-(0,0) pixel from (X - cbias) and two 9-bit in-image tap masks per register
+  uint32_t aoff[CONV ? 4 : 1];
+  uint32_t amask[CONV ? 2 : 1];
+  const int64_t cbias = CONV ? ((int64_t)p.Wd + 1) * p.Cin : 0;
+  int64_t ld_m0 = 0, ld_n0 = 0;         // origin of the tile being loaded
+  int ik0 = 0, itap = 0, ici0 = 0;      // K position of the next K-tile to request (running state: no divisions in the loop)
+  auto setup_tile = [&](int64_t tt) {
+    const int64_t tile_n = tt % p.tiles_n, tile_m = tt / p.tiles_n;
+    ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
+    ik0 = 0; itap = 0; ici0 = 0;
+    if constexpr (CONV != 0) {
+      amask[0] = 0; amask[1] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (wid * 4 + i) * 8 + lr;
+        const int slot = pos ^ ((r >> 1) & 7);
+        const int64_t m = ld_m0 + r;
+        const int hw = p.Ho * p.Wo;
+        const int b = (int)(m / hw);
+        const int rem = (int)(m - (int64_t)b * hw);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+        aoff[i] = (uint32_t)(((((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + cbias) * 2 + slot * 16);
+        uint32_t mask = 0;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int yy = y0 + tp / 3, xx = x0 + tp % 3;
+          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1u << tp;
+        }
+        amask[i >> 1] |= mask << (9 * (i & 1));
+      }
+    }
+  };
+  auto issue = [&](int buf) {
+    const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
+    if constexpr (CONV != 0) {
+      const int ky = itap / 3, kx = itap - ky * 3;
+      const uint16_t* xb = p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t d = dst + (uint32_t)(wid * 4 + i) * 1024u;
+        if ((amask[i >> 1] >> (itap + 9 * (i & 1))) & 1u) glds16_s(aoff[i], xb, d);
+        else glds16_s(0u, g_zero_page, d);                   // out-of-image tap: the piece's other lanes still come from X
+      }
+      ici0 += 64;
+      if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pc = wid * 4 + i;
+        glds16_s(vx0 ^ (uint32_t)((i & 1) << 6), p.X + (ld_m0 + pc * 8) * p.ldx + ik0, dst + (uint32_t)pc * 1024u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int pc = wid * NB + i;
+      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), p.W + (ld_n0 + pc * 8) * p.ldw + ik0, dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
+    }
+    ik0 += 64;
+  };
+
+  f32x16_t acc[NB][2];   // [tn][tm]
+  u32x4_t fx[2][2], fw[2][NB];          // fragment double buffer: k-step ks+1 is requested before the MFMAs of ks issue
+  auto load_frags = [&](int slot, int buf, int ks) {
+    const char* xs = smem_b + buf * PC::STAGE + xrd;
+    const char* ws = smem_b + buf * PC::STAGE + wrd;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) fx[slot][tm] = *reinterpret_cast<const u32x4_t*>(xs + tm * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
+#pragma unroll
+    for (int tn = 0; tn < NB; ++tn) fw[slot][tn] = *reinterpret_cast<const u32x4_t*>(ws + tn * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
+  };
+  auto mfma_step = [&](int slot) {
+#pragma unroll
+    for (int tn = 0; tn < NB; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[slot][tn], fx[slot][tm], acc[tn][tm]);
+  };
+
+  setup_tile(t);
+  issue(0);
+  int buf = 0;
+  for (;;) {
+    const int64_t tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
+    const int64_t tnext = t + G;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of K-tile kt have landed
+      __builtin_amdgcn_s_barrier();                         // ... everybody's have, and stage buf^1 is no longer read
+      load_frags(0, buf, 0);
+      if (kt + 1 < nk) {
+        issue(buf ^ 1);
+      } else if (tnext < ntiles) {
+        setup_tile(tnext);
+        issue(buf ^ 1);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) load_frags((ks + 1) & 1, buf, ks + 1);
+        if constexpr (VAR == 1) __builtin_amdgcn_sched_barrier(0);     // all 7 fragment reads of ks+1 ahead of the MFMAs of ks
+        mfma_step(ks & 1);
+        if constexpr (VAR == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      buf ^= 1;
+    }
+    __builtin_amdgcn_s_barrier();                           // stage buf^1 (just consumed) becomes the epilogue staging area
+
+    // ---- epilogue: per 32-row half and <= 64-column pass, transpose through a wave-private LDS buffer so that each
+    //      lane owns 8 consecutive output columns (16-byte bias / rowbias / residual / output accesses)
+    constexpr int SROW = 68;
+    float* const stg = reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * SROW);
+    constexpr int NP = PC::NPASS;
+    u32x4_t rres[RES ? 2 : 1][RES ? 4 : 1];
+    auto pass_cols = [&](int ps) { return (2 * ps + 1 < NB) ? 64 : 32; };
+    auto load_res = [&](int pi, int slot) {
+      if constexpr (RES) {
+        const int tm = pi / NP, ps = pi % NP;
+        const int64_t mbase = m0 + wm * 64 + tm * 32;
+        const int64_t nbase = n0 + wn * NB * 32 + ps * 64;
+        if (pass_cols(ps) == 64) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t m = mbase + 8 * j + (lane >> 3);
+            rres[slot][j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + nbase + 8 * (lane & 7));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int64_t m = mbase + 16 * j + (lane >> 2);
+            rres[slot][j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + nbase + 8 * (lane & 3));
+          }
+        }
+      }
+    };
+    if constexpr (RES) load_res(0, 0);
+#pragma unroll
+    for (int pi = 0; pi < 2 * NP; ++pi) {
+      const int tm = pi / NP, ps = pi % NP;
+      const int ncol = pass_cols(ps);
+      if constexpr (RES) { if (pi + 1 < 2 * NP) load_res(pi + 1, (pi + 1) & 1); }
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const int tn = 2 * ps + tl;
+        if (tn < NB) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v;
+            v.x = acc[tn][tm][4 * q]; v.y = acc[tn][tm][4 * q + 1]; v.z = acc[tn][tm][4 * q + 2]; v.w = acc[tn][tm][4 * q + 3];
+            *reinterpret_cast<float4*>(stg + l31 * SROW + tl * 32 + 8 * q + 4 * g) = v;
+          }
+        }
+      }
+      wave_lds_fence();
+      const int64_t mbase = m0 + wm * 64 + tm * 32;
+      const int64_t nbase = n0 + wn * NB * 32 + ps * 64;      // first column of this pass
+
+      if constexpr (EPI == EPI_GEGLU) {
+        // NB is even here: columns [0,32) of the pass are h, [32,64) the matching gates
+        const int cc = lane & 3;
+        const int64_t nh = nbase + 8 * cc;
+        const int64_t oc = nbase / 2 + 8 * cc;
+        float bh[8], bg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? p.bias[nh + e] : 0.f; bg[e] = p.bias ? p.bias[nh + 32 + e] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = 16 * j + (lane >> 2);
+          const int64_t m = mbase + row;
+          const float4 h0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
+          const float4 h1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
+          const float4 g0 = *reinterpret_cast<const float4*>(stg + row * SROW + 32 + 8 * cc);
+          const float4 g1 = *reinterpret_cast<const float4*>(stg + row * SROW + 32 + 8 * cc + 4);
+          const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = (hv[e] + bh[e]) * gelu_erf(gv[e] + bg[e]);
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack2bf(y[2 * e], y[2 * e + 1]);
+          *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
+        }
+      } else {
+        const int lpr = ncol / 8;                                // lanes per row: 8 (64 columns) or 4 (32 columns)
+        const int cc = lane & (lpr - 1);
+        const int64_t n = nbase + 8 * cc;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j * (64 / lpr) >= 32) continue;                    // 32-column pass: two row groups of 16
+          const int row = (64 / lpr) * j + lane / lpr;
+          const int64_t m = mbase + row;
+          const float4 a0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
+          const float4 a1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
+          float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[e];
+          if (p.rowbias) {
+            const u32x4_t tb = *reinterpret_cast<const u32x4_t*>(p.rowbias + (m / p.rb_div) * p.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(tb[e]); v[2 * e + 1] += hi_bf(tb[e]); }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          if constexpr (RES) {
+            const u32x4_t tr = rres[pi & 1][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(tr[e]); v[2 * e + 1] += p.beta * hi_bf(tr[e]); }
+          }
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+          *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + n) = o;
+        }
+      }
+      wave_lds_fence();
+    }
+    if (tnext >= ntiles) break;
+    t = tnext;
+  }
+}
+
+int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
+                         // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
+
+template <int CONV, int EPI, int NB, bool RES, int VAR = 0>
+int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
+  using PC = PCfg<NB>;
+  if constexpr (VAR == 0) {
+    if (g_gemm_persist == 2) return launch_persist_res<CONV, EPI, NB, RES, 1>(stream, p, cus);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<CONV, EPI, NB, RES, VAR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int64_t ntiles = p.tiles_m * p.tiles_n;
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  gemm_persist_kernel<CONV, EPI, NB, RES, VAR><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
+  return a3d_launch_status();
+}
+
+// returns -1000 when the shape is not eligible (caller falls back to the 128x128 kernel)
+template <int CONV, int EPI>
+int try_launch_persist(hipStream_t stream, GemmParams& p) {
+  if (!g_gemm_persist || CONV == 2) return -1000;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1000;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0) return -1000;
+  const int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
+  if (nb == 0) return -1000;
+  // 32-bit DMA offsets
+  if (p.ldw % 64 != 0 || (CONV == 0 && p.ldx % 64 != 0)) return -1000;
+  if (CONV == 0 && (uint64_t)p.ldx * 16u >= (1ull << 31)) return -1000;
+  if ((uint64_t)p.ldw * 16u >= (1ull << 31)) return -1000;
+  if (CONV != 0 && ((uint64_t)p.B * p.H * p.Wd + 2u * p.Wd + 2u) * (uint64_t)p.Cin * 2u >= (1ull << 32)) return -1000;
+  const int64_t tiles_m = (p.M + PBM - 1) / PBM, tiles_n = p.N / (nb * 64);
+  const int64_t ntiles = tiles_m * tiles_n;
+  const int64_t rounds = (ntiles + cus - 1) / cus;
+  if (ntiles < (3 * cus) / 4 || ntiles * 5 < rounds * cus * 4) return -1000;       // < 80 % of the last round filled
+  p.tiles_m = tiles_m; p.tiles_n = tiles_n;
+  if constexpr (EPI == EPI_GEGLU) {
+    return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
+  } else {
+    if (nb == 5) return p.R ? launch_persist_res<CONV, EPI, 5, true>(stream, p, cus) : launch_persist_res<CONV, EPI, 5, false>(stream, p, cus);
+    return p.R ? launch_persist_res<CONV, EPI, 4, true>(stream, p, cus) : launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
+  }
+}
+
 int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
 
 template <int CONV, int EPI, int BKT, bool RES>
@@ -391,6 +754,10 @@ int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
 
 template <int CONV, int EPI = EPI_LINEAR>
 int launch(hipStream_t stream, GemmParams& p) {
+  if constexpr (CONV != 2) {
+    const int rc = try_launch_persist<CONV, EPI>(stream, p);
+    if (rc != -1000) return rc;
+  }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t nblk = p.tiles_m * p.tiles_n;
@@ -460,6 +827,7 @@ extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t l
 }
 
 extern "C" int a3d_tune_gemm(int bk) {
+  if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;
   return A3D_OK;

@@ -67,7 +67,10 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
 
-/* Tuning knob (diagnostics): force the GEMM / conv K-step, 32 or 64; 0 = automatic (32 when K <= 640). */
+/* Tuning knob (diagnostics / A-B measurements; results are bit-identical in every mode):
+ *   32 | 64  force the K-step of the 128x128-tile kernel, 0 = automatic;
+ *   1        disable the persistent 256x320 LDS-DMA kernel (every shape takes the 128x128-tile kernel);
+ *   2 | 3    enable it with a compiler-scheduled / pinned fragment prefetch (3 is the default). */
 int a3d_tune_gemm(int bk);
 
 /* Fused feed-forward input projection + GEGLU (diffusers FeedForward.net[0] = GEGLU: proj, chunk(2), h * gelu(gate)):

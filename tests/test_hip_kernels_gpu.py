@@ -96,6 +96,76 @@ def test_gemm_layout_asymmetric(ops):
     assert torch.equal(y, w.t().contiguous())
 
 
+# The big token matrices (M % 256 == 0, >= 192 output tiles of 256 x 320 / 256 x 256) take the persistent LDS-DMA kernel;
+# a3d_tune_gemm(1) forces the 128 x 128 kernel, whose K order and epilogue arithmetic are identical => bit-equal outputs.
+def _persistent_eligible(M, N, geglu=False, cus=256):
+    nb = (4 if N % 256 == 0 else 0) if geglu else (5 if N % 320 == 0 else (4 if N % 256 == 0 else 0))
+    if nb == 0 or M % 256:
+        return False
+    tiles = (M // 256) * (N // (64 * nb))
+    rounds = -(-tiles // cus)
+    return tiles >= 3 * cus // 4 and tiles * 5 >= rounds * cus * 4
+
+
+def _both_paths(ops, fn):
+    try:
+        assert ops.lib.a3d_tune_gemm(1) == 0
+        classic = fn()
+        assert ops.lib.a3d_tune_gemm(2) == 0
+        unpinned = fn()
+    finally:
+        assert ops.lib.a3d_tune_gemm(3) == 0       # the default
+    return fn(), classic, unpinned
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 320, 64), (65536, 320, 320), (65536, 640, 192), (65536, 256, 128), (49152, 1280, 128), (24576, 2560, 64)])
+def test_gemm_persistent_path(ops, ref, M, N, K):
+    assert _persistent_eligible(M, N)          # same rule as try_launch_persist() in csrc/gemm_conv.hip
+    x, w = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5)
+    bias = rnd(N, seed=13, dtype=torch.float32)
+    res = rnd(M, N, seed=14)
+    rb = rnd(M // 4096, N, seed=15)
+    for name, kw in (("plain", {}), ("residual", dict(residual=res, alpha=0.5, beta=1.0)), ("rowbias+res", dict(rowbias=rb, rb_div=4096, residual=res))):
+        got, classic, pinned = _both_paths(ops, lambda: ops.gemm(x, w, bias, **kw))
+        check(f"gemm persistent {name} {M}x{N}x{K}", got, ref.gemm(x, w, bias, **kw))
+        assert torch.equal(got, classic), f"persistent vs 128x128 kernel differ ({name})"
+        assert torch.equal(got, pinned), f"persistent variants differ ({name})"
+    big = rnd(M, 3 * K, seed=16)
+    xs = big[:, K:2 * K]
+    out = torch.zeros(M, 2 * N, device="cuda", dtype=BF)
+    ops.gemm(xs, w, bias, out=out[:, N:])
+    check("gemm persistent strided", out[:, N:], ref.gemm(xs, w, bias))
+    assert (out[:, :N] == 0).all()
+
+
+@pytest.mark.parametrize("M,N2,K", [(65536, 512, 64), (49152, 2560, 320)])
+def test_gemm_geglu_persistent_path(ops, ref, M, N2, K):
+    assert _persistent_eligible(M, N2, geglu=True)
+    x, w = rnd(M, K, seed=21), rnd(N2, K, seed=22, scale=K ** -0.5)
+    bias = rnd(N2, seed=23, dtype=torch.float32)
+    w_il, b_il = ops.interleave_geglu(w), ops.interleave_geglu(bias)
+    got, classic, pinned = _both_paths(ops, lambda: ops.gemm_geglu(x, w_il, b_il))
+    check(f"gemm_geglu persistent {M}x{N2}x{K}", got, ref.geglu(ref.gemm(x, w, bias)))
+    assert torch.equal(got, classic) and torch.equal(got, pinned)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(16, 64, 64, 64, 320, 1), (64, 32, 32, 128, 320, 1), (64, 64, 64, 64, 320, 2),
+                                                    (64, 32, 32, 64, 256, 1), (256, 16, 16, 192, 640, 1)])
+def test_conv3x3_persistent_path(ops, ref, B, H, W, Cin, Cout, stride):
+    x, w = rnd(B * H * W, Cin, seed=31), rnd(Cout, 9 * Cin, seed=32, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=33, dtype=torch.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert _persistent_eligible(B * Ho * Wo, Cout)
+    res = rnd(B * Ho * Wo, Cout, seed=34)
+    rb = rnd(B, Cout, seed=35)
+    for name, kw in (("plain", {}), ("rowbias", dict(rowbias=rb, rb_div=Ho * Wo)), ("residual", dict(residual=res))):
+        (got, _, _), (classic, _, _), (pinned, _, _) = _both_paths(ops, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=stride, **kw))
+        want, _, _ = ref.conv3x3(x, B, H, W, w, bias, stride=stride, **kw)
+        check(f"conv persistent {name} B{B} {H}x{W} {Cin}->{Cout} s{stride}", got, want)
+        assert torch.equal(got, classic), f"persistent vs 128x128 conv differ ({name})"
+        assert torch.equal(got, pinned)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(2, 8, 12, 64, 128, 1, False), (3, 8, 8, 128, 64, 2, False),
                                                       (2, 6, 4, 64, 320, 1, True), (1, 16, 16, 320, 4, 1, False),
                                                       (2, 5, 7, 64, 64, 2, False)])

@@ -93,6 +93,58 @@ def bench_conv(ops):
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + "  ||  ".join(out))
 
 
+def bench_persist(ops):
+    """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernel ((2), (3) = pinned fragment prefetch)."""
+    print("== persistent GEMM A/B: median ms / TFLOP/s / effective GB/s;  classic | persistent | persistent pinned   [+res = with residual]")
+    shapes = [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (524288, 320, 1280),
+              (131072, 640, 640), (131072, 1920, 640), (131072, 640, 2560), (32768, 1280, 1280), (32768, 3840, 1280), (32768, 1280, 5120)]
+    for (M, N, K) in shapes:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N)
+        fl = 2.0 * M * N * K
+        for tag, kw, byts in (("     ", {}, 2.0 * (M * K + M * N)), (" +res", dict(residual=res), 2.0 * (M * K + 2 * M * N))):
+            outs, ref = [], None
+            for mode in (1, 2, 3):
+                ops.lib.a3d_tune_gemm(mode)
+                y = ops.gemm(x, w, bias, **kw)
+                ref = y if ref is None else ref
+                med, mn = timeit(lambda: ops.gemm(x, w, bias, **kw), reps=7)
+                outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s {byts / med / 1e6:5.0f} GB/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
+            ops.lib.a3d_tune_gemm(3)
+            print(f"M={M:7d} N={N:5d} K={K:5d}{tag}: " + " | ".join(outs))
+    print("-- fused GEGLU projection")
+    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
+        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
+        bias = torch.randn(N2, device="cuda")
+        fl = 2.0 * M * N2 * K
+        outs, ref = [], None
+        for mode in (1, 2, 3):
+            ops.lib.a3d_tune_gemm(mode)
+            y = ops.gemm_geglu(x, w, bias)
+            ref = y if ref is None else ref
+            med, mn = timeit(lambda: ops.gemm_geglu(x, w, bias), reps=7)
+            outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
+        ops.lib.a3d_tune_gemm(3)
+        print(f"M={M:7d} N2={N2:5d} K={K:5d}: " + " | ".join(outs))
+    print("-- conv3x3")
+    for (B, H, W, Cin, Cout, st) in [(128, 64, 64, 320, 320, 1), (128, 64, 64, 640, 320, 1), (128, 32, 32, 640, 640, 1), (128, 32, 32, 1280, 640, 1),
+                                     (128, 16, 16, 1280, 1280, 1), (128, 16, 16, 2560, 1280, 1), (128, 64, 64, 320, 320, 2)]:
+        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
+        bias = torch.randn(Cout, device="cuda")
+        Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+        fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
+        outs, ref = [], None
+        for mode in (1, 2, 3):
+            ops.lib.a3d_tune_gemm(mode)
+            y = ops.conv3x3(x, B, H, W, w, bias, stride=st)[0]
+            ref = y if ref is None else ref
+            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st), reps=5)
+            outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
+        ops.lib.a3d_tune_gemm(3)
+        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st}: " + " | ".join(outs))
+
+
 def bench_misc(ops):
     print("== memory-bound kernels at level 0 ([524288, 320] tokens); median ms / effective GB/s (algorithmic bytes)")
     M, C, V, F, L = 524288, 320, 8, 16, 4096
@@ -117,7 +169,7 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+        {"flash": bench_flash, "persist": bench_persist, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
