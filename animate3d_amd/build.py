@@ -19,9 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libanimate3d_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-# flash_attn: the running-max chains use v_max3_f32 directly instead of canonicalising every operand first (the
-# softmax path propagates a NaN score through exp2 regardless, so NaN inputs still give NaN outputs)
-EXTRA_FLAGS = {"flash_attn.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {}      # per-file additions, e.g. {"flash_attn.hip": ["-fno-honor-nans"]} (measured: no effect, not used)
 
 
 def _hipcc() -> str:

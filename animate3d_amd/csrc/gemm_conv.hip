@@ -40,6 +40,7 @@ struct GemmParams {
   int64_t M, N, K;
   float alpha, beta;
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
+  int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up;
   int64_t tiles_n, tiles_m;
@@ -387,7 +388,9 @@ template <int NB> struct PCfg {
   static constexpr int WBYTES = BN * 128;
   static constexpr int EPI_BYTES = 8 * 32 * 68 * 4;                    // per-wave 32 x 68 fp32 transposition buffers
   static constexpr int STAGE = (XBYTES + WBYTES) > EPI_BYTES ? (XBYTES + WBYTES) : EPI_BYTES;
-  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int BIAS_OFF = 2 * STAGE;                           // [2 tile parities][bias fp32 @0 | rowbias bf16 @1280]
+  static constexpr int BIAS_STRIDE = 2048;
+  static constexpr int SMEM = 2 * STAGE + 2 * BIAS_STRIDE;
   static constexpr int NPASS = (NB + 1) / 2;                           // epilogue passes of <= 64 columns per 32-row half
 };
 
@@ -450,11 +453,13 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   uint32_t amask[CONV ? 2 : 1];
   const int64_t cbias = CONV ? ((int64_t)p.Wd + 1) * p.Cin : 0;
   int64_t ld_m0 = 0, ld_n0 = 0;         // origin of the tile being loaded
+  int ld_par = 0;                       // bias-area parity of the tile being loaded
   int ik0 = 0, itap = 0, ici0 = 0;      // K position of the next K-tile to request (running state: no divisions in the loop)
   auto setup_tile = [&](int64_t tt) {
     const int64_t tile_n = tt % p.tiles_n, tile_m = tt / p.tiles_n;
     ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
     ik0 = 0; itap = 0; ici0 = 0;
+    ld_par ^= 1;
     if constexpr (CONV != 0) {
       amask[0] = 0; amask[1] = 0;
 #pragma unroll
@@ -480,6 +485,18 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   };
   auto issue = [&](int buf) {
     const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
+    if (ik0 == 0) {
+      // per-tile epilogue vectors ride along with the first K-tile: bias (fp32, BN floats) and the tile's rowbias row
+      // (bf16; rb_div is a multiple of 256 here, so all 256 rows of the tile share it) -> no global loads in the epilogue
+      const uint32_t bdst = lds0 + (uint32_t)PC::BIAS_OFF + (uint32_t)ld_par * PC::BIAS_STRIDE;
+      if (p.bias) {
+        if (wid == 0) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0, bdst);
+        if (NB == 5 && wid == 1) { if (lane < 16) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0 + 256, bdst + 1024u); }
+      }
+      if (EPI == EPI_LINEAR && p.rowbias && wid == 2) {
+        if (lane < PC::BN / 8) glds16_s((uint32_t)lane * 16u, p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0, bdst + 1280u);
+      }
+    }
     if constexpr (CONV != 0) {
       const int ky = itap / 3, kx = itap - ky * 3;
       const uint16_t* xb = p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
@@ -526,6 +543,10 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   setup_tile(t);
   issue(0);
   int buf = 0;
+  bool first_tile = true;
+  // VMEM stores one wave issues per epilogue: they are the newest entries of the (in-order) vmcnt queue at the next
+  // tile's first wait, so vmcnt(NST) retires the K-tile DMA in front of them without draining the stores
+  constexpr int NST = (EPI == EPI_GEGLU) ? 2 * 2 * PC::NPASS : 2 * (4 * (NB / 2) + 2 * (NB & 1));
   for (;;) {
     const int64_t tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
     const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
@@ -537,8 +558,11 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    const int cur_par = ld_par;                             // bias-area parity of THIS tile (ld_par flips when the next is set up)
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of K-tile kt have landed
+      // this wave's DMA pieces of K-tile kt have landed ...
+      if (kt == 0 && !first_tile && p.vm_counted) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                         // ... everybody's have, and stage buf^1 is no longer read
       load_frags(0, buf, 0);
       if (kt + 1 < nk) {
@@ -563,6 +587,8 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
     constexpr int SROW = 68;
     float* const stg = reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * SROW);
     constexpr int NP = PC::NPASS;
+    const float* const bias_lds = reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE);
+    const uint16_t* const rowbias_lds = reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280);
     u32x4_t rres[RES ? 2 : 1][RES ? 4 : 1];
     auto pass_cols = [&](int ps) { return (2 * ps + 1 < NB) ? 64 : 32; };
     auto load_res = [&](int pi, int slot) {
@@ -613,8 +639,11 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         const int64_t nh = nbase + 8 * cc;
         const int64_t oc = nbase / 2 + 8 * cc;
         float bh[8], bg[8];
+        {
+          const float* bl = bias_lds + (wn * NB * 32 + ps * 64 + 8 * cc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? p.bias[nh + e] : 0.f; bg[e] = p.bias ? p.bias[nh + 32 + e] : 0.f; }
+          for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? bl[e] : 0.f; bg[e] = p.bias ? bl[32 + e] : 0.f; }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int row = 16 * j + (lane >> 2);
@@ -637,9 +666,12 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         const int lpr = ncol / 8;                                // lanes per row: 8 (64 columns) or 4 (32 columns)
         const int cc = lane & (lpr - 1);
         const int64_t n = nbase + 8 * cc;
+        const int ncl = wn * NB * 32 + ps * 64 + 8 * cc;          // column within the tile
         float bv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
+        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? bias_lds[ncl + e] : 0.f;
+        u32x4_t tb = {0u, 0u, 0u, 0u};
+        if (p.rowbias) tb = *reinterpret_cast<const u32x4_t*>(rowbias_lds + ncl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j * (64 / lpr) >= 32) continue;                    // 32-column pass: two row groups of 16
@@ -651,7 +683,6 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bv[e];
           if (p.rowbias) {
-            const u32x4_t tb = *reinterpret_cast<const u32x4_t*>(p.rowbias + (m / p.rb_div) * p.N + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(tb[e]); v[2 * e + 1] += hi_bf(tb[e]); }
           }
@@ -672,9 +703,11 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
     }
     if (tnext >= ntiles) break;
     t = tnext;
+    first_tile = false;
   }
 }
 
+int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
 
@@ -707,7 +740,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1000;
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0) return -1000;
+  if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return -1000;
   const int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
   if (nb == 0) return -1000;
   // 32-bit DMA offsets
@@ -720,6 +753,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   const int64_t rounds = (ntiles + cus - 1) / cus;
   if (ntiles < (3 * cus) / 4 || ntiles * 5 < rounds * cus * 4) return -1000;       // < 80 % of the last round filled
   p.tiles_m = tiles_m; p.tiles_n = tiles_n;
+  p.vm_counted = g_gemm_vm_counted;
   if constexpr (EPI == EPI_GEGLU) {
     return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
   } else {
@@ -828,6 +862,7 @@ extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t l
 
 extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
+  if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;
   return A3D_OK;

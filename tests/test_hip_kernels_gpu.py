@@ -113,9 +113,16 @@ def _both_paths(ops, fn):
         classic = fn()
         assert ops.lib.a3d_tune_gemm(2) == 0
         unpinned = fn()
+        assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(4) == 0     # every store drained before each tile
+        drained = fn()
+        assert torch.equal(drained[0] if isinstance(drained, tuple) else drained, classic[0] if isinstance(classic, tuple) else classic)
     finally:
-        assert ops.lib.a3d_tune_gemm(3) == 0       # the default
-    return fn(), classic, unpinned
+        assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(5) == 0     # the defaults
+    got = fn()
+    for _ in range(2):                              # the counted-vmcnt pipeline must be deterministic run to run
+        again = fn()
+        assert torch.equal(again[0] if isinstance(again, tuple) else again, got[0] if isinstance(got, tuple) else got)
+    return got, classic, unpinned
 
 
 @pytest.mark.parametrize("M,N,K", [(65536, 320, 64), (65536, 320, 320), (65536, 640, 192), (65536, 256, 128), (49152, 1280, 128), (24576, 2560, 64)])

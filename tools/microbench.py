@@ -9,7 +9,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import animate3d_amd.hip_ops as _hip_ops  # noqa: E402
 from animate3d_amd.hip_ops import HipOps, RowMap  # noqa: E402
+
+if os.environ.get("A3D_LIB"):        # A/B of two builds of the library (this tool only; the package always loads the in-tree one)
+    _hip_ops._LIB_PATH = os.environ["A3D_LIB"]
 
 BF = torch.bfloat16
 
@@ -94,8 +98,13 @@ def bench_conv(ops):
 
 
 def bench_persist(ops):
-    """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernel ((2), (3) = pinned fragment prefetch)."""
-    print("== persistent GEMM A/B: median ms / TFLOP/s / effective GB/s;  classic | persistent | persistent pinned   [+res = with residual]")
+    """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernel (3) with all stores drained before each
+    tile (4) or left in flight behind a counted vmcnt wait (5, default)."""
+    print("== persistent GEMM A/B: median ms / TFLOP/s / effective GB/s;  classic | persistent, drained | persistent, counted wait   [+res = with residual]")
+    MODES = ((1, 5), (3, 4), (3, 5))
+
+    def set_mode(m):
+        ops.lib.a3d_tune_gemm(m[0]); ops.lib.a3d_tune_gemm(m[1])
     shapes = [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (524288, 320, 1280),
               (131072, 640, 640), (131072, 1920, 640), (131072, 640, 2560), (32768, 1280, 1280), (32768, 3840, 1280), (32768, 1280, 5120)]
     for (M, N, K) in shapes:
@@ -105,13 +114,13 @@ def bench_persist(ops):
         fl = 2.0 * M * N * K
         for tag, kw, byts in (("     ", {}, 2.0 * (M * K + M * N)), (" +res", dict(residual=res), 2.0 * (M * K + 2 * M * N))):
             outs, ref = [], None
-            for mode in (1, 2, 3):
-                ops.lib.a3d_tune_gemm(mode)
+            for mode in MODES:
+                set_mode(mode)
                 y = ops.gemm(x, w, bias, **kw)
                 ref = y if ref is None else ref
                 med, mn = timeit(lambda: ops.gemm(x, w, bias, **kw), reps=7)
                 outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s {byts / med / 1e6:5.0f} GB/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-            ops.lib.a3d_tune_gemm(3)
+            set_mode((3, 5))
             print(f"M={M:7d} N={N:5d} K={K:5d}{tag}: " + " | ".join(outs))
     print("-- fused GEGLU projection")
     for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
@@ -119,13 +128,13 @@ def bench_persist(ops):
         bias = torch.randn(N2, device="cuda")
         fl = 2.0 * M * N2 * K
         outs, ref = [], None
-        for mode in (1, 2, 3):
-            ops.lib.a3d_tune_gemm(mode)
+        for mode in MODES:
+            set_mode(mode)
             y = ops.gemm_geglu(x, w, bias)
             ref = y if ref is None else ref
             med, mn = timeit(lambda: ops.gemm_geglu(x, w, bias), reps=7)
             outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        ops.lib.a3d_tune_gemm(3)
+        set_mode((3, 5))
         print(f"M={M:7d} N2={N2:5d} K={K:5d}: " + " | ".join(outs))
     print("-- conv3x3")
     for (B, H, W, Cin, Cout, st) in [(128, 64, 64, 320, 320, 1), (128, 64, 64, 640, 320, 1), (128, 32, 32, 640, 640, 1), (128, 32, 32, 1280, 640, 1),
@@ -135,13 +144,13 @@ def bench_persist(ops):
         Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
         fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
         outs, ref = [], None
-        for mode in (1, 2, 3):
-            ops.lib.a3d_tune_gemm(mode)
+        for mode in MODES:
+            set_mode(mode)
             y = ops.conv3x3(x, B, H, W, w, bias, stride=st)[0]
             ref = y if ref is None else ref
             med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st), reps=5)
             outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        ops.lib.a3d_tune_gemm(3)
+        set_mode((3, 5))
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st}: " + " | ".join(outs))
 
 
