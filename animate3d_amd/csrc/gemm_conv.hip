@@ -419,7 +419,6 @@ A3D_DEV void wave_lds_fence() {          // orders this wave's LDS writes before
 template <int CONV, int EPI, int NB, bool RES, int VAR>
 __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p) {
   using PC = PCfg<NB>;
-  static_assert(CONV == 0 || CONV == 1, "up2x convs use the 128x128 kernel");
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   char* const smem_b = reinterpret_cast<char*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -471,15 +470,29 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         const int b = (int)(m / hw);
         const int rem = (int)(m - (int64_t)b * hw);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
-        aoff[i] = (uint32_t)(((((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + cbias) * 2 + slot * 16);
         uint32_t mask = 0;
+        if constexpr (CONV == 2) {
+          // nearest-2x upsample folded into the gather: tap (ky, kx) of output pixel (oy, ox) reads source pixel
+          // ((oy + ky - 1) >> 1, (ox + kx - 1) >> 1) = (sy0 + ((ky + ey) >> 1), sx0 + ((kx + ex) >> 1)) with
+          // sy0 = (oy - 1) >> 1 and ey = 1 for even oy (likewise x): the tap offset is one of four per K-tile
+          const int sy0 = (oy - 1) >> 1, sx0 = (ox - 1) >> 1;
+          aoff[i] = (uint32_t)(((((int64_t)b * p.H + sy0) * p.Wd + sx0) * p.Cin + cbias) * 2 + slot * 16);
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const int yy = y0 + tp / 3, xx = x0 + tp % 3;
-          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1u << tp;
+          for (int tp = 0; tp < 9; ++tp) {
+            const int yy = oy + tp / 3 - 1, xx = ox + tp % 3 - 1;
+            if (yy >= 0 && yy < 2 * p.H && xx >= 0 && xx < 2 * p.Wd) mask |= 1u << tp;
+          }
+          amask[i >> 1] |= (mask << (9 * (i & 1))) | ((uint32_t)(~oy & 1) << (18 + 2 * (i & 1))) | ((uint32_t)(~ox & 1) << (19 + 2 * (i & 1)));
+        } else {
+          const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+          aoff[i] = (uint32_t)(((((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + cbias) * 2 + slot * 16);
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int yy = y0 + tp / 3, xx = x0 + tp % 3;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1u << tp;
+          }
+          amask[i >> 1] |= mask << (9 * (i & 1));
         }
-        amask[i >> 1] |= mask << (9 * (i & 1));
       }
     }
   };
@@ -499,11 +512,17 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
     }
     if constexpr (CONV != 0) {
       const int ky = itap / 3, kx = itap - ky * 3;
-      const uint16_t* xb = p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
+      const uint16_t* xb = CONV == 2 ? p.X + (ici0 - cbias) : p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
+      const uint32_t rowb = (uint32_t)(p.Wd * p.Cin * 2), colb = (uint32_t)(p.Cin * 2);
+      const uint32_t yE = (uint32_t)((ky + 1) >> 1) * rowb, yO = (uint32_t)(ky >> 1) * rowb;
+      const uint32_t xE = (uint32_t)((kx + 1) >> 1) * colb, xO = (uint32_t)(kx >> 1) * colb;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint32_t d = dst + (uint32_t)(wid * 4 + i) * 1024u;
-        if ((amask[i >> 1] >> (itap + 9 * (i & 1))) & 1u) glds16_s(aoff[i], xb, d);
+        const uint32_t mk = amask[i >> 1];
+        uint32_t vo = aoff[i];
+        if constexpr (CONV == 2) vo += (((mk >> (18 + 2 * (i & 1))) & 1u) ? yE : yO) + (((mk >> (19 + 2 * (i & 1))) & 1u) ? xE : xO);
+        if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
         else glds16_s(0u, g_zero_page, d);                   // out-of-image tap: the piece's other lanes still come from X
       }
       ici0 += 64;
@@ -733,7 +752,7 @@ int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
 // returns -1000 when the shape is not eligible (caller falls back to the 128x128 kernel)
 template <int CONV, int EPI>
 int try_launch_persist(hipStream_t stream, GemmParams& p) {
-  if (!g_gemm_persist || CONV == 2) return -1000;
+  if (!g_gemm_persist) return -1000;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -788,7 +807,7 @@ int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
 
 template <int CONV, int EPI = EPI_LINEAR>
 int launch(hipStream_t stream, GemmParams& p) {
-  if constexpr (CONV != 2) {
+  {
     const int rc = try_launch_persist<CONV, EPI>(stream, p);
     if (rc != -1000) return rc;
   }

@@ -156,19 +156,21 @@ def test_gemm_geglu_persistent_path(ops, ref, M, N2, K):
     assert torch.equal(got, classic) and torch.equal(got, pinned)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(16, 64, 64, 64, 320, 1), (64, 32, 32, 128, 320, 1), (64, 64, 64, 64, 320, 2),
-                                                    (64, 32, 32, 64, 256, 1), (256, 16, 16, 192, 640, 1)])
-def test_conv3x3_persistent_path(ops, ref, B, H, W, Cin, Cout, stride):
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(16, 64, 64, 64, 320, 1, False), (64, 32, 32, 128, 320, 1, False), (64, 64, 64, 64, 320, 2, False),
+                                                       (64, 32, 32, 64, 256, 1, False), (256, 16, 16, 192, 640, 1, False),
+                                                       (16, 32, 32, 64, 320, 1, True), (64, 16, 16, 128, 256, 1, True), (4, 64, 128, 64, 320, 1, True)])
+def test_conv3x3_persistent_path(ops, ref, B, H, W, Cin, Cout, stride, up):
     x, w = rnd(B * H * W, Cin, seed=31), rnd(Cout, 9 * Cin, seed=32, scale=(9 * Cin) ** -0.5)
     bias = rnd(Cout, seed=33, dtype=torch.float32)
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    He, We = (2 * H, 2 * W) if up else (H, W)
+    Ho, Wo = (He - 1) // stride + 1, (We - 1) // stride + 1
     assert _persistent_eligible(B * Ho * Wo, Cout)
     res = rnd(B * Ho * Wo, Cout, seed=34)
     rb = rnd(B, Cout, seed=35)
     for name, kw in (("plain", {}), ("rowbias", dict(rowbias=rb, rb_div=Ho * Wo)), ("residual", dict(residual=res))):
-        (got, _, _), (classic, _, _), (pinned, _, _) = _both_paths(ops, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=stride, **kw))
-        want, _, _ = ref.conv3x3(x, B, H, W, w, bias, stride=stride, **kw)
-        check(f"conv persistent {name} B{B} {H}x{W} {Cin}->{Cout} s{stride}", got, want)
+        (got, _, _), (classic, _, _), (pinned, _, _) = _both_paths(ops, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up, **kw))
+        want, _, _ = ref.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up, **kw)
+        check(f"conv persistent {name} B{B} {H}x{W} {Cin}->{Cout} s{stride} up{int(up)}", got, want)
         assert torch.equal(got, classic), f"persistent vs 128x128 conv differ ({name})"
         assert torch.equal(got, pinned)
 

@@ -137,21 +137,23 @@ def bench_persist(ops):
         set_mode((3, 5))
         print(f"M={M:7d} N2={N2:5d} K={K:5d}: " + " | ".join(outs))
     print("-- conv3x3")
-    for (B, H, W, Cin, Cout, st) in [(128, 64, 64, 320, 320, 1), (128, 64, 64, 640, 320, 1), (128, 32, 32, 640, 640, 1), (128, 32, 32, 1280, 640, 1),
-                                     (128, 16, 16, 1280, 1280, 1), (128, 16, 16, 2560, 1280, 1), (128, 64, 64, 320, 320, 2)]:
+    for (B, H, W, Cin, Cout, st, up) in [(128, 64, 64, 320, 320, 1, False), (128, 64, 64, 640, 320, 1, False), (128, 32, 32, 640, 640, 1, False),
+                                         (128, 32, 32, 1280, 640, 1, False), (128, 16, 16, 1280, 1280, 1, False), (128, 16, 16, 2560, 1280, 1, False),
+                                         (128, 64, 64, 320, 320, 2, False), (128, 32, 32, 640, 640, 1, True), (128, 16, 16, 1280, 1280, 1, True)]:
         x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
         bias = torch.randn(Cout, device="cuda")
-        Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+        He, We = (2 * H, 2 * W) if up else (H, W)
+        Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
         fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
         outs, ref = [], None
         for mode in MODES:
             set_mode(mode)
-            y = ops.conv3x3(x, B, H, W, w, bias, stride=st)[0]
+            y = ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up)[0]
             ref = y if ref is None else ref
-            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st), reps=5)
+            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
             outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
         set_mode((3, 5))
-        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st}: " + " | ".join(outs))
+        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + " | ".join(outs))
 
 
 def bench_misc(ops):
