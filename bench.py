@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# HBM traffic of one level-0 attention launch (PMC, not measurable from inside the process): see profiles/r1_flash_pmc_traffic.md
+TRAFFIC_BYTES_PER_LAUNCH = 2.82e9
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -170,7 +172,10 @@ def main():
         achieved = flops / mean_dur / 1e12
         roofline = {"bound": "mfma", "kernel": "flash_attn_kernel<40,64> (level-0 multi-view / first-frame attention)",
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                    "traffic": None, "launches_per_step": len(durs) // args.steps, "mean_launch_ms": mean_dur * 1e3,
+                    "traffic": TRAFFIC_BYTES_PER_LAUNCH if world == 1 else None, "traffic_unit": "HBM bytes per launch",
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 counts 128-B requests as 64 B) and WRITE_SIZE, separate "
+                                      "passes, same launch shape (profiles/r1_flash_pmc_traffic.md); algorithmic bytes 1.34e9",
+                    "launches_per_step": len(durs) // args.steps, "mean_launch_ms": mean_dur * 1e3,
                     "flop_per_launch": flops, "share_of_step_time": sum(durs) / dt}
     else:
         roofline = None
