@@ -403,12 +403,12 @@ A3D_DEV uint32_t lds_addr(const void* p) {
 A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+               : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 A3D_DEV void wave_lds_fence() {          // orders this wave's LDS writes before its later LDS reads (LDS executes a wave's ops in order)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
