@@ -438,7 +438,13 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   // base row is a multiple of 16, so the swizzle term depends on the lane only: offset(ks) = koff0 ^ (ks << 5)
   const uint32_t koff0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
   const uint32_t xrd = (uint32_t)(wm * 64 + l31) * 128u;
-  const uint32_t wrd = (uint32_t)PC::XBYTES + (uint32_t)(wn * NB * 32 + l31) * 128u;
+  // Column blocks of 32 owned by wave column wn (NB = 5): {4 wn .. 4 wn + 3} and 8 + wn, so that the 64-column epilogue
+  // passes of BOTH wave columns start on 128-byte lines of the output rows (a contiguous 160-column split starts wave
+  // column 1 at byte 320 = 2.5 lines and every one of its 128-byte row segments straddles two lines)
+  const int wblk = (NB == 5) ? wn * 4 : wn * NB;        // first column block (local tn 0)
+  const int wblk_last = (NB == 5) ? 8 + wn : wn * NB + NB - 1;
+  const uint32_t wrd = (uint32_t)PC::XBYTES + (uint32_t)(wblk * 32 + l31) * 128u;
+  const uint32_t wrd_last = (uint32_t)PC::XBYTES + (uint32_t)(wblk_last * 32 + l31) * 128u;
 
   // ---- DMA sources.  A DMA piece is 8 consecutive tile rows; its rows are a uniform stride apart, so the piece
   //      position goes into the scalar base address and the per-lane offset only depends on the piece parity
@@ -547,10 +553,12 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   auto load_frags = [&](int slot, int buf, int ks) {
     const char* xs = smem_b + buf * PC::STAGE + xrd;
     const char* ws = smem_b + buf * PC::STAGE + wrd;
+    const char* wl = smem_b + buf * PC::STAGE + wrd_last;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) fx[slot][tm] = *reinterpret_cast<const u32x4_t*>(xs + tm * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
 #pragma unroll
-    for (int tn = 0; tn < NB; ++tn) fw[slot][tn] = *reinterpret_cast<const u32x4_t*>(ws + tn * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
+    for (int tn = 0; tn < NB - 1; ++tn) fw[slot][tn] = *reinterpret_cast<const u32x4_t*>(ws + tn * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
+    fw[slot][NB - 1] = *reinterpret_cast<const u32x4_t*>(wl + (koff0 ^ (uint32_t)(ks << 5)));
   };
   auto mfma_step = [&](int slot) {
 #pragma unroll
@@ -610,11 +618,12 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
     const uint16_t* const rowbias_lds = reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280);
     u32x4_t rres[RES ? 2 : 1][RES ? 4 : 1];
     auto pass_cols = [&](int ps) { return (2 * ps + 1 < NB) ? 64 : 32; };
+    auto pass_col0 = [&](int ps) { return ((2 * ps + 1 < NB) ? wblk + 2 * ps : wblk_last) * 32; };   // first tile column of pass ps
     auto load_res = [&](int pi, int slot) {
       if constexpr (RES) {
         const int tm = pi / NP, ps = pi % NP;
         const int64_t mbase = m0 + wm * 64 + tm * 32;
-        const int64_t nbase = n0 + wn * NB * 32 + ps * 64;
+        const int64_t nbase = n0 + pass_col0(ps);
         if (pass_cols(ps) == 64) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -650,7 +659,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
       }
       wave_lds_fence();
       const int64_t mbase = m0 + wm * 64 + tm * 32;
-      const int64_t nbase = n0 + wn * NB * 32 + ps * 64;      // first column of this pass
+      const int64_t nbase = n0 + pass_col0(ps);               // first column of this pass
 
       if constexpr (EPI == EPI_GEGLU) {
         // NB is even here: columns [0,32) of the pass are h, [32,64) the matching gates
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         const int64_t oc = nbase / 2 + 8 * cc;
         float bh[8], bg[8];
         {
-          const float* bl = bias_lds + (wn * NB * 32 + ps * 64 + 8 * cc);
+          const float* bl = bias_lds + (pass_col0(ps) + 8 * cc);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? bl[e] : 0.f; bg[e] = p.bias ? bl[32 + e] : 0.f; }
         }
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         const int lpr = ncol / 8;                                // lanes per row: 8 (64 columns) or 4 (32 columns)
         const int cc = lane & (lpr - 1);
         const int64_t n = nbase + 8 * cc;
-        const int ncl = wn * NB * 32 + ps * 64 + 8 * cc;          // column within the tile
+        const int ncl = pass_col0(ps) + 8 * cc;                   // column within the tile
         float bv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = p.bias ? bias_lds[ncl + e] : 0.f;
