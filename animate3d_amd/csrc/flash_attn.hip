@@ -781,7 +781,10 @@ void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
 
 }  // namespace
 
+extern int g_a3d_ta_pix;      // temporal_attn.hip
+
 extern "C" int a3d_tune_flash(int variant) {
+  if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
 #ifdef A3D_ABLATIONS
   if (variant < 0 || variant > 5) return A3D_EINVAL;
 #else

@@ -184,6 +184,102 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const LNParams p) {
   }
 }
 
+// Sub-wave rows for the model's widths C = 320 / 640 / 1280 = 40 * LPR: LPR lanes own one row (five 16-byte chunks per
+// lane, chunk = sub + LPR * i => LPR * 16 contiguous bytes per step), a wave normalises 64 / LPR rows at once and loops
+// over LN_BATCH row batches with gamma / beta held in registers.  The one-wave-per-row kernel above leaves 24 of 64 lanes
+// idle at C = 320 and has a single 640-byte load in flight per wave (3.3 TB/s); here every lane has five loads in flight.
+constexpr int LN_BATCH = 4;
+template <int LPR>
+__global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  float ga[5][8], be[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int c = sub + LPR * i;
+    const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c * 8), g1 = *reinterpret_cast<const float4*>(p.gamma + c * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.beta + c * 8), b1 = *reinterpret_cast<const float4*>(p.beta + c * 8 + 4);
+    ga[i][0] = g0.x; ga[i][1] = g0.y; ga[i][2] = g0.z; ga[i][3] = g0.w; ga[i][4] = g1.x; ga[i][5] = g1.y; ga[i][6] = g1.z; ga[i][7] = g1.w;
+    be[i][0] = b0.x; be[i][1] = b0.y; be[i][2] = b0.z; be[i][3] = b0.w; be[i][4] = b1.x; be[i][5] = b1.y; be[i][6] = b1.z; be[i][7] = b1.w;
+  }
+  const float inv_c = 1.f / (float)p.C;
+#pragma unroll 1
+  for (int bt = 0; bt < LN_BATCH; ++bt) {
+    const int64_t m = (((int64_t)blockIdx.x * 4 + wid) * LN_BATCH + bt) * RPW + rsel;
+    const bool ok = m < p.M;
+    const int64_t mm = ok ? m : p.M - 1;
+    const uint16_t* xr = p.X + mm * p.C;
+    u32x4_t raw[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) raw[i] = *reinterpret_cast<const u32x4_t*>(xr + (sub + LPR * i) * 8);
+    float f[5][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { f[i][j] = (j & 1) ? hi_bf(raw[i][j >> 1]) : lo_bf(raw[i][j >> 1]); sum += f[i][j]; }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; sq += d * d; }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * inv_c + p.eps);
+    const uint16_t* e1 = p.pe1 ? p.pe1 + ((mm / p.pe1_div) % p.pe1_mod) * p.C : nullptr;
+    const uint16_t* e2 = (p.Y2 && p.pe2) ? p.pe2 + ((mm / p.pe2_div) % p.pe2_mod) * p.C : nullptr;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = sub + LPR * i;
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (f[i][j] - mean) * rstd * ga[i][j] + be[i][j];
+      {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = y[j];
+        if (e1) {
+          const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e1 + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        if (ok) *reinterpret_cast<u32x4_t*>(p.Y1 + m * p.C + c * 8) = o;
+      }
+      if (p.Y2) {
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = y[j];
+        if (e2) {
+          const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e2 + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        if (ok) *reinterpret_cast<u32x4_t*>(p.Y2 + m * p.C + c * 8) = o;
+      }
+    }
+  }
+}
+
+template <int LPR>
+int launch_ln_rows(hipStream_t s, const LNParams& p) {
+  const int64_t rows_per_block = (int64_t)4 * LN_BATCH * (64 / LPR);
+  const int64_t nblk = (p.M + rows_per_block - 1) / rows_per_block;
+  if (nblk > 0x7fffffffLL) return A3D_EINVAL;
+  layer_norm_rows_kernel<LPR><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(p);
+  return a3d_launch_status();
+}
+
+
 inline int gn_nchunk(int64_t rows) { return (int)((rows + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK); }
 
 }  // namespace
@@ -227,6 +323,11 @@ extern "C" int a3d_layer_norm_bf16(a3d_stream_t stream, const void* X, void* Y1,
   p.M = M; p.C = C; p.eps = eps;
   p.pe1 = (const uint16_t*)pe1; p.pe1_div = pe1 ? pe1_div : 1; p.pe1_mod = pe1 ? pe1_mod : 1;
   p.pe2 = (const uint16_t*)pe2; p.pe2_div = pe2 ? pe2_div : 1; p.pe2_mod = pe2 ? pe2_mod : 1;
+  if (M >= 4096) {          // the token matrices of the UNet; small M (text / IP tokens) keeps one wave per row
+    if (C == 320) return launch_ln_rows<8>((hipStream_t)stream, p);
+    if (C == 640) return launch_ln_rows<16>((hipStream_t)stream, p);
+    if (C == 1280) return launch_ln_rows<32>((hipStream_t)stream, p);
+  }
   const int64_t nblk = (M + 3) / 4;
   if (nblk > 0x7fffffffLL) return A3D_EINVAL;
   layer_norm_kernel<<<dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream>>>(p);

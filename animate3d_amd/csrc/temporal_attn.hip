@@ -12,6 +12,8 @@
 // Every token byte is read from HBM exactly once (the first version re-read K/V F times through L1).
 #include "common.h"
 
+int g_a3d_ta_pix = 1;        // pixels per workgroup at <= 16 frames (a3d_tune_flash(10 + pix), diagnostics; 1 measured fastest)
+
 namespace {
 
 constexpr int SLAB = 320;            // channels per workgroup (one 640-byte row segment)
@@ -39,19 +41,42 @@ __global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAP
   const int64_t pix0 = (int64_t)blockIdx.x * PIX;
   const int c0 = blockIdx.y * SLAB;
 
-  // ---- stage Q, K, V slabs: item = (tensor, frame, pixel, 16-byte chunk)
-  const int chunks = SLAB / 8;                         // 40 chunks per row segment
-  const int items = 3 * F * PIX * chunks;
-  for (int it = tid; it < items; it += blockDim.x) {
+  // ---- stage Q, K, V slabs: item = (tensor, frame, pixel, 16-byte chunk).  When frames == FP (the model's 16) the trip
+  //      count and every divisor are compile-time: all loads are issued back to back, then all LDS writes
+  constexpr int chunks = SLAB / 8;                       // 40 chunks per row segment
+  auto src_of = [&](int it, int Fd) -> const uint16_t* {
     const int ch = it % chunks;
     const int px = (it / chunks) % PIX;
-    const int f = (it / (chunks * PIX)) % F;
-    const int ten = it / (chunks * PIX * F);
+    const int f = (it / (chunks * PIX)) % Fd;
+    const int ten = it / (chunks * PIX * Fd);
     int64_t pix = pix0 + px;
     if (pix >= p.npix) pix = p.npix - 1;
     const int64_t v = pix / p.L, l = pix % p.L;
-    const uint16_t* src = (ten == 0 ? p.Q : (ten == 1 ? p.K : p.V)) + ((v * F + f) * p.L + l) * p.ld + c0 + ch * 8;
-    *reinterpret_cast<u32x4_t*>(smem + ((size_t)ten * F + f) * ROWB + px * SLAB + ch * 8) = *reinterpret_cast<const u32x4_t*>(src);
+    return (ten == 0 ? p.Q : (ten == 1 ? p.K : p.V)) + ((v * Fd + f) * p.L + l) * p.ld + c0 + ch * 8;
+  };
+  auto dst_of = [&](int it, int Fd) -> uint16_t* {
+    const int ch = it % chunks;
+    const int px = (it / chunks) % PIX;
+    const int f = (it / (chunks * PIX)) % Fd;
+    const int ten = it / (chunks * PIX * Fd);
+    return smem + ((size_t)ten * Fd + f) * ROWB + px * SLAB + ch * 8;
+  };
+  if (F == FP) {
+    constexpr int NT = PIX * NSL * FP, ITEMS = 3 * FP * PIX * chunks, NIT = (ITEMS + NT - 1) / NT;
+    u32x4_t stg[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * NT;
+      if (ITEMS % NT == 0 || it < ITEMS) stg[k] = *reinterpret_cast<const u32x4_t*>(src_of(it, FP));
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int it = tid + k * NT;
+      if (ITEMS % NT == 0 || it < ITEMS) *reinterpret_cast<u32x4_t*>(dst_of(it, FP)) = stg[k];
+    }
+  } else {
+    const int items = 3 * F * PIX * chunks;
+    for (int it = tid; it < items; it += blockDim.x) *reinterpret_cast<u32x4_t*>(dst_of(it, F)) = *reinterpret_cast<const u32x4_t*>(src_of(it, F));
   }
   __syncthreads();
 
@@ -153,7 +178,10 @@ int launch(hipStream_t s, const TAParams& p, int C) {
 
 template <int DP>
 int launch_dp(hipStream_t s, const TAParams& p, int C) {
-  if (p.frames <= 16) return launch<16, 2, DP>(s, p, C);     // 256 threads, <= 62 KB LDS
+  // 1 pixel per workgroup (128 threads, <= 31 KB LDS, 5 workgroups per CU) measured 22-28 % faster than 2 pixels: more
+  // independent load / compute phases in flight per CU (profiles/r1_microbench_gemm_conv_misc.log)
+  if (p.frames <= 16 && g_a3d_ta_pix == 2) return launch<16, 2, DP>(s, p, C);   // 256 threads, <= 62 KB LDS
+  if (p.frames <= 16) return launch<16, 1, DP>(s, p, C);
   return launch<32, 1, DP>(s, p, C);                          // 256 threads, <= 62 KB LDS
 }
 

@@ -265,7 +265,8 @@ def test_group_norm(ops, ref, B, rows, C, silu):
           ref.group_norm(x, B, rows, gamma, beta, 32, 1e-5, silu), tol=4e-3, max_ulps=3)
 
 
-@pytest.mark.parametrize("M,C", [(10, 320), (257, 640), (64, 1280), (8, 768)])
+# M >= 4096 with C in {320, 640, 1280} takes the sub-wave-rows kernel (ragged last batch: M not a multiple of the rows per block)
+@pytest.mark.parametrize("M,C", [(10, 320), (257, 640), (64, 1280), (8, 768), (4096, 320), (5003, 320), (4101, 640), (4099, 1280), (6000, 768)])
 def test_layer_norm(ops, ref, M, C):
     x = rnd(M, C, seed=C) * 2 + 0.3
     gamma, beta = 1 + 0.1 * rnd(C, seed=1, dtype=torch.float32), 0.1 * rnd(C, seed=2, dtype=torch.float32)

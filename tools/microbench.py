@@ -169,7 +169,16 @@ def bench_misc(ops):
     u = rnd(M, 8 * C)
     med, _ = timeit(lambda: ops.geglu(u)); print(f"geglu             : {med:7.3f} ms  {M * 12 * C * 2 / med / 1e6:7.0f} GB/s")
     qkv = rnd(M, 3 * C)
-    med, _ = timeit(lambda: ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, 8)); print(f"temporal_attn D40 : {med:7.3f} ms  {4 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    for pix in (2, 1, 4):
+        ops.lib.a3d_tune_flash(10 + pix)
+        med, _ = timeit(lambda: ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, 8)); print(f"temporal_attn D40 pix={pix}: {med:7.3f} ms  {4 * M * C * 2 / med / 1e6:7.0f} GB/s")
+    ops.lib.a3d_tune_flash(12)
+    for (M2, C2, L2) in ((131072, 640, 1024), (32768, 1280, 256)):
+        qkv2 = rnd(M2, 3 * C2)
+        for pix in (2, 1, 4):
+            ops.lib.a3d_tune_flash(10 + pix)
+            med, _ = timeit(lambda: ops.temporal_attn(qkv2[:, :C2], qkv2[:, C2:2 * C2], qkv2[:, 2 * C2:], V, F, L2, 8)); print(f"temporal_attn C={C2} pix={pix}: {med:7.3f} ms  {4 * M2 * C2 * 2 / med / 1e6:7.0f} GB/s")
+        ops.lib.a3d_tune_flash(12)
     a, bb = rnd(M, 640), rnd(M, 320)
     med, _ = timeit(lambda: ops.concat(a, bb)); print(f"concat 640+320    : {med:7.3f} ms  {2 * M * 960 * 2 / med / 1e6:7.0f} GB/s")
 
