@@ -27,14 +27,22 @@ __global__ void gn_partial_kernel(const GNParams p) {
   const int split = (g_lo + 1) * p.cg - ch0;                // first `split` channels belong to g_lo
   float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
   const uint16_t* base = p.X + ((int64_t)b * p.rows) * p.C + ch0;
-  for (int64_t r = r0 + ry; r < r1; r += ny) {
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + r * p.C);
+  auto accum = [&](const u32x4_t& v) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float f = (j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1]);
       if (j < split) { s_lo += f; q_lo += f * f; } else { s_hi += f; q_hi += f * f; }
     }
+  };
+  int64_t r = r0 + ry;
+  for (; r + 3 * ny < r1; r += 4 * ny) {          // four independent row loads in flight per thread, accumulated in row order
+    u32x4_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (r + (int64_t)k * ny) * p.C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) accum(v[k]);
   }
+  for (; r < r1; r += ny) accum(*reinterpret_cast<const u32x4_t*>(base + r * p.C));
   float* mine = spart + ((size_t)ry * nx + c8) * 4;
   mine[0] = s_lo; mine[1] = q_lo; mine[2] = s_hi; mine[3] = q_hi;
   __syncthreads();
@@ -55,12 +63,25 @@ __global__ void gn_partial_kernel(const GNParams p) {
 }
 
 __global__ void gn_finalize_kernel(const GNParams p) {
-  // one block per instance b, one thread per group
-  const int b = blockIdx.x, grp = threadIdx.x;
-  if (grp >= p.groups) return;
+  // one block per instance b: thread (grp, sub) sums chunks sub, sub + nsub, ... (a single thread per group walked all
+  // nchunk partials as one dependent load chain: 512 chunks = 0.1 ms of pure latency for the per-video 3-D norm), then
+  // the nsub partial sums of a group are added in a fixed order (deterministic) in fp64.
+  extern __shared__ double sred[];          // [nsub][groups][2]
+  const int b = blockIdx.x, grp = threadIdx.x, sub = threadIdx.y, nsub = blockDim.y;
   double s = 0.0, q = 0.0;
-  const float* in = p.partial + (int64_t)b * p.nchunk * p.groups * 2 + grp * 2;
-  for (int c = 0; c < p.nchunk; ++c) { s += in[(int64_t)c * p.groups * 2]; q += in[(int64_t)c * p.groups * 2 + 1]; }
+  if (grp < p.groups) {
+    const float* in = p.partial + (int64_t)b * p.nchunk * p.groups * 2 + grp * 2;
+    for (int c = sub; c < p.nchunk; c += nsub) {
+      const float2 v = *reinterpret_cast<const float2*>(in + (int64_t)c * p.groups * 2);
+      s += v.x; q += v.y;
+    }
+    sred[((size_t)sub * p.groups + grp) * 2] = s;
+    sred[((size_t)sub * p.groups + grp) * 2 + 1] = q;
+  }
+  __syncthreads();
+  if (sub != 0 || grp >= p.groups) return;
+  s = 0.0; q = 0.0;
+  for (int k = 0; k < nsub; ++k) { s += sred[((size_t)k * p.groups + grp) * 2]; q += sred[((size_t)k * p.groups + grp) * 2 + 1]; }
   const double n = (double)p.rows * p.cg;
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -85,8 +106,7 @@ __global__ void gn_apply_kernel(const GNParams p) {
     sh[j] = be - mean * rstd * ga;
   }
   const int64_t off = ((int64_t)b * p.rows) * p.C + ch0;
-  for (int64_t r = r0 + ry; r < r1; r += ny) {
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p.X + off + r * p.C);
+  auto apply = [&](const u32x4_t& v, int64_t r) {
     float f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -97,7 +117,16 @@ __global__ void gn_apply_kernel(const GNParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = pack2bf(f[2 * j], f[2 * j + 1]);
     *reinterpret_cast<u32x4_t*>(p.Y + off + r * p.C) = o;
+  };
+  int64_t r = r0 + ry;
+  for (; r + 3 * ny < r1; r += 4 * ny) {          // four independent row loads in flight per thread
+    u32x4_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(p.X + off + (r + (int64_t)k * ny) * p.C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) apply(v[k], r + (int64_t)k * ny);
   }
+  for (; r < r1; r += ny) apply(*reinterpret_cast<const u32x4_t*>(p.X + off + r * p.C), r);
 }
 
 // ---------------- LayerNorm: one wave per row, up to 3 16-byte chunks per lane (C <= 1536)
@@ -305,7 +334,11 @@ extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, 
   const dim3 block(c8, ny), grid(p.nchunk, B);
   hipStream_t s = (hipStream_t)stream;
   gn_partial_kernel<<<grid, block, (size_t)c8 * ny * 4 * sizeof(float), s>>>(p);
-  gn_finalize_kernel<<<dim3(B), dim3((groups + 63) / 64 * 64), 0, s>>>(p);
+  {
+    const int gx = (groups + 31) / 32 * 32;
+    int nsub = 1024 / gx; if (nsub > 32) nsub = 32; if (nsub > p.nchunk) nsub = p.nchunk; if (nsub < 1) nsub = 1;
+    gn_finalize_kernel<<<dim3(B), dim3(gx, nsub), (size_t)nsub * groups * 2 * sizeof(double), s>>>(p);
+  }
   gn_apply_kernel<<<grid, block, 0, s>>>(p);
   return a3d_launch_status();
 }
