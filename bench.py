@@ -191,6 +191,7 @@ def main():
                                    f"batch V={V} videos, one MVUNetMotionModel.forward per step, SD1.5 MV-VDM UNet 1.53 B params, "
                                    "seeded synthetic weights",
                        "parallelism": "single GPU" if world == 1 else f"cfg{model.parallel.cfg_shards} x views{model.parallel.view_shards} (K|V all-gather over RCCL)"},
+            "config2_25_ddim_steps_seconds": 25.0 * ms_per_step / 1e3,
             "flop_per_step": work, "whole_step_tflops": work * value / 1e12,
             "whole_step_mfma_frac": work * value / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roofline,

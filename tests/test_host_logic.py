@@ -99,3 +99,46 @@ def test_tables_against_reference_goldens(golden):
         np.testing.assert_allclose(sine_pos_2d(C // 2, h, w).numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
     for nv in (4, 8):
         np.testing.assert_allclose(get_camera(nv).numpy(), golden[f"camera/{nv}"], rtol=1e-5, atol=1e-6)
+
+
+def _zero_(model, pattern):
+    n = 0
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if pattern(k):
+                v.zero_(); n += 1
+    assert n > 0
+    return n
+
+
+def test_structural_kat_frames_decouple_without_motion_and_i2v():
+    """SURVEY.md §8c KAT (3): with every motion module's proj_out zeroed (and to_out_i2v = 0, its initial value,
+    inference.py:161-165) nothing couples the frames of a video any more, so the F-frame forward must equal the
+    single-frame forwards frame by frame — on the product (token-major layout, row maps) and on the oracle."""
+    n, F, hw = 2, 3, (8, 8)
+    ocfg, ref, model = _pair(n, F, hw)
+    pat = lambda k: ("motion_modules" in k and ".proj_out." in k) or "to_out_i2v" in k
+    _zero_(ref, pat)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    ref1 = O.MVUNetMotionModelRef(ocfg, n, 1, hw).eval()
+    ref1.load_state_dict(ref.state_dict(), strict=True)
+    inp = O.synthetic_inputs(ocfg, n, n, F, hw, seed=11)
+    y_full, yr_full = model(**inp).sample, ref(**inp).sample
+    for f in range(F):
+        one = dict(inp, sample=inp["sample"][:, :, f:f + 1].contiguous())
+        np.testing.assert_allclose(model(**one).sample[:, :, 0].numpy(), y_full[:, :, f].numpy(), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(ref1(**one).sample[:, :, 0].numpy(), yr_full[:, :, f].numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_structural_kat_alpha_zero_is_vanilla_motion_module():
+    """SURVEY.md §8c KAT (2): mix_factor -> -inf (alpha = sigmoid = 0) removes the multi-view spatial branch of every
+    SpatioTemporalI2V processor (attention_processor.py:708-709), i.e. equals the model built without that branch."""
+    n, F, hw = 2, 2, (8, 8)
+    ocfg, ref, model = _pair(n, F, hw)
+    sd = {k: (torch.full_like(v, -1e4) if k.endswith("mix_factor") else v) for k, v in ref.state_dict().items()}
+    assert any(k.endswith("mix_factor") for k in sd)
+    model.load_state_dict(sd, strict=True)
+    ocfg2, ref2, model2 = _pair(n, F, hw, motion_spatial_attn=False)
+    model2.load_state_dict({k: v for k, v in sd.items() if k in model2.state_dict()}, strict=True)
+    inp = O.synthetic_inputs(ocfg, n, n, F, hw, seed=13)
+    np.testing.assert_allclose(model(**inp).sample.numpy(), model2(**inp).sample.numpy(), rtol=2e-3, atol=2e-4)
