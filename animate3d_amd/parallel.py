@@ -75,18 +75,33 @@ class ViewParallel:
         return (bs[:, None] * n + ns[None, :]).reshape(-1)
 
     # ---- collectives
-    def all_gather_views(self, kv: torch.Tensor, b_local: int) -> torch.Tensor:
-        """kv: this rank's projected K|V tokens ``[(b_l n_l f) l, 2C]`` -> the view group's
-        ``[(b_l N f) l, 2C]`` in unsharded row order."""
+    def all_gather_views_start(self, kv: torch.Tensor):
+        """Launch the all-gather of this rank's projected K|V tokens ``[(b_l n_l f) l, 2C]`` over the view group and
+        return a handle; the collective runs on the backend's own stream (RCCL), so kernels issued on the compute
+        stream before ``all_gather_views_finish`` overlap with it (the Q projection, the temporal branch of a motion
+        module)."""
         S = self.view_shards
         rows, width = kv.shape
+        kv = kv.contiguous()
         out = torch.empty((S * rows, width), dtype=kv.dtype, device=kv.device)
-        dist.all_gather_into_tensor(out, kv.contiguous(), group=self.view_group)
+        work = dist.all_gather_into_tensor(out, kv, group=self.view_group, async_op=True)
         self.gather_bytes += (S - 1) * rows * width * kv.element_size()
+        return work, out, kv
+
+    def all_gather_views_finish(self, handle, b_local: int) -> torch.Tensor:
+        """Wait (the compute stream waits, not the host) and return the view group's ``[(b_l N f) l, 2C]`` tokens in
+        unsharded row order."""
+        work, out, kv = handle
+        work.wait()
+        S = self.view_shards
+        rows, width = kv.shape
         if b_local == 1:
             return out                               # [S, n_l F L, 2C] is already (N f) l order
         per_b = rows // b_local
         return out.view(S, b_local, per_b, width).permute(1, 0, 2, 3).reshape(S * rows, width)
+
+    def all_gather_views(self, kv: torch.Tensor, b_local: int) -> torch.Tensor:
+        return self.all_gather_views_finish(self.all_gather_views_start(kv), b_local)
 
     def all_gather_output(self, y_local: torch.Tensor, V: int, n: int) -> torch.Tensor:
         """[V_local, C, F, h, w] on every rank -> full [V, C, F, h, w] in (b n) order on every rank."""

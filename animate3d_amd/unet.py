@@ -403,12 +403,14 @@ class MVUNetMotionModel(nn.Module):
         k0 = RowMap(gdiv=F, ga=n * F * L, gb=0, seg_len=L, seg_stride=F * L)     # same, frame 0 of every b
         return qm, k0
 
-    def _mv_attention(self, x, w_kvq, C, V, n, F, L, heads, i2v):
+    def _mv_attention(self, x, w_kvq, C, V, n, F, L, heads, i2v, overlap=None):
         """Multi-view attention over the n*L tokens of every (b, f) group (+ the first-frame branch).
         ``w_kvq`` rows are [K; V; Q; (Q_i2v)].  Unsharded: one fused GEMM, K/V/Q are column views.
         View-sharded (animate3d_amd.parallel): this rank holds n of the N views; K|V is projected
         into its own contiguous buffer, all-gathered over the view group (RCCL) and the kernels
-        read the gathered K/V through the unsharded row map while Q stays local."""
+        read the gathered K/V through the unsharded row map while Q stays local.  The gather is
+        asynchronous: the Q projection and ``overlap()`` (independent work of the caller, e.g. the
+        temporal branch of a motion module) are issued while it is in flight.  Returns (a, a_i2v, overlap())."""
         ops, par = self.ops, self.parallel
         qm, k0 = self._mv_maps(n, F, L)
         b = V // n
@@ -417,16 +419,18 @@ class MVUNetMotionModel(nn.Module):
             k, v, q = kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C]
             a = ops.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L)
             ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L) if i2v else None
-            return a, ai
+            return a, ai, (overlap() if overlap is not None else None)
         N = n * par.view_shards
         kv = ops.gemm(x, w_kvq[:2 * C])                       # [rows_local, 2C], contiguous
-        qq = ops.gemm(x, w_kvq[2 * C:])                       # [rows_local, C or 2C]
-        kv_all = par.all_gather_views(kv, b)                  # [b * N*F*L, 2C] in unsharded (b n f) l order
+        pending = par.all_gather_views_start(kv)              # RCCL stream
+        qq = ops.gemm(x, w_kvq[2 * C:])                       # [rows_local, C or 2C], overlaps the gather
+        extra = overlap() if overlap is not None else None
+        kv_all = par.all_gather_views_finish(pending, b)      # [b * N*F*L, 2C] in unsharded (b n f) l order
         km, km0 = self._mv_maps(N, F, L)
         k, v = kv_all[:, :C], kv_all[:, C:]
         a = ops.flash_attn(qq[:, :C], k, v, qm, km, b * F, heads, n * L, N * L)
         ai = ops.flash_attn(qq[:, C:2 * C], k, v, qm, km0, b * F, heads, n * L, N * L) if i2v else None
-        return a, ai
+        return a, ai, extra
 
     def _t2d(self, x, V, n, F, H, W, pk, text_rows, ip_rows, T):
         ops, g = self.ops, self.config.norm_num_groups
@@ -435,7 +439,7 @@ class MVUNetMotionModel(nn.Module):
         h = ops.gemm(h, pk.pin[0], pk.pin[1])
         # attn1: multi-view self-attention (+ first-frame attention)
         n1 = ops.layer_norm(h, pk.n1[0], pk.n1[1], 1e-5)
-        a, ai = self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=pk.i2v)
+        a, ai, _ = self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=pk.i2v)
         if pk.i2v:
             a = ops.gemm(ai, pk.oi2v[0], pk.oi2v[1], residual=a)          # main + to_out_i2v(i2v)
         h = ops.gemm(a, pk.o1[0], pk.o1[1], residual=h)
@@ -467,10 +471,15 @@ class MVUNetMotionModel(nn.Module):
                     nt = ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5)
             else:
                 nt = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L)
-            qkv = ops.gemm(nt, a.qkv)
-            at = ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
+            def temporal_branch(nt=nt, a=a):
+                qkv = ops.gemm(nt, a.qkv)
+                return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
             if a.spatial:
-                asp, _ = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False)
+                # the temporal branch is independent of the multi-view one: it runs while the K|V gather is in flight
+                asp, _, at = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False, overlap=temporal_branch)
+            else:
+                at = temporal_branch()
+            if a.spatial:
                 al = a.alpha
                 if al is None:                       # plain sum (use_alpha_blender = False)
                     t1 = ops.gemm(at, a.o[0], a.o[1], residual=h)
