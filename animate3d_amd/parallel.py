@@ -7,8 +7,9 @@ The reference has no inference parallelism at all; this is new
   (attention_processor.py:340,557), so different ``b`` never exchange data.  Free.
 * axis 2 — views: rank (c, s) holds ``n/S`` of the ``n`` views of its ``b`` slice, all frames.
   Temporal attention, the 3-D GroupNorm, convs, GEMMs and cross-attention are local per video; the
-  only exchange is an all-gather of the projected K|V tokens over the S ranks of the view group
-  before each multi-view attention (16 Transformer2D + 42 motion-module attentions per step; the
+  only exchange is an all-gather over the S ranks of the view group before each multi-view attention — of the
+  attention's normalised input tokens (C wide; K|V are then projected locally for all n views), or optionally of
+  the projected K|V tokens (2C wide, ``gather_tokens = False``) — (16 Transformer2D + 42 motion-module attentions per step; the
   I2V branch reuses the same gathered K/V).  On the fully connected xGMI mesh the gather among
   S <= 4 peers uses all S-1 links of a GPU concurrently.
 
@@ -37,6 +38,7 @@ class ViewParallel:
         self.cfg_rank = self.view_rank = 0
         self.view_group = None
         self.gather_bytes = 0            # bytes received by this rank in all-gathers (telemetry)
+        self.gather_tokens = True        # all-gather the attention's input tokens (C wide) instead of projected K|V (2C wide)
 
     # ---- layout: world = cfg_shards x view_shards
     @staticmethod

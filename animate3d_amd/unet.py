@@ -421,11 +421,19 @@ class MVUNetMotionModel(nn.Module):
             ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L) if i2v else None
             return a, ai, (overlap() if overlap is not None else None)
         N = n * par.view_shards
-        kv = ops.gemm(x, w_kvq[:2 * C])                       # [rows_local, 2C], contiguous
-        pending = par.all_gather_views_start(kv)              # RCCL stream
-        qq = ops.gemm(x, w_kvq[2 * C:])                       # [rows_local, C or 2C], overlaps the gather
-        extra = overlap() if overlap is not None else None
-        kv_all = par.all_gather_views_finish(pending, b)      # [b * N*F*L, 2C] in unsharded (b n f) l order
+        if par.gather_tokens:
+            # gather the (normalised) INPUT tokens [rows_local, C] and project K|V for all N views locally: half the
+            # bytes on xGMI for S x the (cheap, HBM-bound) K|V projection
+            pending = par.all_gather_views_start(x)
+            qq = ops.gemm(x, w_kvq[2 * C:])                   # overlaps the gather
+            extra = overlap() if overlap is not None else None
+            kv_all = ops.gemm(par.all_gather_views_finish(pending, b), w_kvq[:2 * C])
+        else:
+            kv = ops.gemm(x, w_kvq[:2 * C])                   # [rows_local, 2C], contiguous
+            pending = par.all_gather_views_start(kv)          # RCCL stream
+            qq = ops.gemm(x, w_kvq[2 * C:])                   # [rows_local, C or 2C], overlaps the gather
+            extra = overlap() if overlap is not None else None
+            kv_all = par.all_gather_views_finish(pending, b)  # [b * N*F*L, 2C] in unsharded (b n f) l order
         km, km0 = self._mv_maps(N, F, L)
         k, v = kv_all[:, :C], kv_all[:, C:]
         a = ops.flash_attn(qq[:, :C], k, v, qm, km, b * F, heads, n * L, N * L)

@@ -42,8 +42,13 @@ def _worker(rank, world, port, n, F, hw, videos, q):
         inp = O.synthetic_inputs(ocfg, videos, n, F, hw, seed=11, cfg_doubled=True)
         full = model(**inp).sample                     # unsharded, same process
         par = shard_unet(model)
-        sharded = model(**inp).sample
-        err = (sharded - full).abs().max().item()
+        sharded = model(**inp).sample                  # default: gathers the attention input tokens (C wide)
+        tok_bytes = par.gather_bytes
+        par.gather_tokens = False                      # alternative: gathers the projected K|V (2C wide)
+        par.gather_bytes = 0
+        sharded_kv = model(**inp).sample
+        err = max((sharded - full).abs().max().item(), (sharded_kv - full).abs().max().item())
+        assert par.gather_bytes == 0 or tok_bytes < par.gather_bytes
         q.put((rank, err, par.cfg_shards, par.view_shards, par.gather_bytes, tuple(sharded.shape)))
     except Exception as e:   # surface the failure instead of letting the parent time out
         q.put((rank, repr(e), 0, 0, 0, ()))
