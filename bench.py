@@ -75,14 +75,14 @@ class TimedOps:
 
 def cpu_baseline(threads):
     """Bounded CPU sample: the oracle (plain-PyTorch fp32 restatement of the reference forward) on
-    BASELINE config 1 at the reference's own default resolution (1 view x 4 frames x 32x32 latent = 256^2 px,
-    no CFG; 1.25 TFLOP), timed on `threads` host threads.  Scaled figures are FLOP-ratio extrapolations."""
+    BASELINE config 1 (1 view x 4 frames x 64x64 latent = 512^2 px, fp32, no CFG; 6.45 TFLOP), one forward timed on
+    `threads` host threads (about 15 s).  The config-2 figure is a FLOP-ratio extrapolation."""
     from animate3d_amd.config import UNetConfig
     from animate3d_amd.flops import step_flops
     from oracle import unet_ref as O
     torch.set_num_threads(threads)
     cfg = O.UNetConfig()
-    hw = (32, 32)
+    hw = (64, 64)
     ref = O.build_fast(cfg, 1, 4, hw, seed=None)      # constant weights: timing only
     inp = O.synthetic_inputs(cfg, 1, 1, 4, hw, seed=1)
     t0 = time.time()
@@ -92,8 +92,8 @@ def cpu_baseline(threads):
     f_cfg1 = step_flops(UNetConfig(), 1, 1, 4, 64, 64)["total"]
     f_cfg2 = step_flops(UNetConfig(), 8, 4, 16, 64, 64)["total"]
     return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
-            "sample": f"1 forward, 1 view x 4 frames x 32x32 latent, fp32, no CFG ({f_sample / 1e12:.2f} TFLOP/step; BASELINE config 1 "
-                      f"at the reference's default 256^2 resolution); CPU oracle = plain-PyTorch restatement of the reference forward "
+            "sample": f"1 forward of BASELINE config 1: 1 view x 4 frames x 64x64 latent, fp32, no CFG ({f_sample / 1e12:.2f} TFLOP/step); "
+                      f"CPU oracle = plain-PyTorch restatement of the reference forward "
                       f"(the reference itself needs diffusers/xformers, absent offline); host has {os.cpu_count()} logical CPUs",
             "seconds_per_step": dt, "tflops": f_sample / dt / 1e12,
             "config1_equivalent_steps_per_s": (1.0 / dt) * f_sample / f_cfg1,
