@@ -735,6 +735,8 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   }
 }
 
+int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
+                              // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
 int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
@@ -779,7 +781,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   const int64_t tiles_m = (p.M + PBM - 1) / PBM, tiles_n = p.N / (nb * 64);
   const int64_t ntiles = tiles_m * tiles_n;
   const int64_t rounds = (ntiles + cus - 1) / cus;
-  if (ntiles < (3 * cus) / 4 || ntiles * 5 < rounds * cus * 4) return -1000;       // < 80 % of the last round filled
+  if (ntiles * 100 < rounds * cus * g_gemm_min_fill) return -1000;                  // average fill of the rounds (per cent)
   p.tiles_m = tiles_m; p.tiles_n = tiles_n;
   p.vm_counted = g_gemm_vm_counted;
   if constexpr (EPI == EPI_GEGLU) {
@@ -891,6 +893,7 @@ extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t l
 extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
   if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
+  if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;
   return A3D_OK;

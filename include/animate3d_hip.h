@@ -71,7 +71,8 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
  *   32 | 64  force the K-step of the 128x128-tile kernel, 0 = automatic;
  *   1        disable the persistent 256x320 LDS-DMA kernel (every shape takes the 128x128-tile kernel);
  *   2 | 3    enable it with a compiler-scheduled / pinned fragment prefetch (3 is the default);
- *   4 | 5    persistent kernel: drain every epilogue store before the next tile / leave them in flight (5, default). */
+ *   4 | 5    persistent kernel: drain every epilogue store before the next tile / leave them in flight (5, default);
+ *   300+p    persistent kernel: minimum average fill of the grid's rounds in per cent (default 50). */
 int a3d_tune_gemm(int bk);
 
 /* Fused feed-forward input projection + GEGLU (diffusers FeedForward.net[0] = GEGLU: proj, chunk(2), h * gelu(gate)):

@@ -104,7 +104,7 @@ def _persistent_eligible(M, N, geglu=False, cus=256):
         return False
     tiles = (M // 256) * (N // (64 * nb))
     rounds = -(-tiles // cus)
-    return tiles >= 3 * cus // 4 and tiles * 5 >= rounds * cus * 4
+    return tiles * 100 >= rounds * cus * 50           # average fill of the persistent grid's rounds >= 50 %
 
 
 def _both_paths(ops, fn):

@@ -156,6 +156,25 @@ def bench_persist(ops):
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + " | ".join(outs))
 
 
+def bench_fill(ops):
+    print("== persistent kernel on partially filled grids: median ms for 128x128 classic | persistent (a3d_tune_gemm(300 + 40): min fill 40 %)")
+    def ab(fn):
+        ops.lib.a3d_tune_gemm(1); a, _ = timeit(fn, reps=9)
+        ops.lib.a3d_tune_gemm(3); ops.lib.a3d_tune_gemm(340); b, _ = timeit(fn, reps=9)
+        ops.lib.a3d_tune_gemm(350)
+        return f"{a:7.3f} | {b:7.3f}"
+    for (M, N, K) in [(8192, 1280, 1280), (8192, 3840, 1280), (8192, 1280, 5120), (8192, 1280, 2560), (8192, 5120, 1280), (32768, 1280, 1280), (32768, 1920, 1280), (131072, 320, 640)]:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda"); res = rnd(M, N)
+        tiles = (M // 256) * (N // 320)
+        print(f"M={M:7d} N={N:5d} K={K:5d} tiles={tiles:4d}: {ab(lambda: ops.gemm(x, w, bias, residual=res))}")
+    for (B, H, W, Cin, Cout) in [(128, 8, 8, 1280, 1280), (128, 8, 8, 2560, 1280), (128, 16, 16, 1280, 1280)]:
+        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
+        bias = torch.randn(Cout, device="cuda")
+        tiles = (B * H * W // 256) * (Cout // 320)
+        print(f"conv B={B} {H}x{W} {Cin}->{Cout} tiles={tiles:4d}: {ab(lambda: ops.conv3x3(x, B, H, W, w, bias))}")
+
+
 def bench_misc(ops):
     print("== memory-bound kernels at level 0 ([524288, 320] tokens); median ms / effective GB/s (algorithmic bytes)")
     M, C, V, F, L = 524288, 320, 8, 16, 4096
@@ -189,7 +208,7 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "persist": bench_persist, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+        {"flash": bench_flash, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
