@@ -76,6 +76,27 @@ def test_forward_parity(models, videos, seed, cond0):
     assert e_em <= 1.5e-2, f"HIP vs bf16-rounding emulation: {e_em:.3e}"
 
 
+def test_forward_parity_config4_geometry(models):
+    """BASELINE config 4's token geometry (8 views x 32 frames; motion_max_seq_length = 32 is the temporal limit) at an
+    8x8 latent so the oracle finishes in seconds: 32-frame temporal attention and positional table, 8-view multi-view and
+    first-frame row maps, 1x1-pixel feature maps at level 3."""
+    ocfg, ref, hip, _ = models
+    n, F, hw = 8, 32, (8, 8)
+    ref8 = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
+    ref8.load_state_dict(ref.state_dict(), strict=True)
+    inp = O.synthetic_inputs(ocfg, n, n, F, hw, seed=5)
+    y_ref = ref8(**inp).sample
+    hip.num_views = n
+    try:
+        y_hip = hip(**_cuda(inp)).sample
+    finally:
+        hip.num_views = N_VIEWS
+    assert y_hip.shape == y_ref.shape == (n, 4, F, 8, 8)
+    e_or, mx_or, sc = _rel(y_hip, y_ref)
+    print(f"[parity] unet 8 views x 32 frames: hip-vs-oracle rel_l2={e_or:.3e} max_abs={mx_or:.3e} (|ref|max {sc:.3e})")
+    assert torch.isfinite(y_hip).all() and e_or <= 3e-2, f"HIP vs fp32 oracle: {e_or:.3e}"
+
+
 def test_output_dtype_and_determinism(models):
     ocfg, ref, hip, _ = models
     inp = _cuda(O.synthetic_inputs(ocfg, 2, N_VIEWS, FRAMES, HW, seed=5))
