@@ -503,8 +503,9 @@ class MVUNetMotionModel(nn.Module):
     # ------------------------------------------------------------------ HIP-graph replay
     def capture_graph(self, **inputs):
         """Capture one forward into a HIP graph and return ``step(**new_inputs) -> UNet3DConditionOutput``: every call copies
-        the new tensors into the captured input buffers and replays the ~1 700 launches without host work (pays off when the
-        step is launch-bound: the 4D-SDS call at a 32x32 latent, BASELINE config 1).  ``inputs`` are the ``forward`` keyword
+        the new tensors into the captured input buffers and replays the ~1 700 launches without host work.  Measured on MI355X the
+        step is GPU-bound even at the small BASELINE sizes (config 5: 85.9 ms eager, 86.1 ms replay; config 1: 34.1 / 34.0 ms),
+        so this only helps when the host thread is busy elsewhere.  ``inputs`` are the ``forward`` keyword
         arguments (plus ``sample`` / ``timestep``); non-tensor arguments are baked in.  The returned ``.sample`` is a static
         buffer that the next call overwrites.  Possible because the C-ABI never allocates, never synchronises and launches only
         on the caller's current stream (include/animate3d_hip.h)."""

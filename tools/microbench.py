@@ -175,6 +175,34 @@ def bench_fill(ops):
         print(f"conv B={B} {H}x{W} {Cin}->{Cout} tiles={tiles:4d}: {ab(lambda: ops.conv3x3(x, B, H, W, w, bias))}")
 
 
+def bench_graph(ops):
+    """Eager launches vs HIP-graph replay of one denoise step at the small BASELINE configurations."""
+    import time
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.unet import MVUNetMotionModel
+    sys.path.insert(0, ROOT)
+    from bench import make_inputs
+    cfg = UNetConfig()
+    model = MVUNetMotionModel(cfg, num_views=4, device="cuda")
+    model.init_synthetic(seed=0)
+    model = model.to(torch.bfloat16).eval()
+    print("== one denoise step, eager launches vs HIP-graph replay (ms)")
+    for tag, V, n, F, lat in (("config 5 (SDS: 4 views x 16 frames, 32x32 latent, CFG)", 8, 4, 16, 32), ("config 1 (1 view x 4 frames, 64x64 latent)", 1, 1, 4, 64)):
+        model.num_views = n
+        inp = make_inputs(cfg, V, n, F, (lat, lat), torch.device("cuda"))
+        def run(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        eager = run(lambda: model(**inp))
+        step = model.capture_graph(**inp)
+        graph = run(lambda: step(**inp))
+        print(f"{tag}: eager {eager:8.2f}   graph {graph:8.2f}")
+
+
 def bench_misc(ops):
     print("== memory-bound kernels at level 0 ([524288, 320] tokens); median ms / effective GB/s (algorithmic bytes)")
     M, C, V, F, L = 524288, 320, 8, 16, 4096
@@ -208,7 +236,7 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+        {"flash": bench_flash, "graph": bench_graph, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
