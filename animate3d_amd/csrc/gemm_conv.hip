@@ -48,6 +48,11 @@ struct GemmParams {
 
 constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;
 
+// alpha * v and + beta * r with the roundings pinned (no compiler-chosen fma contraction), so that every kernel variant
+// produces bit-identical outputs for any alpha (the AlphaBlender mix uses alpha = sigmoid(mix_factor))
+A3D_DEV float epi_scale(float v, float alpha) { return __fmul_rn(v, alpha); }
+A3D_DEV float epi_axpy(float v, float beta, float r) { return __fmaf_rn(beta, r, v); }
+
 // erf-GELU with Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below bf16 resolution): 2 transcendentals +
 // ~10 VALU instead of libm erff's ~25-instruction polynomial ladder — this runs in a GEMM epilogue.
 A3D_DEV float gelu_erf(float gte) {
@@ -326,12 +331,12 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
             for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(t[e]); v[2 * e + 1] += hi_bf(t[e]); }
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          for (int e = 0; e < 8; ++e) v[e] = epi_scale(v[e], p.alpha);
           if constexpr (RES) {
             if (rr) {
               const u32x4_t t = rres[j];            // prefetched (epf is true whenever this branch is taken)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(t[e]); v[2 * e + 1] += p.beta * hi_bf(t[e]); }
+              for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo_bf(t[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi_bf(t[e])); }
             }
           }
           u32x4_t o;
@@ -348,10 +353,11 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
               w[0] += lo_bf(t[0]); w[1] += hi_bf(t[0]); w[2] += lo_bf(t[1]); w[3] += hi_bf(t[1]);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] *= p.alpha;
+            for (int e = 0; e < 4; ++e) w[e] = epi_scale(w[e], p.alpha);
             if (rr) {
               const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rr + 4 * hh);
-              w[0] += p.beta * lo_bf(t[0]); w[1] += p.beta * hi_bf(t[0]); w[2] += p.beta * lo_bf(t[1]); w[3] += p.beta * hi_bf(t[1]);
+              w[0] = epi_axpy(w[0], p.beta, lo_bf(t[0])); w[1] = epi_axpy(w[1], p.beta, hi_bf(t[0]));
+              w[2] = epi_axpy(w[2], p.beta, lo_bf(t[1])); w[3] = epi_axpy(w[3], p.beta, hi_bf(t[1]));
             }
             u32x2_t o;
             o[0] = pack2bf(w[0], w[1]);
@@ -715,11 +721,11 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
             for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(tb[e]); v[2 * e + 1] += hi_bf(tb[e]); }
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+          for (int e = 0; e < 8; ++e) v[e] = epi_scale(v[e], p.alpha);
           if constexpr (RES) {
             const u32x4_t tr = rres[pi & 1][j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += p.beta * lo_bf(tr[e]); v[2 * e + 1] += p.beta * hi_bf(tr[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo_bf(tr[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi_bf(tr[e])); }
           }
           u32x4_t o;
 #pragma unroll

@@ -132,7 +132,8 @@ def test_gemm_persistent_path(ops, ref, M, N, K):
     bias = rnd(N, seed=13, dtype=torch.float32)
     res = rnd(M, N, seed=14)
     rb = rnd(M // 4096, N, seed=15)
-    for name, kw in (("plain", {}), ("residual", dict(residual=res, alpha=0.5, beta=1.0)), ("rowbias+res", dict(rowbias=rb, rb_div=4096, residual=res))):
+    for name, kw in (("plain", {}), ("residual", dict(residual=res, alpha=0.37, beta=1.0)), ("residual beta", dict(residual=res, alpha=0.63, beta=0.9)),
+                     ("rowbias+res", dict(rowbias=rb, rb_div=4096, residual=res))):
         got, classic, pinned = _both_paths(ops, lambda: ops.gemm(x, w, bias, **kw))
         check(f"gemm persistent {name} {M}x{N}x{K}", got, ref.gemm(x, w, bias, **kw))
         assert torch.equal(got, classic), f"persistent vs 128x128 kernel differ ({name})"
