@@ -66,7 +66,8 @@ A3D_DEV float gelu_erf(float gte) {
   const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
   const float erfx = fmaf(-poly, e, 1.0f);                     // erf(|g|/sqrt2)
   const float erfs = gte < 0.f ? -erfx : erfx;
-  return 0.5f * gte * (1.0f + erfs);
+  const float hg = __fmul_rn(0.5f, gte);            // 0.5 g (1 + erf): roundings pinned, identical in every kernel variant
+  return __fmaf_rn(hg, erfs, hg);
 }
 
 // CONV: 0 = dense A, 1 = 3x3 conv gather (pad 1, stride 1|2), 2 = 3x3 conv over a nearest-2x upsampled input

@@ -356,11 +356,11 @@ extern "C" int a3d_layer_norm_bf16(a3d_stream_t stream, const void* X, void* Y1,
   p.M = M; p.C = C; p.eps = eps;
   p.pe1 = (const uint16_t*)pe1; p.pe1_div = pe1 ? pe1_div : 1; p.pe1_mod = pe1 ? pe1_mod : 1;
   p.pe2 = (const uint16_t*)pe2; p.pe2_div = pe2 ? pe2_div : 1; p.pe2_mod = pe2 ? pe2_mod : 1;
-  if (M >= 4096) {          // the token matrices of the UNet; small M (text / IP tokens) keeps one wave per row
-    if (C == 320) return launch_ln_rows<8>((hipStream_t)stream, p);
-    if (C == 640) return launch_ln_rows<16>((hipStream_t)stream, p);
-    if (C == 1280) return launch_ln_rows<32>((hipStream_t)stream, p);
-  }
+  // the model's widths always take the sub-wave-rows kernel (independent of M: a batch slice must reproduce the full batch
+  // bit for bit, tests/test_unet_gpu.py::test_full_size_batch_independence); other widths (text tokens, C = 768): one wave per row
+  if (C == 320) return launch_ln_rows<8>((hipStream_t)stream, p);
+  if (C == 640) return launch_ln_rows<16>((hipStream_t)stream, p);
+  if (C == 1280) return launch_ln_rows<32>((hipStream_t)stream, p);
   const int64_t nblk = (M + 3) / 4;
   if (nblk > 0x7fffffffLL) return A3D_EINVAL;
   layer_norm_kernel<<<dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream>>>(p);
