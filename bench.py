@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # HBM traffic of one level-0 attention launch (PMC, not measurable from inside the process): see profiles/r1_flash_pmc_traffic.md
+METRIC = "UNet denoise-steps/sec, 4view\u00d716frame\u00d7512\u00b2 MV-VDM @1/2/4/8 GPU"     # BASELINE.json, verbatim
 TRAFFIC_BYTES_PER_LAUNCH = 2.82e9
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -184,7 +185,7 @@ def main():
         from animate3d_amd.flops import step_flops
         work = step_flops(cfg, V, n, F, *hw)["total"]      # 394.78 TFLOP at config 2
         line = {
-            "metric": "UNet denoise-steps/sec, 4view x 16frame x 512^2 MV-VDM", "value": value, "unit": "denoise-steps/s",
+            "metric": METRIC, "value": value, "unit": "denoise-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: {n} views x {F} frames x {hw[0] * 8}^2 px ({hw[0]}x{hw[1]} latent), CFG-doubled "
