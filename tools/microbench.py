@@ -203,6 +203,32 @@ def bench_graph(ops):
         print(f"{tag}: eager {eager:8.2f}   graph {graph:8.2f}")
 
 
+def bench_loop(ops):
+    """BASELINE config 2 end to end: 25 DDIM steps (UNet forward on the CFG-doubled batch + fused CFG/DDIM/re-pin) on one GPU."""
+    import time
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.denoise import denoise_loop
+    from animate3d_amd.embeddings import get_camera
+    from animate3d_amd.unet import MVUNetMotionModel
+    cfg = UNetConfig()
+    n, F, hw = 4, 16, (64, 64)
+    model = MVUNetMotionModel(cfg, num_views=n, device="cuda")
+    model.init_synthetic(seed=0)
+    model = model.to(torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(1)
+    first = (0.18215 * torch.randn(n, 4, 1, *hw, generator=g)).cuda()
+    latents = torch.cat([first, torch.randn(n, 4, F - 1, *hw, generator=g).cuda()], dim=2)
+    pe = torch.randn(2 * n, 77, cfg.cross_attention_dim, generator=g).cuda()
+    ie = torch.randn(2 * n, cfg.ip_image_embed_dim, generator=g).cuda(); ie[:n] = 0
+    cam = get_camera(n).cuda()
+    denoise_loop(model, latents, first, pe, ie, cam, num_inference_steps=2); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = denoise_loop(model, latents, first, pe, ie, cam, num_inference_steps=25)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"== config 2, 25 DDIM steps (4 views x 16 frames x 64x64 latent, CFG 7.5): {dt:.2f} s = {dt / 25 * 1e3:.1f} ms per step; finite={bool(torch.isfinite(out).all())}")
+
+
 def bench_misc(ops):
     print("== memory-bound kernels at level 0 ([524288, 320] tokens); median ms / effective GB/s (algorithmic bytes)")
     M, C, V, F, L = 524288, 320, 8, 16, 4096
@@ -236,7 +262,7 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "graph": bench_graph, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+        {"flash": bench_flash, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
