@@ -139,6 +139,71 @@ __global__ void cfg_ddim_kernel(const float* eps_pair, const float* x, const flo
 
 }  // namespace
 
+namespace {
+
+// row softmax of fp32 logits [M, N] -> bf16 probabilities (one wave per row, three passes over the L2-resident row)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* X, int64_t ldx, uint16_t* Y, int64_t ldy, int64_t M, int N) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* x = X + m * ldx;
+  float mx = -INFINITY;
+  for (int c = lane * 4; c < N; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int c = lane * 4; c < N; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + c);
+    sum += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.f / sum;
+  for (int c = lane * 4; c < N; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + c);
+    u32x2_t o;
+    o[0] = pack2bf(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
+    o[1] = pack2bf(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+    *reinterpret_cast<u32x2_t*>(Y + m * ldy + c) = o;
+  }
+}
+
+// y[b, o, p] = scale * (sum_c w[o, c] x[b, c, p]) + bias[o] on planar fp32 images with a handful of channels (VAE post_quant_conv)
+__global__ void channel_mix_kernel(const float* X, const float* Wm, const float* bias, float* Y, int B, int Cin, int Cout, int64_t HW, float scale) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / HW, px = i % HW;
+    float xin[8];
+    for (int c = 0; c < Cin; ++c) xin[c] = X[(b * Cin + c) * HW + px];
+    for (int o = 0; o < Cout; ++o) {
+      float acc = 0.f;
+      for (int c = 0; c < Cin; ++c) acc = fmaf(Wm[o * Cin + c], xin[c], acc);
+      Y[(b * Cout + o) * HW + px] = fmaf(scale, acc, bias ? bias[o] : 0.f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int a3d_softmax_rows_f32_bf16(a3d_stream_t stream, const float* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {
+  if (!X || !Y || M <= 0 || N <= 0 || N % 4 != 0 || N > 0x7fffffffLL || ldx % 4 != 0 || ldy % 4 != 0) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(X) & 15u) || (reinterpret_cast<uintptr_t>(Y) & 7u)) return A3D_EINVAL;
+  const int64_t nblk = (M + 3) / 4;
+  if (nblk > 0x7fffffffLL) return A3D_EINVAL;
+  softmax_rows_kernel<<<dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream>>>(X, ldx, (uint16_t*)Y, ldy, M, (int)N);
+  return a3d_launch_status();
+}
+
+extern "C" int a3d_channel_mix_f32(a3d_stream_t stream, const float* X, const float* W, const float* bias, float* Y,
+                                   int B, int Cin, int Cout, int64_t HW, float scale) {
+  if (!X || !W || !Y || B <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > 8 || HW <= 0) return A3D_EINVAL;
+  channel_mix_kernel<<<dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream>>>(X, W, bias, Y, B, Cin, Cout, HW, scale);
+  return a3d_launch_status();
+}
+
 extern "C" const char* a3d_version(void) { return "animate3d_hip gfx950 r1"; }
 
 extern "C" int a3d_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {

@@ -40,6 +40,7 @@ struct GemmParams {
   int64_t M, N, K;
   float alpha, beta;
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
+  int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up;
@@ -340,10 +341,16 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
               for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo_bf(t[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi_bf(t[e])); }
             }
           }
-          u32x4_t o;
+          if (p.out_f32) {
+            float* yf = reinterpret_cast<float*>(p.Y) + m * p.ldy + n;
+            *reinterpret_cast<float4*>(yf) = float4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(yf + 4) = float4{v[4], v[5], v[6], v[7]};
+          } else {
+            u32x4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
-          *reinterpret_cast<u32x4_t*>(yy) = o;
+            for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<u32x4_t*>(yy) = o;
+          }
         } else {
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
@@ -770,7 +777,7 @@ int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
 // returns -1000 when the shape is not eligible (caller falls back to the 128x128 kernel)
 template <int CONV, int EPI>
 int try_launch_persist(hipStream_t stream, GemmParams& p) {
-  if (!g_gemm_persist) return -1000;
+  if (!g_gemm_persist || p.out_f32) return -1000;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -860,6 +867,19 @@ extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, co
   p.R = (const uint16_t*)R; p.ldr = ldr; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
   p.vec16 = (ldy % 8 == 0) && aligned16(Y) && (!R || (ldr % 8 == 0 && aligned16(R))) && (!rowbias || (N % 8 == 0 && aligned16(rowbias)));
+  return launch<0>((hipStream_t)stream, p);
+}
+
+extern "C" int a3d_gemm_bf16_f32out(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                                    const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha) {
+  if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
+  if (K % 64 != 0 || N % 8 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 4 != 0) return A3D_EINVAL;
+  if (!aligned16(X) || !aligned16(W) || !aligned16(Y)) return A3D_EINVAL;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)) return A3D_EINVAL;
+  GemmParams p{};
+  p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
+  p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
+  p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = 0.f; p.vec16 = 1; p.out_f32 = 1;
   return launch<0>((hipStream_t)stream, p);
 }
 

@@ -23,7 +23,7 @@ __global__ void gn_partial_kernel(const GNParams p) {
   const int64_t r0 = (int64_t)chunk * GN_ROWS_PER_BLOCK;
   const int64_t r1 = (r0 + GN_ROWS_PER_BLOCK < p.rows) ? r0 + GN_ROWS_PER_BLOCK : p.rows;
   const int ch0 = c8 * 8;
-  const int g_lo = ch0 / p.cg;                              // a chunk touches at most 2 groups (cg >= 8)
+  const int g_lo = ch0 / p.cg;                              // a chunk touches at most 2 groups (cg >= 4)
   const int split = (g_lo + 1) * p.cg - ch0;                // first `split` channels belong to g_lo
   float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
   const uint16_t* base = p.X + ((int64_t)b * p.rows) * p.C + ch0;
@@ -320,7 +320,7 @@ extern "C" int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups) {
 extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                                    float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
   if (!X || !Y || !gamma || !beta || !ws || B <= 0 || rows <= 0 || C <= 0 || groups <= 0) return A3D_EINVAL;
-  if (C % 8 != 0 || C % groups != 0 || C / groups < 8 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;
+  if (C % 8 != 0 || C % groups != 0 || C / groups < 4 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;   // a 16-byte chunk spans <= 2 groups
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
   if (B > 65535) return A3D_EINVAL;
   GNParams p{};

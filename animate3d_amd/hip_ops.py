@@ -58,6 +58,9 @@ _SIGNATURES = {
     "a3d_timestep_embed_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int]),
     "a3d_im2col_in": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int]),
     "a3d_unpack_out": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_gemm_bf16_f32out": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32]),
+    "a3d_softmax_rows_f32_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
+    "a3d_channel_mix_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_f32]),
     "a3d_cfg_ddim_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_f32, c_f32, c_f32]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -271,6 +274,36 @@ class HipOps:
         assert x.is_contiguous() and x.shape == (V * F * H * W, C)
         y = torch.empty((V, C, F, H, W), dtype=dtype, device=self.device)
         _check(self.lib.a3d_unpack_out(self._stream(), _p(x), _p(y), _DTYPE_CODE[dtype], V, C, F, H, W), "a3d_unpack_out")
+        return y
+
+    def gemm_f32out(self, x, w, bias=None, alpha: float = 1.0):
+        """fp32 Y = alpha * (x w^T + bias) for logits that must not be rounded to bf16 (VAE mid-block attention)."""
+        x, w = self._act(x, "gemm_f32out.x"), self._act(w, "gemm_f32out.w")
+        M, K = x.shape
+        N = w.shape[0]
+        assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _check(self.lib.a3d_gemm_bf16_f32out(self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, K, alpha),
+               f"a3d_gemm_bf16_f32out M={M} N={N} K={K}")
+        return y
+
+    def softmax_rows(self, x):
+        """fp32 logits [M, N] -> bf16 row softmax."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
+        M, N = x.shape
+        y = self.empty(M, N)
+        _check(self.lib.a3d_softmax_rows_f32_bf16(self._stream(), _p(x), N, _p(y), N, M, N), f"a3d_softmax_rows_f32_bf16 M={M} N={N}")
+        return y
+
+    def channel_mix(self, x, w, bias, scale: float = 1.0):
+        """planar fp32 [B, Cin, H, W] -> [B, Cout, H, W]: scale * (w x) + bias per pixel (<= 8 channels)."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        w = w.to(device=x.device, dtype=torch.float32).contiguous()
+        b = None if bias is None else bias.to(device=x.device, dtype=torch.float32).contiguous()
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        _check(self.lib.a3d_channel_mix_f32(self._stream(), _p(x), _p(w), _p(b), _p(y), B, Cin, Cout, H * W, scale), "a3d_channel_mix_f32")
         return y
 
     def cfg_ddim_step(self, eps_pair, x, first_frame, guidance: float, alpha_t: float, alpha_prev: float):

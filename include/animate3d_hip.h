@@ -67,6 +67,13 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
 
+/* Same contraction with an fp32 result: Y[M,N] (float, row stride ldy floats) = alpha * (X W^T + bias).  For logits that must
+ * not be rounded to bf16: the single-head 512-wide self-attention of the VAE mid block (diffusers AutoencoderKL, used by
+ * pipeline.py:566-579 decode_latents) computes S = Q K^T / sqrt(512) with this, a3d_softmax_rows_f32_bf16, and two more GEMMs.
+ * Requires K % 64 == 0, N % 8 == 0, 16-byte aligned rows. */
+int a3d_gemm_bf16_f32out(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                         const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
+
 /* Tuning knob (diagnostics / A-B measurements; results are bit-identical in every mode):
  *   32 | 64  force the K-step of the 128x128-tile kernel, 0 = automatic;
  *   1        disable the persistent 256x320 LDS-DMA kernel (every shape takes the 128x128-tile kernel);
@@ -150,6 +157,15 @@ int a3d_im2col_in(a3d_stream_t stream, const void* sample, int dtype, void* Y, i
 
 /* rows [(V F) H W, C] bf16 -> [V, C, F, H, W] in `dtype` (unet_motion_mv_model.py:862). */
 int a3d_unpack_out(a3d_stream_t stream, const void* X, void* Y, int dtype, int V, int C, int F, int H, int W);
+
+/* Row softmax of fp32 logits X[M, N] (row stride ldx floats) -> bf16 probabilities Y[M, N] (row stride ldy elements);
+ * the softmax of diffusers' AttnProcessor in the VAE mid block.  N % 4 == 0. */
+int a3d_softmax_rows_f32_bf16(a3d_stream_t stream, const float* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N);
+
+/* Planar fp32 channel mix y[b, o, :] = scale * sum_c w[o, c] x[b, c, :] + bias[o] for <= 8 channels: the VAE's 1x1
+ * post_quant_conv together with the 1 / scaling_factor of pipeline.py:567 (decode_latents). */
+int a3d_channel_mix_f32(a3d_stream_t stream, const float* X, const float* W, const float* bias, float* Y,
+                        int B, int Cin, int Cout, int64_t HW, float scale);
 
 /* CFG combine + DDIM step + first-frame re-pin, one elementwise pass (pipeline.py:1023-1031):
  *   eps = e_uncond + s (e_text - e_uncond) ; x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t)

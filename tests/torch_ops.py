@@ -158,6 +158,19 @@ class TorchRefOps:
     def unpack_out(self, x, V, C, Fr, H, W, dtype):
         return x.float().reshape(V, Fr, H, W, C).permute(0, 4, 1, 2, 3).contiguous().to(dtype)
 
+    def gemm_f32out(self, x, w, bias=None, alpha=1.0):
+        y = x.float() @ w.float().t()
+        if bias is not None:
+            y = y + bias.float()
+        return (alpha * y).float()
+
+    def softmax_rows(self, x):
+        return self._o(torch.softmax(x.float(), dim=-1))
+
+    def channel_mix(self, x, w, bias, scale=1.0):
+        y = scale * torch.einsum("oc,bchw->bohw", w.float().to(x.device), x.float())
+        return y if bias is None else y + bias.float().to(x.device)[None, :, None, None]
+
     def cfg_ddim_step(self, eps_pair, x, first_frame, guidance, alpha_t, alpha_prev):
         n = x.shape[0]
         eu, et = eps_pair[:n], eps_pair[n:]
