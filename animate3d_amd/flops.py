@@ -81,3 +81,26 @@ def step_flops(cfg: UNetConfig, videos: int, views: int, frames: int, h: int, w:
     conv(boc[0], cfg.out_channels, h, w)
     out["total"] = sum(out.values())
     return out
+
+
+def vae_decode_flops(h: int, w: int, block_out_channels=(128, 256, 512, 512), layers_per_block: int = 2,
+                     latent_channels: int = 4, out_channels: int = 3) -> float:
+    """Algorithmic FLOPs (1 MAC = 2 FLOP; norms / activations excluded) of AutoencoderKL.decode for ONE h x w latent
+    (SD1.5 VAE decoder: conv_in, mid block with one single-head attention, four up blocks of three resnets, conv_out)."""
+    conv = lambda px, cin, cout, k=9: 2.0 * px * k * cin * cout
+    rev = list(reversed(block_out_channels))
+    px = h * w
+    c = rev[0]
+    total = conv(px, latent_channels, c)
+    total += 4 * conv(px, c, c)                                   # two mid resnets
+    total += 4 * 2.0 * px * c * c + 2 * 2.0 * px * px * c         # q, k, v, out projections + QK^T and PV
+    cin = c
+    for i, cout in enumerate(rev):
+        for j in range(layers_per_block + 1):
+            ci = cin if j == 0 else cout
+            total += conv(px, ci, cout) + conv(px, cout, cout) + (conv(px, ci, cout, 1) if ci != cout else 0.0)
+        cin = cout
+        if i != len(rev) - 1:
+            px *= 4
+            total += conv(px, cout, cout)                         # nearest-2x upsample + conv
+    return total + conv(px, block_out_channels[0], out_channels)

@@ -229,6 +229,26 @@ def bench_loop(ops):
     print(f"== config 2, 25 DDIM steps (4 views x 16 frames x 64x64 latent, CFG 7.5): {dt:.2f} s = {dt / 25 * 1e3:.1f} ms per step; finite={bool(torch.isfinite(out).all())}")
 
 
+def bench_vae(ops):
+    """decode_latents of BASELINE config 2's output: 4 views x 16 frames of 64x64 latents -> 64 images of 512x512."""
+    import time
+    from animate3d_amd.vae import AutoencoderKLDecoder
+    vae = AutoencoderKLDecoder(device="cuda").init_synthetic(seed=0).to(torch.bfloat16).eval()
+    lat = torch.randn(4, 4, 16, 64, 64, device="cuda") * 0.18215
+    vae.decode_latents(lat[:, :, :2]); torch.cuda.synchronize()
+    for frames in (4, 16):
+        x = lat[:, :, :frames].contiguous()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = vae.decode_latents(x)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        n = 4 * frames
+        from animate3d_amd.flops import vae_decode_flops
+        fl = vae_decode_flops(64, 64) / 1e12
+        print(f"== VAE decode {n} images 64x64 latent -> 512x512: {dt * 1e3:8.1f} ms = {dt / n * 1e3:6.2f} ms per image "
+              f"({fl * n / dt:6.1f} TFLOP/s at {fl:.2f} TFLOP per image); out {tuple(y.shape)} finite={bool(torch.isfinite(y).all())} "
+              f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
 def bench_misc(ops):
     print("== memory-bound kernels at level 0 ([524288, 320] tokens); median ms / effective GB/s (algorithmic bytes)")
     M, C, V, F, L = 524288, 320, 8, 16, 4096
@@ -262,7 +282,7 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+        {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
