@@ -79,3 +79,13 @@ def test_vae_kernels_gpu():
     ga, be = torch.rand(128, device="cuda") + 0.5, torch.randn(128, device="cuda") * 0.1
     got, want = ops.group_norm(xg, 2, 100, ga, be, 32, 1e-6, True).float(), ref.group_norm(xg, 2, 100, ga, be, 32, 1e-6, True).float()
     assert (got - want).abs().max().item() <= 3 * 2.0 ** -8 * want.abs().max().item()
+
+
+def test_vae_decode_flop_model():
+    """2.51 TFLOP per 64x64 latent (SD1.5 decoder; hand count in profiles/README.md); scales with the pixel count except for the
+    L^2 attention term."""
+    from animate3d_amd.flops import vae_decode_flops
+    f64 = vae_decode_flops(64, 64)
+    assert abs(f64 / 1e12 - 2.5145) < 1e-3
+    attn64, attn32 = 2 * 2.0 * 4096 * 4096 * 512, 2 * 2.0 * 1024 * 1024 * 512
+    assert abs((f64 - attn64) / 4 - (vae_decode_flops(32, 32) - attn32)) < 1e6
