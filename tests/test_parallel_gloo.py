@@ -1,4 +1,4 @@
-"""world_size-2/4 gloo tests (CPU) of the multi-GPU path: the view/CFG-sharded forward must equal the
+"""world_size-2/4/8 gloo tests (CPU) of the multi-GPU path: the view/CFG-sharded forward must equal the
 single-process forward.  The host logic runs on the plain-torch op set of tests/torch_ops.py; what is
 under test is the shard plan, the K|V all-gather layout and the output re-assembly of
 animate3d_amd/parallel.py + the sharded branch of MVUNetMotionModel._mv_attention."""
@@ -57,7 +57,8 @@ def _worker(rank, world, port, n, F, hw, videos, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,videos,expect", [(2, 2, 4, (2, 1)), (2, 2, 2, (1, 2)), (4, 2, 4, (2, 2)), (2, 4, 4, (1, 2))])
+@pytest.mark.parametrize("world,n,videos,expect", [(2, 2, 4, (2, 1)), (2, 2, 2, (1, 2)), (4, 2, 4, (2, 2)), (2, 4, 4, (1, 2)),
+                                                   (8, 4, 8, (2, 4))])   # last: bench.py --gpus 8 (CFG x 4 view shards)
 def test_sharded_forward_equals_unsharded(world, n, videos, expect):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
