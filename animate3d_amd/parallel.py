@@ -20,7 +20,7 @@ is all-gathered at the end.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.distributed as dist

@@ -551,7 +551,7 @@ class MVUNetMotionModel(nn.Module):
         if cross_attention_kwargs:
             raise NotImplementedError("cross_attention_kwargs (LoRA scale) is not supported")
         cfg, ops = self.config, self.ops
-        V, Cin, F, H, W = sample.shape
+        V, _, F, H, W = sample.shape
         n = self.num_views or num_views
         if V % n != 0:
             raise AssertionError("[UNet] input batch size must be dividable by the processors' num_views!")
@@ -625,7 +625,7 @@ class MVUNetMotionModel(nn.Module):
         x = ops.gemm(ops.im2col_in(sample), P.conv_in[0], P.conv_in[1])
         h_, w_ = H, W
         skips = [x]
-        for blk, pk in zip(self.down_blocks, P.down):
+        for pk in P.down:
             for j, rp in enumerate(pk.resnets):
                 x = self._resnet(x, B2, h_, w_, rp, semb, rb_rows)
                 if pk.t2d is not None:

@@ -27,7 +27,7 @@ loads key-for-key.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Optional, Tuple
 

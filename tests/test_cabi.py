@@ -36,7 +36,6 @@ def test_ctypes_binding_covers_header(lib_path):
 
 
 def test_code_object_is_gfx950(lib_path):
-    roc = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
     out = subprocess.run(["strings", "-a", lib_path], capture_output=True, text=True).stdout
     assert "gfx950" in out
     assert not re.search(r"gfx9(0a|42|40)\b", out)

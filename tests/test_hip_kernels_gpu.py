@@ -6,7 +6,6 @@ inputs, so the only differences are fp32 summation order, the bf16 rounding of P
 bf16 rounding of the output (relative 2^-9 = 2.0e-3).  Bars: relative L2 error <= 4e-3 for GEMM-like
 ops and attention, max-abs error <= 2 bf16 ulps of the output scale for normalisation/elementwise ops.
 """
-import math
 
 import pytest
 import torch
