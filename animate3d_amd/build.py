@@ -2,6 +2,8 @@
 
     python -m animate3d_amd.build            # incremental
     python -m animate3d_amd.build --force
+    python -m animate3d_amd.build --experiment A3D_EXP_CHUNK_MAJOR   # side build lib/exp/libanimate3d_hip_<macro>.so for
+                                                                      # tools/microbench.py (A3D_LIB=...); never loaded by the package
 """
 from __future__ import annotations
 
@@ -74,5 +76,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_experiment(macro: str, verbose: bool = True) -> str:
+    """Compile every source with -D<macro> into lib/exp/ (measurement builds of code that is compiled out of the product)."""
+    expdir = os.path.join(LIBDIR, "exp", macro)
+    os.makedirs(expdir, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for src in sources():
+        obj = os.path.join(expdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, *FLAGS, "-D" + macro, "-c", src, "-o", obj]
+        if verbose:
+            print("[a3d build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    lib = os.path.join(LIBDIR, "exp", f"libanimate3d_hip_{macro}.so")
+    subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--experiment" in sys.argv:
+        print(build_experiment(sys.argv[sys.argv.index("--experiment") + 1]))
+    else:
+        print(build(force="--force" in sys.argv))

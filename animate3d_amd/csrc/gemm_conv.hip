@@ -42,6 +42,9 @@ struct GemmParams {
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
+#ifdef A3D_EXP_CHUNK_MAJOR
+  int chunk_major;      // persistent conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
+#endif
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up;
   int64_t tiles_n, tiles_m;
@@ -421,6 +424,11 @@ A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
 }
 A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
   unsigned keep;
+#ifdef A3D_EXP_CHUNK_MAJOR
+  const uint64_t a = (uint64_t)(uintptr_t)sbase;      // wave-uniform by construction; say so (folds away when already scalar)
+  sbase = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+#endif
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
@@ -518,6 +526,11 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   };
   auto issue = [&](int buf) {
     const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
+#ifdef A3D_EXP_CHUNK_MAJOR
+    int wk = ik0;                       // K column of the weight rows of this K-tile
+#else
+    const int wk = ik0;
+#endif
     if (ik0 == 0) {
       // per-tile epilogue vectors ride along with the first K-tile: bias (fp32, BN floats) and the tile's rowbias row
       // (bf16; rb_div is a multiple of 256 here, so all 256 rows of the tile share it) -> no global loads in the epilogue
@@ -545,8 +558,16 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
         else glds16_s(0u, g_zero_page, d);                   // out-of-image tap: the piece's other lanes still come from X
       }
-      ici0 += 64;
-      if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
+#ifdef A3D_EXP_CHUNK_MAJOR
+      if (p.chunk_major) {
+        wk = __builtin_amdgcn_readfirstlane(itap * p.Cin + ici0);
+        if (++itap == 9) { itap = 0; ici0 += 64; }
+      } else
+#endif
+      {
+        ici0 += 64;
+        if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -557,7 +578,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int pc = wid * NB + i;
-      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), p.W + (ld_n0 + pc * 8) * p.ldw + ik0, dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
+      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), p.W + (ld_n0 + pc * 8) * p.ldw + wk, dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
     }
     ik0 += 64;
   };
@@ -751,6 +772,8 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
                               // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
+int g_conv_chunk_major = 0;  // experiment builds (-DA3D_EXP_CHUNK_MAJOR) only: a3d_tune_gemm(6) tap-major K walk (= the shipped order, the
+                             // summation order of the 128x128 kernel), (7) chunk-major (fewer L2 misses, different fp32 summation order)
 int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
@@ -798,6 +821,9 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   if (ntiles * 100 < rounds * cus * g_gemm_min_fill) return -1000;                  // average fill of the rounds (per cent)
   p.tiles_m = tiles_m; p.tiles_n = tiles_n;
   p.vm_counted = g_gemm_vm_counted;
+#ifdef A3D_EXP_CHUNK_MAJOR
+  p.chunk_major = (CONV == 1) ? g_conv_chunk_major : 0;
+#endif
   if constexpr (EPI == EPI_GEGLU) {
     return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
   } else {
@@ -920,6 +946,9 @@ extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t l
 extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
   if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
+#ifdef A3D_EXP_CHUNK_MAJOR
+  if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
+#endif
   if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;

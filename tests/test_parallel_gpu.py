@@ -73,3 +73,50 @@ def test_sharded_forward_on_gpu_equals_unsharded(world, n, videos, expect):
         # same kernels, same per-row arithmetic: only the order of fp32 partial sums inside differently sized launches may differ
         assert err < 2e-2, (rank, err)
         assert (gbytes > 0) == (vs > 1)
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from animate3d_amd.parallel import ViewParallel
+        dist.barrier()
+        t = torch.tensor([1.25], device=dev, dtype=torch.float64)           # bench.py's max-over-ranks reduction
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        par = ViewParallel().configure(b=2, n=4)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        tok = torch.randn(2 * 4 * 2 * 64, 640, generator=g).to(dev, torch.bfloat16)
+        side = torch.zeros(1024, 1024, device=dev)
+        h = par.all_gather_views_start(tok)                                  # collective on RCCL's stream ...
+        side = side + 1.0                                                    # ... compute stream keeps working
+        got = par.all_gather_views_finish(h, b_local=2)
+        y = torch.randn(8, 4, 2, 16, 16, generator=g).to(dev, torch.bfloat16)
+        out = par.all_gather_output(y, V=8, n=4)
+        torch.cuda.synchronize()
+        ok = (t.item() == 1.25 and torch.equal(got, tok) and torch.equal(out, y) and bool((side == 1.0).all())
+              and (par.cfg_shards, par.view_shards) == (1, 1))
+        q.put(("ok" if ok else "mismatch", dist.get_backend()))
+    except Exception as e:
+        q.put((repr(e), ""))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_collectives_run_under_the_rccl_backend():
+    """The one-GPU test box cannot host two RCCL ranks, but it can prove that the backend bench.py selects for N > 1
+    ("nccl" = RCCL) initialises here and accepts exactly the calls the sharded path issues: device-bound init, barrier,
+    float64 MAX all-reduce, the asynchronous bf16 all_gather_into_tensor + stream wait, and the output gather (world 1:
+    results must be the inputs)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", status
+    assert backend == "nccl" and p.exitcode == 0

@@ -97,6 +97,24 @@ def bench_conv(ops):
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + "  ||  ".join(out))
 
 
+def bench_convk(ops):
+    print("== persistent conv3x3: K walked tap-major (default) vs chunk-major (a3d_tune_gemm(7)); median ms / TFLOP/s, max |diff|")
+    shapes = [(128, 64, 64, 320, 320), (128, 64, 64, 640, 320), (128, 64, 64, 960, 320), (128, 32, 32, 640, 640), (128, 32, 32, 1280, 640),
+              (128, 32, 32, 1920, 640), (128, 16, 16, 1280, 1280), (128, 16, 16, 2560, 1280)]
+    for (B, H, W, Cin, Cout) in shapes:
+        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
+        bias = torch.randn(Cout, device="cuda")
+        fl = 2.0 * B * H * W * 9 * Cin * Cout
+        out, ys = [], []
+        for mode in (6, 7, 6, 7):
+            ops.lib.a3d_tune_gemm(mode)
+            med, _ = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias), reps=7)
+            ys.append(ops.conv3x3(x, B, H, W, w, bias)[0].float())
+            out.append(f"{'tap' if mode == 6 else 'chunk'}: {med:6.3f} ms {fl / med / 1e9:6.1f} TF/s")
+        ops.lib.a3d_tune_gemm(6)
+        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d}: " + " | ".join(out) + f" | diff {(ys[0] - ys[1]).abs().max().item():.3g} of {ys[0].abs().max().item():.3g}")
+
+
 def bench_persist(ops):
     """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernel (3) with all stores drained before each
     tile (4) or left in flight behind a counted vmcnt wait (5, default)."""
@@ -282,8 +300,11 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+        {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
-                             [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)])}[w](ops)
+                             [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)]),
+         "conv7": lambda o: (o.lib.a3d_tune_gemm(7), [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)],
+                             [o.conv3x3(rnd(128 * 32 * 32, 1280), 128, 32, 32, rnd(640, 11520, scale=0.01), torch.zeros(640, device="cuda")) for _ in range(3)],
+                             o.lib.a3d_tune_gemm(6), [o.conv3x3(rnd(128 * 32 * 32, 1280), 128, 32, 32, rnd(640, 11520, scale=0.01), torch.zeros(640, device="cuda")) for _ in range(3)])}[w](ops)
