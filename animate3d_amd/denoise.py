@@ -9,8 +9,14 @@ released configuration (``configs/inference/inference.yaml:36-47``: DDIM, 25 ste
 
 The scheduler is diffusers' ``DDIMScheduler`` as ``inference.py:61`` builds it (third-party, not in /root/reference; restated
 from its published algorithm): linear betas, ``timestep_spacing="leading"`` (default), ``steps_offset=1``,
-``set_alpha_to_one=True``, epsilon prediction, eta = 0, no clipping.  FreeInit (pipeline.py:989-999) and the step
-callbacks are not covered.  The latents stay fp32 on the device for the whole loop; nothing synchronises with the host.
+``set_alpha_to_one=True``, epsilon prediction, eta = 0, no clipping.  The latents stay fp32 on the device for the whole
+loop; nothing synchronises with the host.  The step callbacks are not covered.
+
+FreeInit (``pipeline.py:987-999``; enabled in the released config, ``configs/inference/inference.yaml:27-28`` and
+``inference.py:244-245``: butterworth, 3 iterations, no fast sampling) wraps the loop: ``denoise_free_init`` below.  It is
+diffusers' ``FreeInitMixin`` (``diffusers/pipelines/free_init_utils.py`` v0.28.0, third-party, restated): after the first pass
+the frames 1.. of the result are diffused back to t = T-1 with the ORIGINAL noise, and their high 3-D frequencies are replaced
+by those of fresh noise.  Two FFTs of a [n, 4, F-1, h, w] tensor three times per sample: torch.fft (rocFFT) is plumbing here.
 """
 from __future__ import annotations
 
@@ -65,4 +71,73 @@ def denoise_loop(unet, latents: torch.Tensor, first_frame_latents: torch.Tensor,
                    i2v_cond_time_zero=i2v_cond_time_zero).sample
         a_t, a_prev = ddim_alphas(t, acp, num_inference_steps, T)
         latents = unet.ops.cfg_ddim_step(eps.float().contiguous(), latents, first, guidance_scale, a_t, a_prev)
+    return latents
+
+
+def free_init_filter(shape, method: str = "butterworth", order: int = 4, spatial_stop_frequency: float = 0.25,
+                     temporal_stop_frequency: float = 0.25, device=None) -> torch.Tensor:
+    """Low-pass mask over the (fft-shifted) last three dims ``(time, height, width)`` of ``shape``; float32, broadcastable
+    ``[1, ..., time, height, width]``.  FreeInitMixin._get_free_init_freq_filter, vectorised (the original fills it with a
+    Python triple loop): d^2 = (s/t_stop * (2t/T - 1))^2 + (2y/H - 1)^2 + (2x/W - 1)^2 ; butterworth 1 / (1 + (d^2/s^2)^order)."""
+    time, height, width = int(shape[-3]), int(shape[-2]), int(shape[-1])
+    lead = (1,) * (len(shape) - 3)
+    s, ts = float(spatial_stop_frequency), float(temporal_stop_frequency)
+    if s == 0 or ts == 0:
+        return torch.zeros(lead + (time, height, width), dtype=torch.float32, device=device)
+    ax = lambda n: 2.0 * torch.arange(n, dtype=torch.float64) / n - 1.0
+    d2 = ((s / ts) * ax(time))[:, None, None] ** 2 + ax(height)[None, :, None] ** 2 + ax(width)[None, None, :] ** 2
+    if method == "butterworth":
+        mask = 1.0 / (1.0 + (d2 / s ** 2) ** order)
+    elif method == "gaussian":
+        mask = torch.exp(-1.0 / (2.0 * s ** 2) * d2)
+    elif method == "ideal":
+        mask = (d2 <= s * 2).double()
+    else:
+        raise NotImplementedError(f"FreeInit filter method {method!r} (butterworth, gaussian, ideal)")
+    return mask.to(torch.float32).reshape(lead + (time, height, width)).to(device)
+
+
+def free_init_mix(x: torch.Tensor, noise: torch.Tensor, low_pass_filter: torch.Tensor) -> torch.Tensor:
+    """Low 3-D frequencies of ``x`` + high frequencies of ``noise`` (FreeInitMixin._apply_freq_filter); float32 in and out."""
+    dims = (-3, -2, -1)
+    xf = torch.fft.fftshift(torch.fft.fftn(x, dim=dims), dim=dims)
+    nf = torch.fft.fftshift(torch.fft.fftn(noise, dim=dims), dim=dims)
+    mixed = xf * low_pass_filter + nf * (1 - low_pass_filter)
+    return torch.fft.ifftn(torch.fft.ifftshift(mixed, dim=dims), dim=dims).real
+
+
+def free_init_renoise(rest_latents: torch.Tensor, initial_noise: torch.Tensor, alpha_prod_T: float, low_pass_filter: torch.Tensor,
+                      generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """FreeInitMixin._apply_free_init for iteration > 0: ``scheduler.add_noise(latents, initial_noise, T-1)`` in fp32, fresh
+    fp32 noise of the same shape from ``generator``, frequency mix."""
+    z_t = (alpha_prod_T ** 0.5) * rest_latents.float() + ((1.0 - alpha_prod_T) ** 0.5) * initial_noise.float()
+    z_rand = torch.randn(rest_latents.shape, generator=generator, device=rest_latents.device, dtype=torch.float32)
+    return free_init_mix(z_t, z_rand, low_pass_filter).to(rest_latents.dtype)
+
+
+@torch.no_grad()
+def denoise_free_init(unet, latents: torch.Tensor, first_frame_latents: torch.Tensor, prompt_embeds: torch.Tensor,
+                      image_embeds: torch.Tensor, camera: torch.Tensor, num_iters: int = 3, generator: Optional[torch.Generator] = None,
+                      method: str = "butterworth", order: int = 4, spatial_stop_frequency: float = 0.25,
+                      temporal_stop_frequency: float = 0.25, loop=None, **loop_kwargs) -> torch.Tensor:
+    """``pipeline.py:987-1031`` with ``free_init_enabled``: ``num_iters`` full denoising passes; before pass k > 0 the frames
+    1.. are re-initialised from the previous result (only they: ``pipeline.py:990-992``) and the conditioning frame is put back
+    (``:999``).  ``loop`` defaults to ``denoise_loop`` (same keyword arguments, e.g. ``num_inference_steps``, ``guidance_scale``)."""
+    if num_iters < 1:
+        raise ValueError("num_iters must be >= 1")
+    loop = loop or denoise_loop
+    sk = loop_kwargs.get("scheduler_kwargs") or {}
+    T = sk.get("num_train_timesteps", 1000)
+    _, acp = ddim_schedule(1, **sk)
+    a_T = float(acp[T - 1])
+    initial_noise = latents[:, :, 1:].detach().clone()                         # iteration 0 keeps the caller's noise
+    filt = None
+    for it in range(num_iters):
+        if it > 0:
+            if filt is None:
+                filt = free_init_filter((1,) + tuple(initial_noise.shape[1:]), method, order, spatial_stop_frequency,
+                                        temporal_stop_frequency, device=latents.device)
+            rest = free_init_renoise(latents[:, :, 1:], initial_noise, a_T, filt, generator)
+            latents = torch.cat([first_frame_latents.to(rest.dtype), rest], dim=2)
+        latents = loop(unet, latents, first_frame_latents, prompt_embeds, image_embeds, camera, **loop_kwargs)
     return latents

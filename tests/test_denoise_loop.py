@@ -3,8 +3,9 @@ loop against the oracle loop on the GPU."""
 import pytest
 import torch
 
-from animate3d_amd.denoise import ddim_alphas, ddim_schedule
-from oracle.denoise_ref import DDIMRef, denoise_loop_ref
+from animate3d_amd.denoise import (ddim_alphas, ddim_schedule, denoise_free_init, free_init_filter, free_init_mix,
+                                   free_init_renoise)
+from oracle.denoise_ref import DDIMRef, FreeInitRef, denoise_free_init_ref, denoise_loop_ref
 
 
 def test_ddim_schedule_known_answers():
@@ -33,6 +34,79 @@ def test_last_ddim_step_returns_predicted_x0():
     x, eps = torch.randn(2, 4, 3, 8, 8), torch.randn(2, 4, 3, 8, 8)
     a = ref.alphas_cumprod[1]
     torch.testing.assert_close(ref.step(eps, 1, x), (x - (1 - a) ** 0.5 * eps) / a ** 0.5)
+
+
+@pytest.mark.parametrize("method", ["butterworth", "gaussian", "ideal"])
+def test_free_init_filter_equals_the_triple_loop(method):
+    """Vectorised mask == FreeInitMixin's per-element loop (restated in the oracle), plus its structural known answers."""
+    shape = (1, 4, 15, 8, 12)
+    got = free_init_filter(shape, method=method)
+    want = FreeInitRef(DDIMRef(), method=method).freq_filter(shape)
+    assert got.shape == (1, 1, 15, 8, 12) and got.dtype == torch.float32
+    torch.testing.assert_close(got.expand(shape), want, rtol=0, atol=1e-7)
+    assert got[0, 0, 0, 4, 6] <= got[0, 0, 7, 4, 6] and float(got[0, 0, :, 4, 6].max()) > 0.9      # spatial DC bin: passes most near the temporal centre
+    even = free_init_filter((1, 4, 16, 8, 8), method=method)
+    assert float(even[0, 0, 8, 4, 4]) == 1.0                                                      # d^2 = 0 at the shifted DC bin
+    assert float(even[0, 0, 0, 0, 0]) < 1e-3                                                      # far corner is blocked
+    assert free_init_filter(shape, spatial_stop_frequency=0).abs().max() == 0                     # degenerate stop frequency: all zeros
+    with pytest.raises(NotImplementedError):
+        free_init_filter(shape, method="box")
+
+
+def test_free_init_mix_known_answers_and_oracle():
+    g = torch.Generator().manual_seed(2)
+    x, noise = torch.randn(2, 4, 7, 8, 8, generator=g), torch.randn(2, 4, 7, 8, 8, generator=g)
+    torch.testing.assert_close(free_init_mix(x, noise, torch.ones(1, 1, 7, 8, 8)), x, rtol=0, atol=1e-5)       # all-pass keeps x
+    torch.testing.assert_close(free_init_mix(x, noise, torch.zeros(1, 1, 7, 8, 8)), noise, rtol=0, atol=1e-5)  # all-stop keeps noise
+    filt = free_init_filter((1, 4, 7, 8, 8))
+    got = free_init_mix(x, noise, filt)
+    torch.testing.assert_close(got, FreeInitRef.apply_freq_filter(x, noise, filt.expand(1, 4, 7, 8, 8)), rtol=0, atol=1e-6)
+    # linear in (x, noise), and the two filters partition unity: mix(x, x) = x
+    torch.testing.assert_close(free_init_mix(x, x, filt), x, rtol=0, atol=1e-5)
+    torch.testing.assert_close(free_init_mix(2 * x, 2 * noise, filt), 2 * got, rtol=0, atol=1e-5)
+
+
+def test_free_init_renoise_equals_oracle_with_the_same_generator():
+    g = torch.Generator().manual_seed(4)
+    rest, init = torch.randn(2, 4, 5, 8, 8, generator=g), torch.randn(2, 4, 5, 8, 8, generator=g)
+    sched = DDIMRef()
+    fi = FreeInitRef(sched)
+    fi.apply(init, 0, None)
+    want = fi.apply(rest, 1, torch.Generator().manual_seed(9))
+    _, acp = ddim_schedule(1)
+    got = free_init_renoise(rest, init, float(acp[999]), free_init_filter((1, 4, 5, 8, 8)), torch.Generator().manual_seed(9))
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-6)
+    assert abs(float(acp[999]) - float(sched.alphas_cumprod[999])) < 1e-9
+
+
+def test_denoise_free_init_wrapper_equals_oracle_wrapper():
+    """Host logic of the FreeInit wrapper (pipeline.py:987-999): three passes, re-initialisation of frames 1.. only, conditioning
+    frame restored, one generator stream — with the oracle's loop plugged in as ``loop`` so that it runs on CPU."""
+    from oracle import unet_ref as O
+    n, F, hw = 2, 3, (8, 8)
+    small = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=4, norm_num_groups=8)
+    ocfg = O.UNetConfig(**small)
+    ref = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
+    O.init_synthetic_weights(ref, seed=0)
+    inp = O.synthetic_inputs(ocfg, 2 * n, n, F, hw, seed=3, cfg_doubled=True)
+    g = torch.Generator().manual_seed(5)
+    first = 0.18215 * torch.randn(n, 4, 1, *hw, generator=g)
+    latents = torch.cat([first, torch.randn(n, 4, F - 1, *hw, generator=g)], dim=2)
+    args = dict(prompt_embeds=inp["encoder_hidden_states"], image_embeds=inp["added_cond_kwargs"]["image_embeds"], camera=inp["camera"][:n])
+    calls = []
+
+    def loop(unet, lat, ff, pe, ie, cam, **kw):
+        calls.append(lat.clone())
+        return denoise_loop_ref(unet, lat, ff, pe, ie, cam, **kw)
+
+    want = denoise_free_init_ref(ref, latents, first, generator=torch.Generator().manual_seed(8), num_inference_steps=2, **args)
+    got = denoise_free_init(ref, latents, first, generator=torch.Generator().manual_seed(8), loop=loop, num_inference_steps=2, **args)
+    assert len(calls) == 3 and torch.equal(calls[0], latents)
+    assert all(torch.equal(c[:, :, :1], first) for c in calls)                     # conditioning frame restored before every pass
+    assert not torch.equal(calls[1][:, :, 1:], calls[0][:, :, 1:])
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        denoise_free_init(ref, latents, first, num_iters=0, loop=loop, **args)
 
 
 @pytest.mark.gpu
