@@ -43,7 +43,7 @@ struct GemmParams {
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
 #ifdef A3D_EXP_CHUNK_MAJOR
-  int chunk_major;      // persistent conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
+  int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
 #endif
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up;
@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   RegTile rt0, rt1;     // two K-tiles in flight (prefetch distance 2)
   auto load_tile = [&](int64_t k0, RegTile& rt) {
     u32x4_t (&ra)[NPASS] = rt.a; u32x4_t (&rw)[NPASS] = rt.w;
+#ifdef A3D_EXP_CHUNK_MAJOR
+    if (CONV == 1 && p.chunk_major) {       // same K walk as the persistent kernel: (64-channel chunk, tap, position in the chunk)
+      const int64_t j = k0 >> 6, c = j / 9;
+      k0 = (j - c * 9) * p.Cin + c * 64 + (k0 & 63);
+    }
+#endif
     if constexpr (CONV != 0) {
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
@@ -821,9 +827,6 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   if (ntiles * 100 < rounds * cus * g_gemm_min_fill) return -1000;                  // average fill of the rounds (per cent)
   p.tiles_m = tiles_m; p.tiles_n = tiles_n;
   p.vm_counted = g_gemm_vm_counted;
-#ifdef A3D_EXP_CHUNK_MAJOR
-  p.chunk_major = (CONV == 1) ? g_conv_chunk_major : 0;
-#endif
   if constexpr (EPI == EPI_GEGLU) {
     return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
   } else {
@@ -928,6 +931,9 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
   p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
+#ifdef A3D_EXP_CHUNK_MAJOR
+  p.chunk_major = up2x ? 0 : g_conv_chunk_major;       // both kernels walk K the same way, so they stay bit-identical
+#endif
   return up2x ? launch<2>((hipStream_t)stream, p) : launch<1>((hipStream_t)stream, p);
 }
 

@@ -111,8 +111,11 @@ def bench_convk(ops):
             med, _ = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias), reps=7)
             ys.append(ops.conv3x3(x, B, H, W, w, bias)[0].float())
             out.append(f"{'tap' if mode == 6 else 'chunk'}: {med:6.3f} ms {fl / med / 1e9:6.1f} TF/s")
-        ops.lib.a3d_tune_gemm(6)
-        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d}: " + " | ".join(out) + f" | diff {(ys[0] - ys[1]).abs().max().item():.3g} of {ys[0].abs().max().item():.3g}")
+        ops.lib.a3d_tune_gemm(7); ops.lib.a3d_tune_gemm(1)                  # chunk-major walk in the 128x128 kernel: must be bit-identical
+        same = torch.equal(ops.conv3x3(x, B, H, W, w, bias)[0].float(), ys[1])
+        ops.lib.a3d_tune_gemm(3); ops.lib.a3d_tune_gemm(6)
+        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d}: " + " | ".join(out) + f" | diff {(ys[0] - ys[1]).abs().max().item():.3g} of {ys[0].abs().max().item():.3g}"
+              f" | chunk-major 128x128 == persistent: {same}")
 
 
 def bench_persist(ops):
