@@ -1,4 +1,4 @@
-"""MI355X-native VAE decode — SURVEY.md §8(f) item 2, the next row after the denoising loop.
+"""MI355X-native VAE decode and encode — SURVEY.md §8(f) item 2, the next row after the denoising loop.
 
 Drop-in for what ``AnimationPipeline.decode_latents`` needs (animatediff/pipelines/pipeline.py:566-579):
 ``latents / scaling_factor -> (b f) c h w -> vae.decode(...).sample -> b c f h w float32``.  The VAE is diffusers'
@@ -12,6 +12,11 @@ Everything arithmetic goes through the same C-ABI as the UNet (include/animate3d
 the gather), GroupNorm+SiLU, 1x1 shortcut GEMMs with the residual add as epilogue; the single-head 512-wide mid-block
 attention is four GEMMs + a row softmax on fp32 logits (S is never rounded to bf16; the V bias is added after P V because
 softmax rows sum to one).  ``post_quant_conv`` and the ``1 / scaling_factor`` are one 4-channel fp32 kernel.  No fallback.
+
+``AutoencoderKLEncoder`` is the other half (``encoder.*``, ``quant_conv.*``) for ``AnimationPipeline.encode_latents``
+(pipeline.py:540-562: ``vae.encode(images).latent_dist.sample() * scaling_factor`` gives the conditioning first-frame latents).
+Same kernels; diffusers' ``Downsample2D(padding=0)`` pads right/bottom only before its stride-2 conv — that equals the pad-1
+stride-2 conv of the C-ABI on the spatially flipped image with the flipped filter, flipped back (even sizes), so no new kernel.
 """
 from __future__ import annotations
 
@@ -88,10 +93,38 @@ class _Decoder(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
 
 
-class AutoencoderKLDecoder(nn.Module):
-    """Parameters under diffusers' names; ``decode`` / ``decode_latents`` run on the HIP kernels."""
+class _Downsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
 
-    def __init__(self, config: Optional[VAEConfig] = None, ops=None, device: Optional[Union[str, torch.device]] = None):
+
+class _DownBlock(nn.Module):
+    def __init__(self, cin, cout, n, groups, downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        self.downsamplers = nn.ModuleList([_Downsample(cout)]) if downsample else None
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg: VAEConfig):
+        super().__init__()
+        boc, g = cfg.block_out_channels, cfg.norm_num_groups
+        self.conv_in = nn.Conv2d(cfg.out_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        cout = boc[0]
+        for i, c in enumerate(boc):
+            cin, cout = cout, c
+            self.down_blocks.append(_DownBlock(cin, cout, cfg.layers_per_block, g, downsample=i != len(boc) - 1))
+        self.mid_block = _Mid(boc[-1], g)
+        self.conv_norm_out = nn.GroupNorm(g, boc[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(boc[-1], 2 * cfg.latent_channels, 3, padding=1)
+
+
+class _VAEHalf(nn.Module):
+    """What the two halves share: op-set plumbing, weight packing and the resnet / mid-attention forward pieces."""
+
+    def __init__(self, config: Optional[VAEConfig], ops):
         super().__init__()
         cfg = config or VAEConfig()
         if cfg.block_out_channels[-1] // cfg.attention_head_dim > 1:
@@ -99,9 +132,6 @@ class AutoencoderKLDecoder(nn.Module):
         self.config = cfg
         self._ops = ops
         self._packed = None
-        with (torch.device(device) if device is not None else torch.device("cpu")):
-            self.post_quant_conv = nn.Conv2d(cfg.latent_channels, cfg.latent_channels, 1)
-            self.decoder = _Decoder(cfg)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -162,28 +192,6 @@ class AutoencoderKLDecoder(nn.Module):
         return SimpleNamespace(n1=(self._f(r.norm1.weight), self._f(r.norm1.bias)), c1=self._conv_w(r.conv1),
                                n2=(self._f(r.norm2.weight), self._f(r.norm2.bias)), c2=self._conv_w(r.conv2), sc=sc)
 
-    def _pack(self):
-        d, cfg = self.decoder, self.config
-        P = SimpleNamespace()
-        P.pq = (self.post_quant_conv.weight.detach().float().reshape(cfg.latent_channels, cfg.latent_channels).contiguous(),
-                self._f(self.post_quant_conv.bias))
-        wi = d.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(d.conv_in.weight.shape[0], -1)
-        wpad = wi.new_zeros(wi.shape[0], 64)
-        wpad[:, : wi.shape[1]] = wi                        # conv_in as a K = 64 GEMM over im2col patches
-        P.conv_in = (self._w(wpad), self._f(d.conv_in.bias))
-        a = d.mid_block.attentions[0]
-        P.mid = SimpleNamespace(
-            r0=self._pack_resnet(d.mid_block.resnets[0]), r1=self._pack_resnet(d.mid_block.resnets[1]),
-            gn=(self._f(a.group_norm.weight), self._f(a.group_norm.bias)),
-            q=(self._w(a.to_q.weight), self._f(a.to_q.bias)), k=(self._w(a.to_k.weight), self._f(a.to_k.bias)),
-            v=(self._w(a.to_v.weight), self._f(a.to_v.bias)), o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)))
-        P.up = [SimpleNamespace(res=[self._pack_resnet(r) for r in b.resnets],
-                                up=None if b.upsamplers is None else self._conv_w(b.upsamplers[0].conv)) for b in d.up_blocks]
-        P.norm_out = (self._f(d.conv_norm_out.weight), self._f(d.conv_norm_out.bias))
-        P.conv_out = self._conv_w(d.conv_out, pad_out_to=4)
-        self._packed = P
-        return P
-
     # ------------------------------------------------------------------ forward pieces (rows = [B*H*W, C] bf16)
     def _resnet(self, x, B, H, W, pk):
         ops, g = self.ops, self.config.norm_num_groups
@@ -209,6 +217,39 @@ class AutoencoderKLDecoder(nn.Module):
             vt = ops.gemm(pk.v[0], t[rows])                  # V^T [C, L] = W_v x^T (bias deferred: rows of P sum to 1)
             ops.gemm(p, vt, pk.v[1], out=a[rows])            # P V + b_v
         return ops.gemm(a, pk.o[0], pk.o[1], residual=x)
+
+
+class AutoencoderKLDecoder(_VAEHalf):
+    """Parameters under diffusers' names; ``decode`` / ``decode_latents`` run on the HIP kernels."""
+
+    def __init__(self, config: Optional[VAEConfig] = None, ops=None, device: Optional[Union[str, torch.device]] = None):
+        super().__init__(config, ops)
+        cfg = self.config
+        with (torch.device(device) if device is not None else torch.device("cpu")):
+            self.post_quant_conv = nn.Conv2d(cfg.latent_channels, cfg.latent_channels, 1)
+            self.decoder = _Decoder(cfg)
+
+    def _pack(self):
+        d, cfg = self.decoder, self.config
+        P = SimpleNamespace()
+        P.pq = (self.post_quant_conv.weight.detach().float().reshape(cfg.latent_channels, cfg.latent_channels).contiguous(),
+                self._f(self.post_quant_conv.bias))
+        wi = d.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(d.conv_in.weight.shape[0], -1)
+        wpad = wi.new_zeros(wi.shape[0], 64)
+        wpad[:, : wi.shape[1]] = wi                        # conv_in as a K = 64 GEMM over im2col patches
+        P.conv_in = (self._w(wpad), self._f(d.conv_in.bias))
+        a = d.mid_block.attentions[0]
+        P.mid = SimpleNamespace(
+            r0=self._pack_resnet(d.mid_block.resnets[0]), r1=self._pack_resnet(d.mid_block.resnets[1]),
+            gn=(self._f(a.group_norm.weight), self._f(a.group_norm.bias)),
+            q=(self._w(a.to_q.weight), self._f(a.to_q.bias)), k=(self._w(a.to_k.weight), self._f(a.to_k.bias)),
+            v=(self._w(a.to_v.weight), self._f(a.to_v.bias)), o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)))
+        P.up = [SimpleNamespace(res=[self._pack_resnet(r) for r in b.resnets],
+                                up=None if b.upsamplers is None else self._conv_w(b.upsamplers[0].conv)) for b in d.up_blocks]
+        P.norm_out = (self._f(d.conv_norm_out.weight), self._f(d.conv_norm_out.bias))
+        P.conv_out = self._conv_w(d.conv_out, pad_out_to=4)
+        self._packed = P
+        return P
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
@@ -239,3 +280,88 @@ class AutoencoderKLDecoder(nn.Module):
         z = latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
         image = self.decode(z, scale=1.0 / self.config.scaling_factor)
         return image[None, :].reshape((b, f, -1) + image.shape[2:]).permute(0, 2, 1, 3, 4).float()
+
+
+class AutoencoderKLEncoder(_VAEHalf):
+    """The encoder half under diffusers' names (``encoder.*``, ``quant_conv.*``): ``encode`` returns the posterior moments,
+    ``encode_latents`` is pipeline.py:556-560 (sample, times scaling_factor)."""
+
+    def __init__(self, config: Optional[VAEConfig] = None, ops=None, device: Optional[Union[str, torch.device]] = None):
+        super().__init__(config, ops)
+        cfg = self.config
+        with (torch.device(device) if device is not None else torch.device("cpu")):
+            self.encoder = _Encoder(cfg)
+            self.quant_conv = nn.Conv2d(2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+
+    def _pack(self):
+        e, cfg = self.encoder, self.config
+        P = SimpleNamespace()
+        wi = e.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(e.conv_in.weight.shape[0], -1)
+        wpad = wi.new_zeros(wi.shape[0], 64)
+        wpad[:, : wi.shape[1]] = wi                        # conv_in as a K = 64 GEMM over im2col patches of the RGB image
+        P.conv_in = (self._w(wpad), self._f(e.conv_in.bias))
+        P.down = []
+        for b in e.down_blocks:
+            dn = None
+            if b.downsamplers is not None:                 # flipped filter for the flipped image (module docstring)
+                conv = b.downsamplers[0].conv
+                w = conv.weight.detach().float().flip(2, 3).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1)
+                dn = (self._w(w), self._f(conv.bias))
+            P.down.append(SimpleNamespace(res=[self._pack_resnet(r) for r in b.resnets], down=dn))
+        a = e.mid_block.attentions[0]
+        P.mid = SimpleNamespace(
+            r0=self._pack_resnet(e.mid_block.resnets[0]), r1=self._pack_resnet(e.mid_block.resnets[1]),
+            gn=(self._f(a.group_norm.weight), self._f(a.group_norm.bias)),
+            q=(self._w(a.to_q.weight), self._f(a.to_q.bias)), k=(self._w(a.to_k.weight), self._f(a.to_k.bias)),
+            v=(self._w(a.to_v.weight), self._f(a.to_v.bias)), o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)))
+        P.norm_out = (self._f(e.conv_norm_out.weight), self._f(e.conv_norm_out.bias))
+        P.conv_out = self._conv_w(e.conv_out)
+        c2 = 2 * cfg.latent_channels
+        P.quant = (self.quant_conv.weight.detach().float().reshape(c2, c2).contiguous(), self._f(self.quant_conv.bias))
+        self._packed = P
+        return P
+
+    def _downsample(self, x, B, H, W, pk):
+        """Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) then conv3x3 stride 2 == flip(conv3x3_s2_p1(flip(x), flip(w)))."""
+        if H % 2 or W % 2:
+            raise ValueError(f"VAE encoder needs even feature maps at every level, got {H}x{W}")
+        C = x.shape[1]
+        xf = x.reshape(B, H, W, C).flip(1, 2).reshape(B * H * W, C).contiguous()
+        y, Ho, Wo = self.ops.conv3x3(xf, B, H, W, pk[0], pk[1], stride=2)
+        Co = y.shape[1]
+        return y.reshape(B, Ho, Wo, Co).flip(1, 2).reshape(B * Ho * Wo, Co).contiguous(), Ho, Wo
+
+    @torch.no_grad()
+    def encode(self, images: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """AutoencoderKL.encode(x).latent_dist for x [B, 3, H, W] in [-1, 1]: (mean, logvar) fp32 [B, 4, H/8, W/8], logvar
+        clamped to [-30, 20] as DiagonalGaussianDistribution does."""
+        ops, cfg = self.ops, self.config
+        P = self._packed if self._packed is not None else self._pack()
+        B, Ci, H, W = images.shape
+        levels = len(cfg.block_out_channels) - 1
+        if Ci != cfg.out_channels or H % (1 << levels) or W % (1 << levels):
+            raise ValueError(f"images must be [B, {cfg.out_channels}, H, W] with H, W multiples of {1 << levels}")
+        img = images.to(device=self.device, dtype=torch.float32).contiguous()
+        x = ops.gemm(ops.im2col_in(img.reshape(B, Ci, 1, H, W)), P.conv_in[0], P.conv_in[1])
+        for blk in P.down:
+            for r in blk.res:
+                x = self._resnet(x, B, H, W, r)
+            if blk.down is not None:
+                x, H, W = self._downsample(x, B, H, W, blk.down)
+        x = self._resnet(x, B, H, W, P.mid.r0)
+        x = self._mid_attention(x, B, H, W, P.mid)
+        x = self._resnet(x, B, H, W, P.mid.r1)
+        x = ops.group_norm(x, B, H * W, P.norm_out[0], P.norm_out[1], cfg.norm_num_groups, 1e-6, True)
+        x, _, _ = ops.conv3x3(x, B, H, W, P.conv_out[0], P.conv_out[1])
+        c2 = 2 * cfg.latent_channels
+        moments = ops.unpack_out(x, B, c2, 1, H, W, torch.float32)[:, :, 0].contiguous()
+        moments = ops.channel_mix(moments, P.quant[0], P.quant[1], 1.0)             # quant_conv (1x1) in fp32
+        mean, logvar = moments[:, : cfg.latent_channels], moments[:, cfg.latent_channels:]
+        return mean.contiguous(), logvar.clamp(-30.0, 20.0).contiguous()
+
+    @torch.no_grad()
+    def encode_latents(self, images: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """pipeline.py:556-560: ``vae.encode(x).latent_dist.sample() * scaling_factor`` -> [B, 4, H/8, W/8] fp32."""
+        mean, logvar = self.encode(images)
+        noise = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
+        return (mean + torch.exp(0.5 * logvar) * noise) * self.config.scaling_factor

@@ -1,12 +1,16 @@
 """TEST INFRASTRUCTURE — CPU restatement of the VAE decode the reference calls in `decode_latents`
-(animatediff/pipelines/pipeline.py:566-579: latents / scaling_factor -> (b f) c h w -> vae.decode -> b c f h w float32).
+(animatediff/pipelines/pipeline.py:566-579: latents / scaling_factor -> (b f) c h w -> vae.decode -> b c f h w float32)
+and of the VAE encode of `encode_latents` (pipeline.py:540-562: vae.encode(x).latent_dist.sample() * scaling_factor).
 
 The VAE itself is diffusers' `AutoencoderKL` (third-party `diffusers==0.28.0`, requirements.txt:2; loaded from the SD1.5
 checkpoint at inference.py:62, absent from /root/reference and from this image), restated here from its published structure
 with the SD1.5 VAE configuration: block_out_channels (128, 256, 512, 512), layers_per_block 2 (the decoder uses 3 resnets per
 up block), norm_num_groups 32, latent_channels 4, scaling_factor 0.18215, one single-head self-attention (head dim 512) in the
 mid block, GroupNorm eps 1e-6, SiLU.  Parameter names are diffusers' (`post_quant_conv`, `decoder.*`), so a real VAE
-state dict loads key for key.  PARITY UNPINNED: no diffusers install, weights or golden vectors exist offline."""
+state dict loads key for key.  The encoder half (`encoder.*`, `quant_conv.*`): conv_in 3 -> 128, four DownEncoderBlock2D of two
+resnets each, `Downsample2D(padding=0)` = F.pad(x, (0, 1, 0, 1)) + 3x3 stride-2 conv after the first three, the same mid block,
+GroupNorm/SiLU/conv_out to 2 x latent_channels, 1x1 `quant_conv`, `DiagonalGaussianDistribution` (logvar clamped to [-30, 20],
+sample = mean + exp(0.5 logvar) * randn).  PARITY UNPINNED: no diffusers install, weights or golden vectors exist offline."""
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -130,6 +134,67 @@ class VAEDecoderRef(nn.Module):
         image = self.decode(latents)
         video = image[None, :].reshape((b, f, -1) + image.shape[2:]).permute(0, 2, 1, 3, 4)
         return video.float()
+
+
+class Downsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, n, groups, downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([Resnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        self.downsamplers = nn.ModuleList([Downsample(cout)]) if downsample else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return x if self.downsamplers is None else self.downsamplers[0](x)
+
+
+class Encoder(nn.Module):
+    def __init__(self, cfg: VAEConfig):
+        super().__init__()
+        boc, g = cfg.block_out_channels, cfg.norm_num_groups
+        self.conv_in = nn.Conv2d(cfg.out_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        cout = boc[0]
+        for i, c in enumerate(boc):
+            cin, cout = cout, c
+            self.down_blocks.append(DownBlock(cin, cout, cfg.layers_per_block, g, downsample=i != len(boc) - 1))
+        self.mid_block = Mid(boc[-1], g, cfg.attention_head_dim)
+        self.conv_norm_out = nn.GroupNorm(g, boc[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(boc[-1], 2 * cfg.latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class VAEEncoderRef(nn.Module):
+    def __init__(self, cfg: VAEConfig = VAEConfig()):
+        super().__init__()
+        self.cfg = cfg
+        self.encoder = Encoder(cfg)
+        self.quant_conv = nn.Conv2d(2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+
+    @torch.no_grad()
+    def encode(self, x):                      # AutoencoderKL.encode(x).latent_dist -> (mean, logvar)
+        mean, logvar = torch.chunk(self.quant_conv(self.encoder(x)), 2, dim=1)
+        return mean, torch.clamp(logvar, -30.0, 20.0)
+
+    @torch.no_grad()
+    def encode_latents(self, x, generator=None):      # pipeline.py:556-560
+        mean, logvar = self.encode(x)
+        sample = mean + torch.exp(0.5 * logvar) * torch.randn(mean.shape, generator=generator, dtype=mean.dtype)
+        return sample * self.cfg.scaling_factor
 
 
 def init_synthetic_weights(m: nn.Module, seed: int = 0):

@@ -1,10 +1,10 @@
-"""VAE decode: host logic on CPU with the plain-torch op set, HIP kernels on the GPU, both against the
-oracle restatement of diffusers' AutoencoderKL decoder (oracle/vae_ref.py; parity unpinned — no diffusers offline)."""
+"""VAE decode and encode: host logic on CPU with the plain-torch op set, HIP kernels on the GPU (decode),
+both against the oracle restatement of diffusers' AutoencoderKL (oracle/vae_ref.py; parity unpinned — no diffusers offline)."""
 import numpy as np
 import pytest
 import torch
 
-from animate3d_amd.vae import AutoencoderKLDecoder, VAEConfig
+from animate3d_amd.vae import AutoencoderKLDecoder, AutoencoderKLEncoder, VAEConfig
 from oracle import vae_ref as R
 from tests.torch_ops import TorchRefOps
 
@@ -36,6 +36,51 @@ def test_sd15_vae_decoder_key_count():
     assert vae.decoder.up_blocks[3].upsamplers is None and vae.decoder.conv_out.weight.shape == (3, 128, 3, 3)
     with pytest.raises(ValueError):
         AutoencoderKLDecoder(VAEConfig(attention_head_dim=64), device="meta")      # multi-head mid attention: not the SD VAE
+
+
+def test_encoder_state_dict_keys_and_host_logic_match_oracle():
+    """Encoder half on the plain-torch op set: same keys as the oracle's (= diffusers') modules, the flipped stride-2 conv
+    reproduces Downsample2D's right/bottom padding, quant_conv + clamp + sampling follow pipeline.py:556-560."""
+    ref = R.init_synthetic_weights(R.VAEEncoderRef(R.VAEConfig(**SMALL)), seed=1).eval()
+    enc = AutoencoderKLEncoder(VAEConfig(**SMALL), ops=TorchRefOps())
+    assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
+    missing, unexpected = enc.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected
+    x = torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    mean_w, logvar_w = ref.encode(x)
+    mean_g, logvar_g = enc.encode(x)
+    assert mean_g.shape == mean_w.shape == (2, 4, 4, 6) and mean_g.dtype == torch.float32
+    np.testing.assert_allclose(mean_g.numpy(), mean_w.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(logvar_g.numpy(), logvar_w.numpy(), rtol=2e-3, atol=2e-4)
+    want = ref.encode_latents(x, generator=torch.Generator().manual_seed(7))
+    got = enc.encode_latents(x, generator=torch.Generator().manual_seed(7))
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-3, atol=2e-4)
+    with pytest.raises(ValueError):
+        enc.encode(torch.zeros(1, 3, 36, 32))                                        # not a multiple of 8
+    with pytest.raises(ValueError):
+        enc.encode(torch.zeros(1, 4, 32, 32))
+
+
+def test_flipped_stride2_conv_is_the_right_bottom_padded_conv():
+    """The identity the encoder's downsampler rests on, on odd-looking sizes and a non-symmetric filter:
+    conv(F.pad(x, (0,1,0,1)), w, stride 2) == flip(conv(flip(x), flip(w), stride 2, padding 1)) for even H, W."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(2, 5, 6, 10, generator=g), torch.randn(7, 5, 3, 3, generator=g), torch.randn(7, generator=g)
+    want = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    got = F.conv2d(x.flip(2, 3), w.flip(2, 3), b, stride=2, padding=1).flip(2, 3)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_sd15_vae_encoder_key_count():
+    """SD1.5 AutoencoderKL encoder half: 106 tensors under `encoder.*` (8 resnets + 2 mid resnets: 10 x 8 + 2 shortcuts x 2,
+    attention 10, 3 downsamplers x 2, conv_in/conv_out/conv_norm_out 6) + 2 under `quant_conv.*`."""
+    enc = AutoencoderKLEncoder(device="meta")
+    keys = list(enc.state_dict().keys())
+    assert len([k for k in keys if k.startswith("encoder.")]) == 106 and len(keys) == 108
+    assert enc.encoder.conv_in.weight.shape == (128, 3, 3, 3) and enc.encoder.conv_out.weight.shape == (8, 512, 3, 3)
+    assert enc.encoder.down_blocks[1].resnets[0].conv_shortcut.weight.shape == (256, 128, 1, 1)
+    assert enc.encoder.down_blocks[3].downsamplers is None and enc.quant_conv.weight.shape == (8, 8, 1, 1)
 
 
 @pytest.mark.gpu
