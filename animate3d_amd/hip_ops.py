@@ -287,12 +287,13 @@ class HipOps:
                f"a3d_gemm_bf16_f32out M={M} N={N} K={K}")
         return y
 
-    def softmax_rows(self, x):
-        """fp32 logits [M, N] -> bf16 row softmax."""
+    def softmax_rows(self, x, out=None):
+        """fp32 logits [M, N] -> bf16 row softmax (``out``: [M, N] view with its own row stride)."""
         assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
         M, N = x.shape
-        y = self.empty(M, N)
-        _check(self.lib.a3d_softmax_rows_f32_bf16(self._stream(), _p(x), N, _p(y), N, M, N), f"a3d_softmax_rows_f32_bf16 M={M} N={N}")
+        y = self._act(out, "softmax_rows.out") if out is not None else self.empty(M, N)
+        assert y.shape == (M, N)
+        _check(self.lib.a3d_softmax_rows_f32_bf16(self._stream(), _p(x), N, _p(y), y.stride(0), M, N), f"a3d_softmax_rows_f32_bf16 M={M} N={N}")
         return y
 
     def channel_mix(self, x, w, bias, scale: float = 1.0):

@@ -210,11 +210,19 @@ class _VAEHalf(nn.Module):
         q = ops.gemm(t, pk.q[0], pk.q[1])
         k = ops.gemm(t, pk.k[0], pk.k[1])
         a = ops.empty(B * L, C)
+        Lp = -(-L // 64) * 64                                # the P V contraction runs over L: the GEMM needs a multiple of 64
+        if Lp != L:                                          # other latent sizes: zero-padded P columns / V^T columns
+            p_pad, vt_pad = ops.empty(L, Lp).zero_(), ops.empty(C, Lp).zero_()
         for b in range(B):                                   # per image: L x L logits in fp32, never rounded to bf16
             rows = slice(b * L, (b + 1) * L)
             s = ops.gemm_f32out(q[rows], k[rows], alpha=C ** -0.5)
-            p = ops.softmax_rows(s)
-            vt = ops.gemm(pk.v[0], t[rows])                  # V^T [C, L] = W_v x^T (bias deferred: rows of P sum to 1)
+            if Lp == L:
+                p = ops.softmax_rows(s)
+                vt = ops.gemm(pk.v[0], t[rows])              # V^T [C, L] = W_v x^T (bias deferred: rows of P sum to 1)
+            else:
+                ops.softmax_rows(s, out=p_pad[:, :L])
+                ops.gemm(pk.v[0], t[rows], out=vt_pad[:, :L])
+                p, vt = p_pad, vt_pad
             ops.gemm(p, vt, pk.v[1], out=a[rows])            # P V + b_v
         return ops.gemm(a, pk.o[0], pk.o[1], residual=x)
 

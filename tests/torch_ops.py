@@ -164,8 +164,12 @@ class TorchRefOps:
             y = y + bias.float()
         return (alpha * y).float()
 
-    def softmax_rows(self, x):
-        return self._o(torch.softmax(x.float(), dim=-1))
+    def softmax_rows(self, x, out=None):
+        y = self._o(torch.softmax(x.float(), dim=-1))
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     def channel_mix(self, x, w, bias, scale=1.0):
         y = scale * torch.einsum("oc,bchw->bohw", w.float().to(x.device), x.float())
