@@ -1,0 +1,82 @@
+"""The SDS-side input assembly and epilogue (SURVEY.md §8c "Python caller rows") against golden vectors produced by the
+REFERENCE's own ``compute_mvdream_recon_loss`` (tests/golden/make_sds_goldens.py), with the stand-in UNet of tests/sds_stub.py on
+both sides."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from animate3d_amd.sds import normalize_camera, sds_recon_loss
+from tests.sds_stub import StubDDIM, stub_unet
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sds.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize("tag", ["rescale", "plain"])
+def test_sds_step_matches_the_reference(golden, tag):
+    G = {k.split("/", 1)[1]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith(tag + "/")}
+    n, f, scale, rescale, tz = G["cfg"].tolist()
+    seen = {}
+
+    def unet(sample, timestep, **kw):
+        seen.update(sample=sample.clone(), t=timestep.clone(), camera=kw["camera"].clone(), image_embeds=kw["added_cond_kwargs"]["image_embeds"].clone())
+        return stub_unet(sample, timestep, **kw)
+
+    lat = G["latents"].clone().requires_grad_(True)
+    loss, aux = sds_recon_loss(unet, lat, G["t"], G["text"], G["image_embeds"], G["c2w"], n_view=int(n), n_frame=int(f), guidance_scale=scale,
+                               recon_std_rescale=rescale, i2v_cond_time_zero=bool(tz), alphas_cumprod=StubDDIM().alphas_cumprod, noise=G["noise"])
+    loss.backward()
+    # what the UNet is handed: CFG-doubled noisy videos with the clean first frame, per-view timesteps, normalised cameras of
+    # frame 0, image embeddings followed by zeros
+    torch.testing.assert_close(seen["sample"], G["unet_sample"], rtol=1e-6, atol=1e-6)
+    assert torch.equal(seen["t"].long(), G["unet_t"].long())
+    torch.testing.assert_close(seen["camera"], G["unet_camera"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(seen["image_embeds"], G["unet_image_embeds"], rtol=0, atol=0)
+    torch.testing.assert_close(aux["latents_noisy"], G["latents_noisy"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(aux["noise_pred"], G["noise_pred"], rtol=1e-5, atol=1e-4)          # guidance scale 100 amplifies rounding
+    torch.testing.assert_close(aux["latents_recon"], G["latents_recon"], rtol=1e-5, atol=2e-4)
+    torch.testing.assert_close(loss.detach(), G["loss"], rtol=1e-5, atol=0)
+    torch.testing.assert_close(lat.grad, G["grad"], rtol=1e-5, atol=1e-5)
+    # structural: frame 0 of the target is the input's frame 0, so it carries no gradient
+    g6 = lat.grad.reshape(-1, int(f), *lat.shape[1:])
+    assert float(g6[:, 0].abs().max()) == 0.0 and float(g6[:, 1:].abs().max()) > 0.0
+
+
+def test_sds_batches_and_argument_checks():
+    """b = 2 equals two independent b = 1 steps (alpha per b — the reference's [b]-shaped broadcast only exists for b = 1),
+    own noise from a generator, and the error behaviour."""
+    n, f, hw = 2, 3, 4
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(2 * n * f, 4, hw, hw, generator=g)
+    t = torch.tensor([100, 700])
+    text = torch.randn(2 * 2 * n, 5, 16, generator=g)               # (text for b0 b1, uncond for b0 b1)
+    emb = torch.randn(2 * n, 12, generator=g)
+    c2w = torch.eye(4).repeat(2 * n * f, 1, 1) + 0.2 * torch.randn(2 * n * f, 4, 4, generator=g)
+    noise = torch.randn(2, n, f - 1, 4, hw, hw, generator=g)
+    kw = dict(n_view=n, n_frame=f, guidance_scale=7.5, recon_std_rescale=0.5)
+    loss, aux = sds_recon_loss(stub_unet, lat, t, text, emb, c2w, noise=noise, **kw)
+    parts = []
+    for i in range(2):
+        rows = slice(i * n * f, (i + 1) * n * f)
+        txt = torch.cat([text[i * n:(i + 1) * n], text[2 * n + i * n: 2 * n + (i + 1) * n]])
+        li, ai = sds_recon_loss(stub_unet, lat[rows], t[i:i + 1], txt, emb[i * n:(i + 1) * n], c2w[rows], noise=noise[i:i + 1], **kw)
+        parts.append((li, ai))
+        torch.testing.assert_close(aux["latents_recon"][rows], ai["latents_recon"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss, (parts[0][0] + parts[1][0]) / 2, rtol=1e-5, atol=0)
+    l1, _ = sds_recon_loss(stub_unet, lat, t, text, emb, c2w, generator=torch.Generator().manual_seed(3), **kw)
+    l2, _ = sds_recon_loss(stub_unet, lat, t, text, emb, c2w, generator=torch.Generator().manual_seed(3), **kw)
+    assert torch.equal(l1, l2) and torch.isfinite(l1)
+    cam = normalize_camera(c2w)
+    torch.testing.assert_close(cam.reshape(-1, 4, 4)[:, :3, 3].norm(dim=1), torch.ones(2 * n * f), rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        sds_recon_loss(stub_unet, lat[:5], t, text, emb, c2w, **kw)
+    with pytest.raises(ValueError):
+        sds_recon_loss(stub_unet, lat, t[:1], text, emb, c2w, **kw)
+    with pytest.raises(ValueError):
+        sds_recon_loss(stub_unet, lat, t, text[:3], emb, c2w, **kw)
