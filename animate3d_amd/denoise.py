@@ -54,8 +54,8 @@ def denoise_loop(unet, latents: torch.Tensor, first_frame_latents: torch.Tensor,
     """latents [n, 4, F, h, w] fp32 with frame 0 = first_frame_latents [n, 4, 1, h, w]; prompt_embeds [2n, 77, 768] and
     image_embeds [2n, 1024] in (uncond, text) order (pipeline.py:931-937); camera [n, 16] (pipeline.py:984).  Returns the
     final latents.  ``unet`` is an ``animate3d_amd.unet.MVUNetMotionModel`` (its ``ops`` supplies the fused step kernel)."""
-    if latents.dtype != torch.float32 or not latents.is_cuda:
-        raise ValueError("latents must be a float32 CUDA tensor (the reference keeps fp32 latents through scheduler.step)")
+    if latents.dtype != torch.float32:
+        raise ValueError("latents must be float32 (the reference keeps fp32 latents through scheduler.step)")
     n = latents.shape[0]
     if prompt_embeds.shape[0] != 2 * n or image_embeds.shape[0] != 2 * n or camera.shape[0] != n:
         raise ValueError("classifier-free guidance batch: prompt_embeds / image_embeds need 2n rows, camera n rows")

@@ -10,7 +10,9 @@ last step uses final_alpha_cumprod = 1 and therefore returns the predicted x0, a
 FreeInit (``pipeline.py:987-999``) is diffusers' ``FreeInitMixin`` (``pipelines/free_init_utils.py`` v0.28.0), also third-party and
 absent: restated below method by method (``_get_free_init_freq_filter`` with its Python triple loop, ``_apply_freq_filter``,
 ``_apply_free_init``), PARITY UNPINNED likewise; known answers are structural (mask = 1 at the shifted DC bin, all-pass mask returns
-the re-noised latents, zero mask returns the fresh noise)."""
+the re-noised latents, zero mask returns the fresh noise).  The reference-OWNED part of the loop (CFG order and combine, camera
+doubling, first-frame re-pin, which frames FreeInit touches) is pinned separately: tests/golden/pipeline_loop.npz holds outputs of the
+reference's own loop statement run with these restated third-party pieces (tests/golden/make_pipeline_loop_goldens.py)."""
 import math
 
 import torch

@@ -109,6 +109,43 @@ def test_denoise_free_init_wrapper_equals_oracle_wrapper():
         denoise_free_init(ref, latents, first, num_iters=0, loop=loop, **args)
 
 
+@pytest.mark.parametrize("tag", ["freeinit", "plain"])
+def test_loop_and_free_init_match_the_reference_loop(tag):
+    """The product's denoise_loop + denoise_free_init (plain-torch op set for the fused step, stand-in UNet) against golden
+    vectors produced by the REFERENCE's own loop statement of pipeline.py:988-1045 (tests/golden/make_pipeline_loop_goldens.py):
+    pins the (uncond, text) order and combine, the camera doubling, the per-step re-pin of the conditioning frame, the frames
+    FreeInit re-initialises and the single generator stream."""
+    import os
+    import numpy as np
+    from tests.sds_stub import stub_unet
+    from tests.torch_ops import TorchRefOps
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_loop.npz"))
+    G = {k.split("/", 1)[1]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(tag + "/")}
+    free_init, steps, n, F, scale, tz, ncalls = G["cfg"].tolist()
+    calls = []
+
+    class Unet:
+        ops = TorchRefOps(torch.float32)
+
+        def __call__(self, sample, t, **kw):
+            calls.append((sample.clone(), int(t), kw["camera"].clone()))
+            return stub_unet(sample, t, **kw)
+
+    kw = dict(num_inference_steps=int(steps), guidance_scale=scale, i2v_cond_time_zero=bool(tz))
+    args = (Unet(), G["latents"].clone(), G["first"], G["prompt"], G["embeds"], G["camera"])
+    if free_init:
+        got = denoise_free_init(*args, num_iters=3, generator=torch.Generator().manual_seed(77), **kw)
+    else:
+        from animate3d_amd.denoise import denoise_loop
+        got = denoise_loop(*args, **kw)
+    assert len(calls) == int(ncalls) and [c[1] for c in calls] == G["unet_t"].long().tolist()
+    torch.testing.assert_close(calls[0][0], G["first_unet_sample"], rtol=0, atol=0)
+    torch.testing.assert_close(calls[0][2], G["unet_camera"], rtol=0, atol=0)
+    torch.testing.assert_close(calls[-1][0], G["last_unet_sample"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got, G["result"], rtol=1e-4, atol=1e-5)
+    assert torch.equal(got[:, :, :1], G["first"])
+
+
 @pytest.mark.gpu
 def test_denoise_loop_matches_oracle_loop():
     """3 DDIM steps of the product loop (HIP UNet + fused CFG/DDIM/re-pin kernel) against the oracle loop driving the CPU
