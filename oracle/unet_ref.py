@@ -10,7 +10,9 @@ Parity status
   ``embeddings.py``; they are PINNED by golden vectors generated from the
   reference's own code (``tests/golden/make_processor_goldens.py`` ->
   ``tests/golden/processors.npz``; checked by ``tests/test_oracle_golden.py``).
-* The UNet glue follows ``animatediff/models/unet_motion_mv_model.py:633-867``.
+* The UNet glue follows ``animatediff/models/unet_motion_mv_model.py:633-867`` and is PINNED as well: the reference's own
+  ``forward``, compiled from its syntax tree and run over this file's blocks, gives bit-identical outputs
+  (``tests/golden/make_unet_forward_goldens.py`` -> ``tests/golden/unet_forward.npz``).
 * Everything the reference imports from ``diffusers==0.28.0`` (ResnetBlock2D,
   Transformer2DModel, TransformerTemporalModel, BasicTransformerBlock, GEGLU
   feed-forward, Attention, Timesteps, TimestepEmbedding, ImageProjection,
