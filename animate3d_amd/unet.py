@@ -25,6 +25,7 @@ What is different is everything underneath:
 from __future__ import annotations
 
 import math
+import re
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple, Union
 
@@ -190,9 +191,15 @@ class MVUNetMotionModel(nn.Module):
         state-dict entries; ``unet`` / ``motion_adapter`` only need ``state_dict()``."""
         model = cls(**kw)
         if load_weights:
-            sd = {k: v for k, v in unet.state_dict().items()}
+            # exactly the members the reference copies (:332-360): conv_in, time / camera embedding, the resnets, attentions and
+            # samplers of every block, conv_norm_out, conv_out — not encoder_hid_proj; motion modules come from the adapter (:394-402)
+            own = re.compile(r"^(conv_in|time_embedding|camera_embedding|conv_norm_out|conv_out)\."
+                             r"|^(down_blocks|up_blocks)\.\d+\.(resnets|attentions|downsamplers|upsamplers)\."
+                             r"|^mid_block\.(resnets|attentions)\.")
+            sd = {k: v for k, v in unet.state_dict().items() if own.match(k)}
             if motion_adapter is not None:
-                sd.update({k: v for k, v in motion_adapter.state_dict().items() if "motion_modules" in k})
+                sd.update({k: v for k, v in motion_adapter.state_dict().items()
+                           if re.match(r"^((down_blocks|up_blocks)\.\d+|mid_block)\.motion_modules\.", k)})
             model.load_state_dict(sd, strict=False)
         return model
 

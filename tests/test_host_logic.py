@@ -142,3 +142,37 @@ def test_structural_kat_alpha_zero_is_vanilla_motion_module():
     model2.load_state_dict({k: v for k, v in sd.items() if k in model2.state_dict()}, strict=True)
     inp = O.synthetic_inputs(ocfg, n, n, F, hw, seed=13)
     np.testing.assert_allclose(model(**inp).sample.numpy(), model2(**inp).sample.numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_from_unet2d_copies_what_the_reference_copies():
+    """Weight mapping of ``from_unet2d`` / ``load_motion_modules`` (unet_motion_mv_model.py:275-368, 394-402): the fixture
+    tests/golden/from_unet2d.json is the provenance of every parameter after the REFERENCE's own methods ran on three differently
+    seeded module trees (tests/golden/make_from_unet2d_goldens.py); the drop-in must take the same tensors from the same source
+    and leave the same ones (``encoder_hid_proj``) alone."""
+    import json
+    import os
+    from tests.torch_ops import TorchRefOps
+    tags = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "from_unet2d.json")))
+    small = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=4, norm_num_groups=8)
+
+    def tree(seed):
+        m = O.MVUNetMotionModelRef(O.UNetConfig(**small), 2, 3, (8, 8)).eval()
+        return O.init_synthetic_weights(m, seed=seed, dense=True)
+
+    unet2d, adapter = tree(1), tree(2)
+    model = MVUNetMotionModel.from_unet2d(unet2d, adapter, config=UNetConfig(**small), ops=TorchRefOps(), num_views=2)
+    got, a, b = model.state_dict(), unet2d.state_dict(), adapter.state_dict()
+    assert sorted(got.keys()) == sorted(tags.keys())
+    counts = {}
+    for k, tag in tags.items():
+        counts[tag] = counts.get(tag, 0) + 1
+        if tag == "unet":
+            assert torch.equal(got[k], a[k]), k
+        elif tag == "adapter":
+            assert torch.equal(got[k], b[k]), k
+        elif tag == "untouched":
+            assert not torch.equal(got[k], a[k]) and not torch.equal(got[k], b[k]), k
+    assert counts["unet"] == 768 and counts["adapter"] == 798 and counts["untouched"] == 4
+    # load_weights=False builds the topology only
+    bare = MVUNetMotionModel.from_unet2d(unet2d, adapter, load_weights=False, config=UNetConfig(**small), ops=TorchRefOps(), num_views=2)
+    assert not torch.equal(bare.state_dict()["conv_in.weight"], a["conv_in.weight"])
