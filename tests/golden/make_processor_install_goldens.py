@@ -1,0 +1,128 @@
+"""Generate tests/golden/processor_install.json by running the REFERENCE's own processor-installation statements.
+
+Run in the build container only (needs /root/reference):
+
+    python -B tests/golden/make_processor_install_goldens.py
+
+The statements of ``inference.py`` that decide which attention processor every attention layer gets and with which sizes, and
+which transformer blocks lose their ``pos_embed`` (inference.py:90-192; duplicated in train.py:221-322 and
+animatemv_guidance.py:149-251), are taken from the reference file's syntax tree as they lie and executed against: a stand-in
+``unet`` whose attention-layer names are the diffusers names of the oracle's module tree (the same names the product exposes), the
+released switch set of configs/inference/inference.yaml:9-24, and recording stand-ins for the four processor classes.  The
+fixture is the recorded decision per layer: class, hidden_size, feature_size, num_views, num_frames, and the I2V initialisation
+(``to_q_i2v := to_q``, ``to_out_i2v := 0``).
+
+Only data (layer names of the diffusers layout and the recorded constructor arguments) is written; no reference source leaves
+/root/reference.
+"""
+import ast
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+sys.dont_write_bytecode = True
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import unet_ref as O  # noqa: E402
+
+REF = "/root/reference"
+NUM_VIEWS, VIDEO_LENGTH = 4, 16
+
+
+class _Recorder(nn.Module):
+    def __init__(self, **kw):
+        super().__init__()
+        self.kw = {k: (v if isinstance(v, (int, float, bool, list, tuple)) else type(v).__name__) for k, v in kw.items()}
+        self.loaded = None
+
+    def load_state_dict(self, sd, *a, **k):
+        self.loaded = sd
+
+    def to(self, *a, **k):
+        return self
+
+
+def main():
+    tree = ast.parse(open(os.path.join(REF, "inference.py")).read())
+    fn = next(nd for nd in ast.walk(tree) if isinstance(nd, ast.FunctionDef) and any(
+        isinstance(s, ast.Assign) and getattr(s.targets[0], "id", None) == "attn_procs" for s in nd.body))
+    start = next(i for i, s in enumerate(fn.body) if isinstance(s, ast.If) and "motion_module_attn_cfg" in ast.unparse(s.test) and "sample_size" in ast.unparse(s))
+    end = next(i for i, s in enumerate(fn.body) if isinstance(s, ast.If) and "use_spatial_encoding" in ast.unparse(s.test))
+    stmts = fn.body[start:end + 1]
+    assert any(isinstance(s, ast.For) for s in stmts) and "set_attn_processor" in ast.unparse(stmts[-2])
+
+    cfg = O.UNetConfig()                                   # real widths: 320 / 640 / 1280 / 1280
+    with torch.device("meta"):
+        model = O.MVUNetMotionModelRef(cfg, NUM_VIEWS, VIDEO_LENGTH, (32, 32))
+    names = [f"{n}.processor" for n, m in model.named_modules() if isinstance(m, O.Attention)]
+
+    class IPAdapterAttnProcessor:                            # what diffusers' _load_ip_adapter_weights installed on attn2 (inference.py:84)
+        def __init__(self, hidden_size):
+            self.hidden_size, self.cross_attention_dim, self.num_tokens, self.scale = hidden_size, 768, (4,), [1.0]
+            self.to_k_ip, self.to_v_ip = [SimpleNamespace(weight=torch.zeros(1))], [SimpleNamespace(weight=torch.zeros(1))]
+
+    def attn_of(name):
+        mod = model
+        for part in name.split(".")[:-1]:
+            mod = getattr(mod, part)
+        return mod
+
+    procs = {}
+    for name in names:
+        if "motion_modules" not in name and name.endswith("attn2.processor"):
+            procs[name] = IPAdapterAttnProcessor(attn_of(name).to_out[0].out_features)
+        else:
+            procs[name] = object()
+    installed = {}
+    unet = SimpleNamespace(attn_processors=procs, config=SimpleNamespace(block_out_channels=cfg.block_out_channels),
+                           down_blocks=model.down_blocks, mid_block=model.mid_block, up_blocks=model.up_blocks,
+                           set_attn_processor=lambda d: installed.update(d))
+    for part in ("down_blocks", "mid_block", "up_blocks"):  # getattr walk of the I2V branch (inference.py:151-153)
+        setattr(unet, part, getattr(model, part))
+    for blk in list(model.down_blocks) + [model.mid_block] + list(model.up_blocks):
+        for mm in blk.motion_modules:
+            mm.transformer_blocks[0].pos_embed = "sinusoidal"
+    attn_cfg = SimpleNamespace(use_spatial_encoding=True, use_camera_encoding=False)
+    config = SimpleNamespace(                                # configs/inference/inference.yaml:9-24
+        motion_module_attn_cfg=SimpleNamespace(enabled=True, use_alpha_blender=True,
+                                               spatial_attn=SimpleNamespace(enabled=True, attn_cfg=attn_cfg), image_attn=SimpleNamespace(enabled=False)),
+        mvdream_attn_cfg=SimpleNamespace(image_attn=SimpleNamespace(enabled=True)))
+
+    def cls(name):
+        return type(name, (_Recorder,), {})
+
+    ns = {"torch": torch, "unet": unet, "config": config, "num_views": NUM_VIEWS, "video_length": VIDEO_LENGTH,
+          "IPAdapterAttnProcessor": IPAdapterAttnProcessor,
+          "SpatioTemporalI2VXFormersAttnProcessor": cls("SpatioTemporalI2VXFormersAttnProcessor"),
+          "IPAdapterXFormersAttnProcessor": cls("IPAdapterXFormersAttnProcessor"),
+          "MVDreamI2VXFormersAttnProcessor": cls("MVDreamI2VXFormersAttnProcessor"),
+          "MVDreamXFormersAttnProcessor": cls("MVDreamXFormersAttnProcessor")}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=stmts, type_ignores=[])), "processor_install", "exec"), ns)
+    assert sorted(installed) == sorted(names)
+    out = {}
+    for name, p in installed.items():
+        rec = {"class": type(p).__name__, **{k: v for k, v in p.kw.items() if k in ("hidden_size", "feature_size", "num_views", "num_frames",
+                                                                                  "cross_attention_dim", "num_tokens", "scale", "use_alpha_blender")}}
+        if p.loaded is not None and "to_q_i2v.weight" in p.loaded:
+            a = attn_of(name)
+            rec["to_q_i2v_is_to_q"] = p.loaded["to_q_i2v.weight"] is a.to_q.weight
+            rec["to_out_i2v_shape"] = list(p.loaded["to_out_i2v.weight"].shape)
+            rec["to_out_i2v_zero"] = True          # torch.zeros_like on the meta device: zero by construction (inference.py:158-159)
+        out[name] = rec
+    pos_none = [f"{bn}.{i}.motion_modules.{j}" if bn != "mid_block" else f"mid_block.motion_modules.{j}"
+                for bn, blocks in (("down_blocks", model.down_blocks), ("mid_block", [model.mid_block]), ("up_blocks", model.up_blocks))
+                for i, blk in enumerate(blocks) for j, mm in enumerate(blk.motion_modules) if mm.transformer_blocks[0].pos_embed is None]
+    path = os.path.join(HERE, "processor_install.json")
+    with open(path, "w") as f:
+        json.dump({"processors": out, "pos_embed_none": pos_none, "num_views": NUM_VIEWS, "num_frames": VIDEO_LENGTH}, f, indent=0, sort_keys=True)
+    from collections import Counter
+    print("wrote", path, Counter(r["class"] for r in out.values()), len(pos_none), "motion modules without pos_embed")
+
+
+if __name__ == "__main__":
+    main()

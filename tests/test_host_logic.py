@@ -176,3 +176,57 @@ def test_from_unet2d_copies_what_the_reference_copies():
     # load_weights=False builds the topology only
     bare = MVUNetMotionModel.from_unet2d(unet2d, adapter, load_weights=False, config=UNetConfig(**small), ops=TorchRefOps(), num_views=2)
     assert not torch.equal(bare.state_dict()["conv_in.weight"], a["conv_in.weight"])
+
+
+def test_processor_installation_matches_the_reference_statements():
+    """Which processor every attention layer gets, with which sizes (inference.py:90-192): the fixture
+    tests/golden/processor_install.json records what the REFERENCE's own statements decided for the released switch set
+    (tests/golden/make_processor_install_goldens.py).  The oracle's and the product's role-based installation must agree layer by
+    layer; at the reference's hard-coded 256-px sample size the oracle's feature sizes are the reference's."""
+    import json
+    import os
+    from animate3d_amd import modules as M
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "processor_install.json")))
+    n, f = fx["num_views"], fx["num_frames"]
+    want = fx["processors"]
+    with torch.device("meta"):
+        ref = O.MVUNetMotionModelRef(O.UNetConfig(), n, f, (32, 32))             # 256 px / 8 = inference.py:93-95
+    hip = MVUNetMotionModel(UNetConfig(), ops=object(), num_views=n, device="meta")
+    oracle_procs = {f"{name}.processor": m.processor for name, m in ref.named_modules() if isinstance(m, O.Attention)}
+    product_procs = hip.attn_processors
+    assert sorted(oracle_procs) == sorted(product_procs) == sorted(want)
+    classes = {"SpatioTemporalI2VXFormersAttnProcessor": (O.SpatioTemporalProc, M.SpatioTemporalI2VAttnProcessor),
+               "MVDreamI2VXFormersAttnProcessor": (O.MVDreamI2VProc, M.MVDreamI2VAttnProcessor),
+               "IPAdapterXFormersAttnProcessor": (O.IPAdapterProc, M.IPAdapterAttnProcessor)}
+    for name, rec in want.items():
+        oc, pc = classes[rec["class"]]
+        op, pp = oracle_procs[name], product_procs[name]
+        assert type(op) is oc and type(pp) is pc, name
+        if "hidden_size" in rec:
+            assert pp.hidden_size == rec["hidden_size"], name
+            assert getattr(op, "hidden_size", rec["hidden_size"]) == rec["hidden_size"], name
+        if rec["class"].startswith("SpatioTemporal"):
+            assert op.feature_hw == (rec["feature_size"], rec["feature_size"]) and (op.num_views, op.num_frames) == (n, f), name
+            assert pp.use_alpha_blender == rec["use_alpha_blender"] and hasattr(pp, "alpha_blender") and hasattr(pp, "time_pos_embed")
+        if rec["class"].startswith("MVDreamI2V"):
+            assert rec["to_q_i2v_is_to_q"] and rec["to_out_i2v_zero"]
+            assert list(pp.to_out_i2v.weight.shape) == rec["to_out_i2v_shape"] == list(op.to_out_i2v.weight.shape)
+        if rec["class"].startswith("IPAdapter"):
+            assert pp.cross_attention_dim == rec["cross_attention_dim"] and list(pp.num_tokens) == list(rec["num_tokens"])
+    # inference.py:176-192: every motion module's BasicTransformerBlock loses its pos_embed
+    assert len(fx["pos_embed_none"]) == 21
+    for path in fx["pos_embed_none"]:
+        for model in (ref, hip):
+            mod = model
+            for part in path.split("."):
+                mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            assert mod.transformer_blocks[0].pos_embed is None, path
+    # the I2V initialisation itself (to_q_i2v := to_q, to_out_i2v := 0) on real (small) modules
+    small = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=4, norm_num_groups=8)
+    live = O.MVUNetMotionModelRef(O.UNetConfig(**small), 2, 2, (8, 8))
+    blk = live.down_blocks[0].attentions[0].transformer_blocks[0]
+    assert torch.equal(blk.attn1.processor.to_q_i2v.weight, blk.attn1.to_q.weight) and float(blk.attn1.processor.to_out_i2v.weight.detach().abs().max()) == 0.0
+    prod = MVUNetMotionModel(UNetConfig(**small), ops=object(), num_views=2)
+    pb = prod.down_blocks[0].attentions[0].transformer_blocks[0]
+    assert torch.equal(pb.attn1.processor.to_q_i2v.weight, pb.attn1.to_q.weight) and float(pb.attn1.processor.to_out_i2v.weight.detach().abs().max()) == 0.0
+    assert float(pb.attn1.processor.to_out_i2v.bias.detach().abs().max()) == 0.0
