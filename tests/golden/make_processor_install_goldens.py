@@ -117,9 +117,32 @@ def main():
     pos_none = [f"{bn}.{i}.motion_modules.{j}" if bn != "mid_block" else f"mid_block.motion_modules.{j}"
                 for bn, blocks in (("down_blocks", model.down_blocks), ("mid_block", [model.mid_block]), ("up_blocks", model.up_blocks))
                 for i, blk in enumerate(blocks) for j, mm in enumerate(blk.motion_modules) if mm.transformer_blocks[0].pos_embed is None]
+    # ---- the reference's own ``attn_processors`` / ``set_attn_processor`` (unet_motion_mv_model.py:439-497) walked over the oracle's
+    #      and the product's module trees: the traversal order of the layer names, and that a dict round-trips
+    from typing import Dict, Union
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.unet import MVUNetMotionModel
+    utree = ast.parse(open(os.path.join(REF, "animatediff/models/unet_motion_mv_model.py")).read())
+    ucls = next(nd for nd in utree.body if isinstance(nd, ast.ClassDef) and nd.name == "MVUNetMotionModel")
+    meths = [nd for nd in ucls.body if isinstance(nd, ast.FunctionDef) and nd.name in ("attn_processors", "set_attn_processor")]
+    for nd in meths:
+        nd.decorator_list = []
+    ns2 = {"torch": torch, "Dict": Dict, "Union": Union, "AttentionProcessor": object}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=meths, type_ignores=[])), "attn_processors", "exec"), ns2)
+    product = MVUNetMotionModel(UNetConfig(), ops=object(), num_views=NUM_VIEWS, device="meta")
+    # (the product registers down_blocks, up_blocks, mid_block in the reference's order, unet_motion_mv_model.py:152-153,187 — the
+    #  order diffusers' IP-Adapter loader numbers the attn2 layers in; the oracle's tree registers mid before up, which nothing uses)
+    walked = ns2["attn_processors"](product)
+    order = list(walked.keys())
+    assert order == list(product.attn_processors.keys()) and sorted(order) == sorted(ns2["attn_processors"](model).keys())
+    assert all(walked[k] is product.attn_processors[k] for k in walked)
+    shim = type("Shim", (), {"attn_processors": property(ns2["attn_processors"]), "named_children": lambda self: product.named_children()})()
+    ns2["set_attn_processor"](shim, dict(walked))            # the reference's setter accepts the product's processors dict and consumes it all
+
     path = os.path.join(HERE, "processor_install.json")
     with open(path, "w") as f:
-        json.dump({"processors": out, "pos_embed_none": pos_none, "num_views": NUM_VIEWS, "num_frames": VIDEO_LENGTH}, f, indent=0, sort_keys=True)
+        json.dump({"processors": out, "pos_embed_none": pos_none, "num_views": NUM_VIEWS, "num_frames": VIDEO_LENGTH,
+                   "attn_processor_order": order}, f, indent=0, sort_keys=True)
     from collections import Counter
     print("wrote", path, Counter(r["class"] for r in out.values()), len(pos_none), "motion modules without pos_embed")
 

@@ -195,6 +195,12 @@ def test_processor_installation_matches_the_reference_statements():
     oracle_procs = {f"{name}.processor": m.processor for name, m in ref.named_modules() if isinstance(m, O.Attention)}
     product_procs = hip.attn_processors
     assert sorted(oracle_procs) == sorted(product_procs) == sorted(want)
+    # traversal order of the reference's own ``attn_processors`` (unet_motion_mv_model.py:439-462) over these module trees
+    # (down_blocks, up_blocks, mid_block: the registration order of unet_motion_mv_model.py:152-153,187, which is also the order
+    #  in which diffusers' IP-Adapter loader numbers the attn2 layers 1, 3, .., 31 — so the mid block is number 31)
+    assert list(product_procs.keys()) == fx["attn_processor_order"]
+    attn2 = [k for k in fx["attn_processor_order"] if "motion_modules" not in k and k.endswith("attn2.processor")]
+    assert len(attn2) == 16 and attn2[-1].startswith("mid_block") and attn2[6].startswith("up_blocks.1.attentions.0")
     classes = {"SpatioTemporalI2VXFormersAttnProcessor": (O.SpatioTemporalProc, M.SpatioTemporalI2VAttnProcessor),
                "MVDreamI2VXFormersAttnProcessor": (O.MVDreamI2VProc, M.MVDreamI2VAttnProcessor),
                "IPAdapterXFormersAttnProcessor": (O.IPAdapterProc, M.IPAdapterAttnProcessor)}
