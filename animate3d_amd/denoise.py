@@ -46,6 +46,23 @@ def ddim_alphas(t: int, alphas_cumprod: torch.Tensor, num_inference_steps: int, 
     return a_t, a_prev
 
 
+def prepare_latents(first_frame_latents: torch.Tensor, num_frames: int, generator: Optional[torch.Generator] = None,
+                    device=None, dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Step 5 of ``__call__`` (pipeline.py:950-973, ``i2v_similarity_init`` = None as released): the encoded conditioning images
+    ``[n, 4, h, w]`` become frame 0, frames 1.. are N(0, 1) noise times the scheduler's ``init_noise_sigma`` (1 for DDIM), drawn
+    as diffusers' ``randn_tensor`` draws them (on the generator's device, then moved).  Returns (latents [n, 4, F, h, w],
+    first_frame_latents [n, 4, 1, h, w])."""
+    if num_frames < 2:
+        raise ValueError("num_frames must be >= 2 (frame 0 is the conditioning frame)")
+    device = torch.device(device) if device is not None else first_frame_latents.device
+    first = first_frame_latents if first_frame_latents.dim() == 5 else first_frame_latents.unsqueeze(2)
+    first = first.to(device=device, dtype=dtype)
+    n, c, _, h, w = first.shape
+    gdev = generator.device if generator is not None else device
+    rest = torch.randn((n, c, num_frames - 1, h, w), generator=generator, device=gdev, dtype=dtype).to(device)
+    return torch.cat([first, rest], dim=2), first
+
+
 @torch.no_grad()
 def denoise_loop(unet, latents: torch.Tensor, first_frame_latents: torch.Tensor, prompt_embeds: torch.Tensor,
                  image_embeds: torch.Tensor, camera: torch.Tensor, num_inference_steps: int = 25,

@@ -93,6 +93,18 @@ def main():
             out[f"{tag}/{k}"] = v.numpy().copy()
         out[f"{tag}/cfg"] = np.array([float(free_init), steps, n, F, scale, float(tz), len(unet_calls)])
         out[f"{tag}/unet_t"] = np.array([c[1] for c in unet_calls])
+    # ---- step 5, ``prepare_latents`` (pipeline.py:677-733) with ``i2v_similarity_init`` = None, and the first-frame concat (:950-973)
+    tree = ast.parse(open(os.path.join(REF, "animatediff/pipelines/pipeline.py")).read())
+    cls = next(nd for nd in tree.body if isinstance(nd, ast.ClassDef) and nd.name == "AnimateDiffMVI2VPipeline")
+    prep = next(nd for nd in cls.body if isinstance(nd, ast.FunctionDef) and nd.name == "prepare_latents")
+    ns = {"torch": torch, "randn_tensor": lambda shape, generator=None, device=None, dtype=None: torch.randn(shape, generator=generator, dtype=dtype)}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[prep], type_ignores=[])), "prepare_latents", "exec"), ns)
+    me = SimpleNamespace(vae_scale_factor=8, scheduler=SimpleNamespace(init_noise_sigma=1.0))
+    first = torch.randn(3, 4, 8, 8, generator=torch.Generator().manual_seed(5)).unsqueeze(2)
+    rest = ns["prepare_latents"](me, 3, 4, 6 - 1, 64, 64, torch.float32, "cpu", torch.Generator().manual_seed(21), None, None,
+                                 latent_timestep=None, latent_cond_image=first)
+    out["prepare/first"] = first.numpy().copy()
+    out["prepare/latents"] = torch.cat([first, rest], dim=2).numpy().copy()
     path = os.path.join(HERE, "pipeline_loop.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})

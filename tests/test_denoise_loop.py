@@ -146,6 +146,20 @@ def test_loop_and_free_init_match_the_reference_loop(tag):
     assert torch.equal(got[:, :, :1], G["first"])
 
 
+def test_prepare_latents_matches_the_reference():
+    """Step 5 of the pipeline (pipeline.py:677-733, 950-973) run from the reference's own ``prepare_latents``: same noise for the
+    same generator, conditioning frame first."""
+    import os
+    import numpy as np
+    from animate3d_amd.denoise import prepare_latents
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_loop.npz"))
+    first = torch.from_numpy(gold["prepare/first"])
+    lat, ff = prepare_latents(first[:, :, 0], 6, generator=torch.Generator().manual_seed(21))
+    assert torch.equal(lat, torch.from_numpy(gold["prepare/latents"])) and torch.equal(ff, first) and lat.shape == (3, 4, 6, 8, 8)
+    with pytest.raises(ValueError):
+        prepare_latents(first, 1)
+
+
 @pytest.mark.gpu
 def test_denoise_loop_matches_oracle_loop():
     """3 DDIM steps of the product loop (HIP UNet + fused CFG/DDIM/re-pin kernel) against the oracle loop driving the CPU
