@@ -705,7 +705,6 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
       if constexpr (EPI == EPI_GEGLU) {
         // NB is even here: columns [0,32) of the pass are h, [32,64) the matching gates
         const int cc = lane & 3;
-        const int64_t nh = nbase + 8 * cc;
         const int64_t oc = nbase / 2 + 8 * cc;
         float bh[8], bg[8];
         {
@@ -778,8 +777,10 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
                               // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
+#ifdef A3D_EXP_CHUNK_MAJOR
 int g_conv_chunk_major = 0;  // experiment builds (-DA3D_EXP_CHUNK_MAJOR) only: a3d_tune_gemm(6) tap-major K walk (= the shipped order, the
                              // summation order of the 128x128 kernel), (7) chunk-major (fewer L2 misses, different fp32 summation order)
+#endif
 int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
