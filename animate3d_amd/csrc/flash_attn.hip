@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   constexpr int KS_PAD = D / 16, G_PAD = (D % 16) / 8;    // fragment slot of contraction index D (OFS_PAD)
   static_assert((KROW / 8) % 2 == 1 && (VROW / 8) % 2 == 1, "LDS row strides must be an odd number of 16-B slots");
   static_assert(OFS != OFS_PAD || (DK > D && D % 8 == 0), "OFS_PAD needs a spare contraction slot");
+#ifndef A3D_EXP_FLASH80
   static_assert(OFS != OFS_FMA || QT == 1, "the fma variant keeps one query sub-tile per wave");
+#endif
 
   __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (KS_ELEMS + VT_ELEMS)];
   uint16_t* const Ks0 = smem;
@@ -280,6 +282,34 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           }
     }
 
+#ifdef A3D_EXP_FLASH80
+    if constexpr (OFS == OFS_FMA) {
+      // ---- scores are raw; running max in raw units, lazy by LAZY_THR / scale_log2 (any number of query sub-tiles)
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs) {
+        float mx = sacc[qs][0][0];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
+        if (__any(mx > m_off[qs] + LAZY_THR / p.scale_log2)) {
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          const float m_new = fmaxf(m_off[qs], mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_off[qs] - m_new) * p.scale_log2);
+          m_off[qs] = m_new;
+          if constexpr (!ONES) l_run *= alpha;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
+        }
+        const float mneg = -m_off[qs] * p.scale_log2;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[qs][u][r] = fmaf(sacc[qs][u][r], p.scale_log2, mneg);
+      }
+#else
     if constexpr (OFS == OFS_FMA) {
       // ---- D = 160: scores are raw; running max in raw units, lazy by LAZY_THR / scale_log2
       float mx = sacc[0][0][0];
@@ -303,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[0][u][r] = fmaf(sacc[0][u][r], p.scale_log2, mneg);
+#endif
     } else {
       // ---- lazy offset update: the common path is max + compare + one wave vote per query sub-tile; the slow
       //      path re-bases S', rescales O and moves the offset
@@ -785,6 +816,9 @@ extern int g_a3d_ta_pix;      // temporal_attn.hip
 
 extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
+#ifdef A3D_EXP_FLASH80
+  if (variant == 8 || variant == 9) { g_flash_variant = variant; return A3D_OK; }
+#endif
 #ifdef A3D_ABLATIONS
   if (variant < 0 || variant > 5) return A3D_EINVAL;
 #else
@@ -830,7 +864,13 @@ extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const voi
       }
       launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p);
       break;
-    case 80: launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p); break;
+    case 80:
+#ifdef A3D_EXP_FLASH80   // two query sub-tiles per wave at head dim 80 (every K / V^T fragment feeds two MFMAs): a3d_tune_flash(8 | 9)
+      if (g_flash_variant == 8) { launch<80, 32, 2, OFS_FMA>(aligned, groups, s, p); break; }
+      if (g_flash_variant == 9) { launch<80, 64, 2, OFS_FMA>(aligned, groups, s, p); break; }
+#endif
+      launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p);
+      break;
     case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;
     default: return A3D_EUNSUPPORTED;
   }

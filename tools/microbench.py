@@ -46,7 +46,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         flops = 4.0 * G * S * S * C
         ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in ((0, 1, 2, 3, 4, 5) if D == 40 else (0,)):
+        for var in ((0, 1, 2, 3, 4, 5) if D == 40 else ((0, 8, 9, 0, 8, 9) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
             if ops.lib.a3d_tune_flash(var) != 0:      # ablation variants exist only in -DA3D_ABLATIONS builds
                 continue
             out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
@@ -305,6 +305,7 @@ if __name__ == "__main__":
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
+         "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
                              [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)]),
