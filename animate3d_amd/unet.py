@@ -329,7 +329,10 @@ class MVUNetMotionModel(nn.Module):
                 n=(self._f(ln.weight), self._f(ln.bias)),
                 qkv=self._w(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach(), a.to_v.weight.detach()], 0)),
                 o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)),
-                pe_t=self._w(pe), alpha=None)
+                pe_t=self._w(pe), alpha=None,
+                # diffusers' BasicTransformerBlock.pos_embed stays on (inference.py:176-178 nulls it only when the spatial branch
+                # carries an encoding): the temporal PE then sits on the LayerNorm output that BOTH branches read
+                block_pe=not hasattr(pr, "time_pos_embed"))
             if pr.use_spatial_attn:
                 ns.qkv_sp = self._w(torch.cat([pr.to_k_sp.weight.detach(), pr.to_v_sp.weight.detach(), pr.to_q_sp.weight.detach()], 0))   # [K; V; Q]
                 ns.osp = (self._w(pr.to_out_sp.weight), self._f(pr.to_out_sp.bias))
@@ -483,7 +486,7 @@ class MVUNetMotionModel(nn.Module):
                 if a.spatial_pe:
                     nt, ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L, pe2=self._pe_spatial(C, H, W), pe2_div=1, two=True)
                 else:
-                    nt = ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5)
+                    nt = ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L) if a.block_pe else ops.layer_norm(h, a.n[0], a.n[1], 1e-5)
             else:
                 nt = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L)
             def temporal_branch(nt=nt, a=a):

@@ -420,12 +420,16 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim, eps=1e-5)
         self.ff = FeedForward(dim)
         self.double_self_attention = double_self_attention
-        self.pos_embed = None     # inference.py:176-192 nulls it; the processor adds the PE itself
+        # diffusers gives a motion module's block a sinusoidal ``pos_embed`` (added to the LayerNorm output before attn1 AND attn2);
+        # inference.py:176-192 sets it to None when the spatial branch carries an encoding (the processor then adds the temporal PE
+        # itself).  A callable here (set by _install_processors for the other switch sets) stands for the kept module.
+        self.pos_embed = None
 
     def forward(self, x, encoder_hidden_states=None):
-        x = x + self.attn1(self.norm1(x))
+        pe = self.pos_embed if self.pos_embed is not None else (lambda t: t)
+        x = x + self.attn1(pe(self.norm1(x)))
         ctx = None if self.double_self_attention else encoder_hidden_states
-        x = x + self.attn2(self.norm2(x), encoder_hidden_states=ctx)
+        x = x + self.attn2(pe(self.norm2(x)), encoder_hidden_states=ctx)
         return x + self.ff(self.norm3(x))
 
 
@@ -662,6 +666,9 @@ class MVUNetMotionModelRef(nn.Module):
             blk = m.transformer_blocks[0]
             blk.attn1.set_processor(motion(c, hw))
             blk.attn2.set_processor(motion(c, hw))
+            if not (cfg.motion_spatial_attn and cfg.motion_use_spatial_encoding):      # inference.py:176-178: pos_embed is kept
+                table = sinusoidal_pos_1d(c, cfg.motion_max_seq_length)
+                blk.pos_embed = lambda t, table=table: t + table[:, : t.shape[1]].to(t)
 
         for i, blk in enumerate(self.down_blocks):
             c = cfg.block_out_channels[i]

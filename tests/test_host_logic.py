@@ -236,3 +236,31 @@ def test_processor_installation_matches_the_reference_statements():
     pb = prod.down_blocks[0].attentions[0].transformer_blocks[0]
     assert torch.equal(pb.attn1.processor.to_q_i2v.weight, pb.attn1.to_q.weight) and float(pb.attn1.processor.to_out_i2v.weight.detach().abs().max()) == 0.0
     assert float(pb.attn1.processor.to_out_i2v.bias.detach().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("switches", [dict(mvdream_image_attn=False), dict(motion_use_alpha_blender=False), dict(motion_spatial_attn=False),
+                                      dict(motion_use_spatial_encoding=False), dict(motion_spatial_attn=False, mvdream_image_attn=False)])
+def test_non_released_switch_sets_match_oracle(switches):
+    """The processor switches the released configs never flip (configs/*/​*.yaml all use spatial attention + sinusoid encoding +
+    alpha blender + I2V): product host logic == oracle there too.  In particular where diffusers' BasicTransformerBlock keeps its
+    temporal ``pos_embed`` (inference.py:176-178 nulls it only when the spatial branch carries an encoding): spatial branch off ->
+    PE on the temporal attention's input; spatial on without encoding -> PE on the input of BOTH branches."""
+    small = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=4, norm_num_groups=8, **switches)
+    n, videos, F, hw = 2, 4, 3, (8, 8)
+    ref = O.MVUNetMotionModelRef(O.UNetConfig(**small), n, F, hw).eval()
+    O.init_synthetic_weights(ref, seed=1)
+    model = MVUNetMotionModel(UNetConfig(**small), ops=TorchRefOps(), num_views=n)
+    model.load_state_dict(ref.state_dict())
+    inp = O.synthetic_inputs(O.UNetConfig(**small), videos, n, F, hw, seed=3, cfg_doubled=True)
+    inp["timestep"] = torch.tensor([7, 501, 999, 250])
+    want = ref(**inp, i2v_cond_time_zero=True).sample
+    got = model(**inp, i2v_cond_time_zero=True).sample
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-3, atol=2e-4)
+    if not (small.get("motion_spatial_attn", True) and small.get("motion_use_spatial_encoding", True)):
+        blk = ref.down_blocks[0].motion_modules[0].transformer_blocks[0]
+        assert blk.pos_embed is not None                                  # the kept temporal PE matters: dropping it changes the result
+        saved = [b.transformer_blocks[0].pos_embed for b in ref.modules() if isinstance(b, O.TransformerTemporalModel)]
+        for b in ref.modules():
+            if isinstance(b, O.TransformerTemporalModel):
+                b.transformer_blocks[0].pos_embed = None
+        assert (ref(**inp, i2v_cond_time_zero=True).sample - want).abs().max() > 1e-3
