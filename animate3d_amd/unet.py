@@ -62,6 +62,9 @@ class MVUNetMotionModel(nn.Module):
         self.parallel = None                # set by animate3d_amd.parallel.shard_unet
         if len(cfg.block_out_channels) != len(cfg.down_has_attn):
             raise ValueError("block_out_channels and down_has_attn must have the same length")
+        if 9 * cfg.in_channels > 64:        # conv_in runs as a K = 64 GEMM over 3x3 patches (a3d_im2col_in)
+            raise ValueError(f"in_channels = {cfg.in_channels} is not supported (<= 7; the MV-VDM UNet has 4 — the 9-channel PIA conv_in "
+                             "of unet_motion_mv_model.py:312-330 is not on this path)")
         ctx = torch.device(device) if device is not None else torch.device("cpu")
         with ctx:
             self._build(cfg)

@@ -264,3 +264,23 @@ def test_non_released_switch_sets_match_oracle(switches):
             if isinstance(b, O.TransformerTemporalModel):
                 b.transformer_blocks[0].pos_embed = None
         assert (ref(**inp, i2v_cond_time_zero=True).sample - want).abs().max() > 1e-3
+
+
+def test_structural_config_variants_match_oracle():
+    """Topology knobs away from the SD1.5 values (block count and widths, attention placement, heads, layers per block, token
+    counts, IP scale): product host logic == oracle; unsupported ones raise at construction."""
+    base = dict(block_out_channels=(32, 64, 64, 64), num_attention_heads=4, norm_num_groups=8)
+    for sw in (dict(ip_scale=0.4, ip_num_tokens=8), dict(layers_per_block=1, down_has_attn=(True, False, True, False)),
+               dict(block_out_channels=(32, 64), down_has_attn=(True, False), motion_num_attention_heads=2),
+               dict(cross_attention_dim=48, motion_max_seq_length=8, out_channels=8, ip_image_embed_dim=40)):
+        kw = dict(base, **sw)
+        n, videos, F, hw = 2, 4, 3, (8, 8)
+        ocfg = O.UNetConfig(**kw)
+        ref = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
+        O.init_synthetic_weights(ref, seed=1)
+        model = MVUNetMotionModel(UNetConfig(**kw), ops=TorchRefOps(), num_views=n)
+        model.load_state_dict(ref.state_dict(), strict=True)
+        inp = O.synthetic_inputs(ocfg, videos, n, F, hw, seed=3, cfg_doubled=True)
+        np.testing.assert_allclose(model(**inp).sample.numpy(), ref(**inp).sample.numpy(), rtol=2e-3, atol=2e-4, err_msg=str(sw))
+    with pytest.raises(ValueError):
+        MVUNetMotionModel(UNetConfig(**dict(base, in_channels=9)), ops=TorchRefOps(), num_views=2)
