@@ -44,6 +44,22 @@ A3D_DEV int64_t xcd_remap(int64_t bid, int64_t nblk) {
   return base + idx;
 }
 
+// Per-device one-time state (dynamic-LDS attribute, CU count): one process may drive several GPUs, so the "done" flags
+// are bit masks / tables indexed by the current HIP device, not process-wide booleans.
+static inline int a3d_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) d = 0;
+  return d;
+}
+template <typename F>
+static inline int a3d_once_per_device(uint64_t& done_mask, F&& fn) {
+  const int d = a3d_current_device();
+  if ((done_mask >> d) & 1ull) return 0;
+  const int rc = fn();
+  if (rc == 0) done_mask |= (1ull << d);
+  return rc;
+}
+
 static inline int a3d_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? A3D_OK : (int)e;

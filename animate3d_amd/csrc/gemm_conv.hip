@@ -791,13 +791,10 @@ int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
   if constexpr (VAR == 0) {
     if (g_gemm_persist == 2) return launch_persist_res<CONV, EPI, NB, RES, 1>(stream, p, cus);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<CONV, EPI, NB, RES, VAR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static uint64_t attr_done = 0;
+  if (int rc = a3d_once_per_device(attr_done, [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<CONV, EPI, NB, RES, VAR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
   const int64_t ntiles = p.tiles_m * p.tiles_n;
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
   gemm_persist_kernel<CONV, EPI, NB, RES, VAR><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
@@ -808,12 +805,14 @@ int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
 template <int CONV, int EPI>
 int try_launch_persist(hipStream_t stream, GemmParams& p) {
   if (!g_gemm_persist || p.out_f32) return -1000;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1000;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  static int cus_of[64] = {0};
+  const int dev = a3d_current_device();
+  if (cus_of[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
+    cus_of[dev] = n > 0 ? n : 256;
   }
+  const int cus = cus_of[dev];
   if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return -1000;
   const int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
   if (nb == 0) return -1000;
@@ -841,13 +840,10 @@ int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 /
 template <int CONV, int EPI, int BKT, bool RES>
 int launch_res(hipStream_t stream, GemmParams& p, int64_t nblk) {
   using TC = TileCfg<BKT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI, BKT, RES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, TC::SMEM_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static uint64_t attr_done = 0;
+  if (int rc = a3d_once_per_device(attr_done, [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<CONV, EPI, BKT, RES>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, TC::SMEM_BYTES); })) return rc;
   gemm_kernel<CONV, EPI, BKT, RES><<<dim3((unsigned)nblk), dim3(256), TC::SMEM_BYTES, stream>>>(p);
   return a3d_launch_status();
 }

@@ -165,13 +165,10 @@ int launch(hipStream_t s, const TAParams& p, int C) {
   const int64_t nblk = (p.npix + PIX - 1) / PIX;
   if (nblk > 0x7fffffffLL) return A3D_EINVAL;
   const size_t lds = (size_t)3 * p.frames * (PIX * SLAB + 8) * sizeof(uint16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<FP, PIX, DP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP * (PIX * SLAB + 8) * 2);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static uint64_t attr_done = 0;
+  if (int rc = a3d_once_per_device(attr_done, [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel<FP, PIX, DP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP * (PIX * SLAB + 8) * 2); })) return rc;
   temporal_attn_kernel<FP, PIX, DP><<<dim3((unsigned)nblk, (unsigned)(C / SLAB)), dim3(PIX * NSL * FP), lds, s>>>(p);
   return a3d_launch_status();
 }

@@ -263,6 +263,37 @@ def test_flash_attn_rescale_branch(ops, ref):
     check("attn rescale spikes", ops.flash_attn(q, k, v, m, m, 1, heads, L, L), ref.flash_attn(q, k, v, m, m, 1, heads, L, L))
 
 
+@pytest.mark.parametrize("spikes", [(3,), (40, 70), (500,), (31, 32, 63, 64, 95, 96), (250, 260, 270, 280, 290, 300, 310)])
+@pytest.mark.parametrize("L,q_len", [(512, 512), (1024, 700)])
+def test_flash_attn_interleaved_rescale_paths(ops, ref, spikes, L, q_len):
+    """Level-0 shapes take the software-pipelined kernel (flash_attn_il_kernel): its offset moves per 32-key sub-tile, with the
+    pending probabilities folded in first.  Spikes in the very first sub-tile (initial offset), in consecutive sub-tiles, at
+    sub-tile borders and in the last one (peeled iterations); a ragged query count exercises the masked rows."""
+    heads, D = 8, 40
+    C = heads * D
+    q, k, v = rnd(q_len, C, seed=1), rnd(L, C, seed=2), rnd(L, C, seed=3)
+    for t, row in enumerate(spikes):
+        k[row] = q[7 + 3 * t] * (3.0 + 1.5 * t)
+    check(f"il attn spikes {spikes} L{L} q{q_len}", ops.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L),
+          ref.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L))
+
+
+def test_flash_attn_kernel_variants_agree(ops, ref):
+    """The interleaved (default), ping-pong and plain D = 40 kernels on one long multi-view shape, each against the fp32 reference."""
+    heads, D, b, n, F, L = 8, 40, 1, 4, 2, 256
+    C = heads * D
+    qkv = rnd(b * n * F * L, 3 * C, seed=11)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    qm, k0 = _mv_maps(n, F, L)
+    want = ref.flash_attn(q, k, v, qm, k0, b * F, heads, n * L, n * L)
+    try:
+        for var in (0, 16, 5):
+            assert ops.lib.a3d_tune_flash(var) == 0
+            check(f"D40 kernel variant {var}", ops.flash_attn(q, k, v, qm, k0, b * F, heads, n * L, n * L), want)
+    finally:
+        ops.lib.a3d_tune_flash(0)
+
+
 @pytest.mark.parametrize("D", [40, 80, 160])
 @pytest.mark.parametrize("V,F,L", [(2, 3, 16), (1, 4, 64), (2, 16, 64), (1, 32, 8), (1, 3, 5), (3, 16, 7)])
 def test_temporal_attn(ops, ref, D, V, F, L):

@@ -46,7 +46,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         flops = 4.0 * G * S * S * C
         ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in ((0, 1, 2, 3, 4, 5) if D == 40 else ((0, 8, 9, 0, 8, 9) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
+        for var in ((0, 16, 7, 5, 0, 16) if D == 40 else ((0, 8, 9, 0, 8, 9) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
             if ops.lib.a3d_tune_flash(var) != 0:      # ablation variants exist only in -DA3D_ABLATIONS builds
                 continue
             out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
@@ -54,6 +54,27 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
             med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5 if D == 40 else 10)
             print(f"D={D:3d} S={S:5d} G={G} var={var}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
         ops.lib.a3d_tune_flash(0)
+
+
+def bench_il_abl(ops):
+    """Timing ablations of the interleaved D = 40 attention kernel (-DA3D_ABLATIONS build; results wrong by construction)."""
+    D, n, F, L, b = 40, 4, 16, 4096, 2
+    heads, C = 8, 8 * D
+    qkv = rnd(b * n * F * L, 3 * C)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    qm = RowMap(F, n * F * L, L, L, F * L)
+    S, G = n * L, b * F
+    flops = 4.0 * G * S * S * C
+    names = {0: "full", 1: "no exp", 2: "no max/vote", 4: "no staging", 8: "no barrier", 12: "no staging, no barrier", 16: "no QK mfma", 32: "no PV mfma",
+             48: "no mfma", 64: "no frag reads", 76: "no frag reads/staging/barrier", 129: "no exp, no cvt", 131: "no exp/cvt/max",
+             207: "mfma only (no exp/cvt/max/staging/barrier/frag reads)", 124: "no mfma/frag/staging/barrier: exp+cvt+max only"}
+    for base, tag in ((1000, "8 waves"), (1256, "4 waves")):
+        for a, nm in names.items():
+            if ops.lib.a3d_tune_flash(base + a) != 0:
+                continue
+            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=4)
+            print(f"il {tag} ABL={a:3d} {nm:58s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s-equivalent")
+    ops.lib.a3d_tune_flash(0)
 
 
 def bench_gemm(ops):
@@ -304,6 +325,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+         "il_abl": bench_il_abl,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
