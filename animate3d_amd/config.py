@@ -29,6 +29,11 @@ class UNetConfig:
     motion_spatial_attn: bool = True          # motion_module_attn_cfg.spatial_attn.enabled
     motion_use_spatial_encoding: bool = True  # ...attn_cfg.use_spatial_encoding (sinusoid)
     motion_use_alpha_blender: bool = True     # motion_module_attn_cfg.use_alpha_blender
+    # switches the released configs leave off (attention_processor.py:478-540)
+    motion_image_attn: bool = False           # motion_module_attn_cfg.image_attn.enabled: first-frame attention per view
+    motion_use_camera_encoding: bool = False  # ...spatial_attn.attn_cfg.use_camera_encoding: one vector per view
+    motion_spatial_encoding_type: str = "sinusoid"    # or "learnable" (embeddings.py:99-157)
+    motion_camera_encoding_type: str = "sinusoid"     # or "learnable" (LabelEmbedding table)
     encoder_hid_dim_type: Optional[str] = "ip_image_proj"
 
     def to_dict(self):

@@ -46,7 +46,7 @@ struct GemmParams {
   int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
 #endif
   // conv geometry (CONV only)
-  int B, H, Wd, Cin, Ho, Wo, stride, up;
+  int B, H, Wd, Cin, Ho, Wo, stride, up, He, We;   // He x We: extent of the (virtual) upsampled image of the up2x conv
   int64_t tiles_n, tiles_m;
 };
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
           else ra[i] = u32x4_t{0u, 0u, 0u, 0u};
         }
       } else {                         // nearest-2x upsample folded into the address (3 convs per step)
-        const int He = 2 * p.H, We = 2 * p.Wd;
+        const int He = p.He, We = p.We;          // 2H x 2W, or one less when the caller forces the output size
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
           const int yy = a_y[i] + ky - 1, xx = a_x[i] + kx - 1;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) {
             const int yy = oy + tp / 3 - 1, xx = ox + tp % 3 - 1;
-            if (yy >= 0 && yy < 2 * p.H && xx >= 0 && xx < 2 * p.Wd) mask |= 1u << tp;
+            if (yy >= 0 && yy < p.He && xx >= 0 && xx < p.We) mask |= 1u << tp;
           }
           amask[i >> 1] |= (mask << (9 * (i & 1))) | ((uint32_t)(~oy & 1) << (18 + 2 * (i & 1))) | ((uint32_t)(~ox & 1) << (19 + 2 * (i & 1)));
         } else {
@@ -914,16 +914,19 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
                                 int B, int H, int W, int Cin, int Cout, int stride, int up2x) {
   if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
   if (Cin % 64 != 0 || Cout % 4 != 0 || (stride != 1 && stride != 2)) return A3D_EINVAL;
-  if (up2x && stride != 1) return A3D_EINVAL;
+  if (up2x < 0 || up2x > 7 || (up2x > 1 && !(up2x & 1)) || (up2x && stride != 1)) return A3D_EINVAL;
   if (!aligned16(X) || !aligned16(Wp) || (reinterpret_cast<uintptr_t>(Y) & 7u)) return A3D_EINVAL;
   if (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)) return A3D_EINVAL;
   if (rowbias && rb_div <= 0) return A3D_EINVAL;
-  const int He = up2x ? 2 * H : H, We = up2x ? 2 * W : W;
+  // up2x bit 0: nearest-2x upsample in front of the conv; bits 1 / 2: the upsampled image is cropped by its last row /
+  // column (nearest interpolation to the forced size 2H-1 / 2W-1 of unet_motion_mv_model.py:831-837 is exactly that)
+  const int He = up2x ? 2 * H - ((up2x >> 1) & 1) : H, We = up2x ? 2 * W - ((up2x >> 2) & 1) : W;
+  if (He <= 0 || We <= 0) return A3D_EINVAL;
   GemmParams p{};
   p.X = (const uint16_t*)X; p.ldx = Cin; p.W = (const uint16_t*)Wp; p.ldw = (int64_t)9 * Cin;
   p.bias = bias; p.rowbias = (const uint16_t*)rowbias; p.rb_div = rowbias ? rb_div : 1;
   p.R = (const uint16_t*)R; p.ldr = Cout; p.Y = (uint16_t*)Y; p.ldy = Cout;
-  p.B = B; p.H = H; p.Wd = W; p.Cin = Cin; p.stride = stride; p.up = up2x ? 1 : 0;
+  p.B = B; p.H = H; p.Wd = W; p.Cin = Cin; p.stride = stride; p.up = up2x ? 1 : 0; p.He = He; p.We = We;
   p.Ho = (He + 2 - 3) / stride + 1; p.Wo = (We + 2 - 3) / stride + 1;
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;

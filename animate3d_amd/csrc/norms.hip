@@ -320,7 +320,10 @@ extern "C" int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups) {
 extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                                    float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
   if (!X || !Y || !gamma || !beta || !ws || B <= 0 || rows <= 0 || C <= 0 || groups <= 0) return A3D_EINVAL;
-  if (C % 8 != 0 || C % groups != 0 || C / groups < 4 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;   // a 16-byte chunk spans <= 2 groups
+  if (C % 8 != 0 || C % groups != 0 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;
+  // a 16-byte chunk (8 channels) must touch at most 2 groups: channels-per-group 4 (chunk = exactly 2 groups) or >= 7
+  // (8 channels starting anywhere span <= 2 groups of >= 7); 5 and 6 can straddle 3 groups and are rejected
+  if (const int cg = C / groups; cg < 4 || cg == 5 || cg == 6) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
   if (B > 65535) return A3D_EINVAL;
   GNParams p{};

@@ -46,6 +46,14 @@ def ddim_alphas(t: int, alphas_cumprod: torch.Tensor, num_inference_steps: int, 
     return a_t, a_prev
 
 
+def randn_like_reference(shape, generator: Optional[torch.Generator], device, dtype: torch.dtype) -> torch.Tensor:
+    """diffusers' ``randn_tensor``: draw on the generator's device (a CPU generator is the usual idiom, ``inference.py``
+    seeds one) and move; without a generator draw on ``device``."""
+    device = torch.device(device)
+    gdev = generator.device if generator is not None else device
+    return torch.randn(tuple(shape), generator=generator, device=gdev, dtype=dtype).to(device)
+
+
 def prepare_latents(first_frame_latents: torch.Tensor, num_frames: int, generator: Optional[torch.Generator] = None,
                     device=None, dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
     """Step 5 of ``__call__`` (pipeline.py:950-973, ``i2v_similarity_init`` = None as released): the encoded conditioning images
@@ -58,8 +66,7 @@ def prepare_latents(first_frame_latents: torch.Tensor, num_frames: int, generato
     first = first_frame_latents if first_frame_latents.dim() == 5 else first_frame_latents.unsqueeze(2)
     first = first.to(device=device, dtype=dtype)
     n, c, _, h, w = first.shape
-    gdev = generator.device if generator is not None else device
-    rest = torch.randn((n, c, num_frames - 1, h, w), generator=generator, device=gdev, dtype=dtype).to(device)
+    rest = randn_like_reference((n, c, num_frames - 1, h, w), generator, device, dtype)
     return torch.cat([first, rest], dim=2), first
 
 
@@ -128,7 +135,7 @@ def free_init_renoise(rest_latents: torch.Tensor, initial_noise: torch.Tensor, a
     """FreeInitMixin._apply_free_init for iteration > 0: ``scheduler.add_noise(latents, initial_noise, T-1)`` in fp32, fresh
     fp32 noise of the same shape from ``generator``, frequency mix."""
     z_t = (alpha_prod_T ** 0.5) * rest_latents.float() + ((1.0 - alpha_prod_T) ** 0.5) * initial_noise.float()
-    z_rand = torch.randn(rest_latents.shape, generator=generator, device=rest_latents.device, dtype=torch.float32)
+    z_rand = randn_like_reference(rest_latents.shape, generator, rest_latents.device, torch.float32)
     return free_init_mix(z_t, z_rand, low_pass_filter).to(rest_latents.dtype)
 
 

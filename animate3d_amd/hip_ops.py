@@ -97,6 +97,22 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def on_model_device(method):
+    """Decorator for the entry points of a module that owns a ``HipOps``: the C-ABI launches on the CURRENT device's stream
+    (``torch.cuda.current_stream``) and allocates there, so a model living on cuda:1 must run with cuda:1 current.  One
+    process per GPU is the deployment model; this makes a second device in one process work as well."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        dev = self.device
+        if dev.type == "cuda" and torch.cuda.current_device() != (dev.index if dev.index is not None else torch.cuda.current_device()):
+            with torch.cuda.device(dev):
+                return method(self, *args, **kwargs)
+        return method(self, *args, **kwargs)
+    return wrapper
+
+
 class HipOps:
     """The op set of the denoise step, executed by the gfx950 kernels.  All activations are 2-D
     ``[rows, C]`` bf16 CUDA tensors (NHWC images flattened to rows)."""
@@ -161,13 +177,21 @@ class HipOps:
         _check(rc, f"a3d_gemm_geglu_bf16 M={M} N2={N2} K={K}")
         return y
 
-    def conv3x3(self, x, B: int, H: int, W: int, w, bias, *, stride: int = 1, up2x: bool = False, rowbias=None, rb_div: int = 1, residual=None):
-        """x [B*H*W, Cin] -> (y [B*Ho*Wo, Cout], Ho, Wo); w packed [Cout, 9*Cin] (ky, kx, ci)."""
+    def conv3x3(self, x, B: int, H: int, W: int, w, bias, *, stride: int = 1, up2x: bool = False, rowbias=None, rb_div: int = 1, residual=None,
+                up_size=None):
+        """x [B*H*W, Cin] -> (y [B*Ho*Wo, Cout], Ho, Wo); w packed [Cout, 9*Cin] (ky, kx, ci).  ``up_size`` = (Ho, Wo) forces
+        the size of the nearest upsampling in front of the conv (2H or 2H-1, likewise W: unet_motion_mv_model.py:831-837)."""
         x, w = self._act(x, "conv.x"), self._act(w, "conv.w")
         Cin = x.shape[1]
         Cout = w.shape[0]
         assert x.is_contiguous() and w.is_contiguous() and x.shape[0] == B * H * W and w.shape[1] == 9 * Cin
         He, We = (2 * H, 2 * W) if up2x else (H, W)
+        up_code = 1 if up2x else 0
+        if up_size is not None:
+            if not up2x or up_size[0] not in (2 * H, 2 * H - 1) or up_size[1] not in (2 * W, 2 * W - 1):
+                raise ValueError(f"forced upsample size {tuple(up_size)} is not reachable from {(H, W)} (2x or 2x - 1 per axis)")
+            He, We = int(up_size[0]), int(up_size[1])
+            up_code |= (2 if He == 2 * H - 1 else 0) | (4 if We == 2 * W - 1 else 0)
         Ho, Wo = (He - 1) // stride + 1, (We - 1) // stride + 1
         y = self.empty(B * Ho * Wo, Cout)
         if residual is not None:
@@ -175,7 +199,7 @@ class HipOps:
         if rowbias is not None:
             assert rowbias.is_contiguous() and rowbias.shape[1] == Cout
         rc = self.lib.a3d_conv3x3_bf16(self._stream(), _p(x), _p(w), _p(bias), _p(rowbias), rb_div, _p(residual), _p(y),
-                                       B, H, W, Cin, Cout, stride, 1 if up2x else 0)
+                                       B, H, W, Cin, Cout, stride, up_code)
         _check(rc, f"a3d_conv3x3_bf16 B={B} H={H} W={W} Cin={Cin} Cout={Cout} stride={stride} up={up2x}")
         return y, Ho, Wo
 

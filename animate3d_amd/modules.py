@@ -72,29 +72,92 @@ class _AlphaBlender(Holder):
         self.mix_factor = nn.Parameter(torch.zeros(1))
 
 
+class _Learned2D(Holder):
+    """embeddings.py:99-157 LearnedPositionalEncoding2D: channels [0, C/2) = col_embed(x), [C/2, C) = row_embed(y)."""
+
+    def __init__(self, num_feats, rows, cols):
+        super().__init__()
+        self.row_embed = nn.Embedding(rows, num_feats)
+        self.col_embed = nn.Embedding(cols, num_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+
+class _LabelEmbedding(Holder):
+    def __init__(self, num_classes, hidden_size):
+        super().__init__()
+        self.embedding_table = nn.Embedding(num_classes, hidden_size)
+
+
+class _SoftmaxAlphaBlender(Holder):
+    def __init__(self):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.zeros(3))
+
+
 class SpatioTemporalI2VAttnProcessor(Holder):
-    """Motion-module processor: temporal attention + multi-view spatial attention, blended
-    (reference class SpatioTemporalI2VXFormersAttnProcessor, attention_processor.py:448-723;
-    released switch set: spatial attn on, sinusoid 2-D PE, camera encoding off, image attn off)."""
+    """Motion-module processor: temporal attention + optional multi-view spatial attention (2-D positional encoding
+    sinusoid / learnable, optional per-view camera encoding) + optional first-frame image attention, merged by sum,
+    AlphaBlender or the 3-way SoftmaxAlphaBlender (reference class SpatioTemporalI2VXFormersAttnProcessor,
+    attention_processor.py:448-744).  Released switch set: spatial attention with the sinusoid encoding and the blender."""
     kind = "spatio_temporal"
 
     def __init__(self, hidden_size: int, spatial_attn: bool = True, use_spatial_encoding: bool = True,
-                 use_alpha_blender: bool = True, max_seq_length: int = 32):
+                 use_alpha_blender: bool = True, max_seq_length: int = 32, image_attn: bool = False,
+                 use_camera_encoding: bool = False, spatial_encoding_type: str = "sinusoid",
+                 camera_encoding_type: str = "sinusoid", feature_size: int = 32, num_views: Optional[int] = None):
         super().__init__()
         self.hidden_size = hidden_size
         self.use_spatial_attn, self.use_spatial_encoding, self.use_alpha_blender = spatial_attn, use_spatial_encoding, use_alpha_blender
+        self.use_image_attn, self.use_camera_encoding = image_attn, use_camera_encoding
+        self.spatial_encoding_type, self.camera_encoding_type = spatial_encoding_type, camera_encoding_type
         if spatial_attn:
             self.to_q_sp = _lin(hidden_size, hidden_size, bias=False)
             self.to_k_sp = _lin(hidden_size, hidden_size, bias=False)
             self.to_v_sp = _lin(hidden_size, hidden_size, bias=False)
             self.to_out_sp = _lin(hidden_size, hidden_size, bias=True)
-            if use_spatial_encoding:
+            if use_spatial_encoding or use_camera_encoding:
                 self.time_pos_embed = _PE(hidden_size, max_seq_length)
-            if use_alpha_blender:
-                self.alpha_blender = _AlphaBlender()
-            else:
-                nn.init.zeros_(self.to_out_sp.weight)
-                nn.init.zeros_(self.to_out_sp.bias)
+            if use_spatial_encoding:
+                if spatial_encoding_type == "learnable":
+                    self.spatial_pos_embed = _Learned2D(hidden_size // 2, feature_size, feature_size)
+                elif spatial_encoding_type != "sinusoid":
+                    raise ValueError(f"Spatial encoding type {spatial_encoding_type} is not supported yet!")
+            if use_camera_encoding:
+                if num_views is None:
+                    raise ValueError("camera encoding needs num_views at construction (MVUNetMotionModel(num_views=...))")
+                if camera_encoding_type == "learnable":
+                    self.camera_embed = _LabelEmbedding(num_views, hidden_size)
+                elif camera_encoding_type == "sinusoid":
+                    self.camera_embed = _PE(hidden_size, num_views)
+                else:
+                    raise ValueError(f"Camera encoding type {camera_encoding_type} is not supported yet!")
+        if image_attn:
+            self.to_q_i2v = _lin(hidden_size, hidden_size, bias=False)
+            self.to_k_i2v = _lin(hidden_size, hidden_size, bias=False)
+            self.to_v_i2v = _lin(hidden_size, hidden_size, bias=False)
+            self.to_out_i2v = _lin(hidden_size, hidden_size, bias=True)
+        num_attn = 1 + int(spatial_attn) + int(image_attn)
+        if not use_alpha_blender:
+            for m in ([self.to_out_sp] if spatial_attn else []) + ([self.to_out_i2v] if image_attn else []):
+                nn.init.zeros_(m.weight)
+                nn.init.zeros_(m.bias)
+        elif num_attn == 2:
+            self.alpha_blender = _AlphaBlender()
+        elif num_attn == 3:
+            self.alpha_blender = _SoftmaxAlphaBlender()
+
+    def blend_coefficients(self):
+        """(temporal, spatial, image) weights of the merge (attention_processor.py:700-713, 727-744)."""
+        sp, im = self.use_spatial_attn, self.use_image_attn
+        if not self.use_alpha_blender or not (sp or im):
+            return 1.0, 1.0 if sp else 0.0, 1.0 if im else 0.0
+        m = self.alpha_blender.mix_factor.detach().float()
+        if sp and im:
+            a = torch.softmax(m, dim=0)
+            return float(a[1]), float(a[0]), float(a[2])
+        a = float(torch.sigmoid(m)[0])
+        return 1.0 - a, (a if sp else 0.0), (a if im else 0.0)
 
 
 # ---------------- diffusers-named containers

@@ -22,7 +22,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from .denoise import ddim_schedule
+from .denoise import ddim_schedule, randn_like_reference
 
 
 def normalize_camera(c2w: torch.Tensor) -> torch.Tensor:
@@ -62,7 +62,7 @@ def sds_recon_loss(unet, latents: torch.Tensor, t: torch.Tensor, text_embeddings
     with torch.no_grad():
         rest = videos[:, :, 1:]
         if noise is None:
-            noise = torch.randn(rest.shape, generator=generator, device=latents.device, dtype=latents.dtype)
+            noise = randn_like_reference(rest.shape, generator, latents.device, latents.dtype)
         else:                                               # the reference draws it in "b n c f h w" order; accept that layout too
             noise = noise.to(latents)
             if noise.shape == (b, n, c, f - 1, h, w):

@@ -35,7 +35,7 @@ import torch.nn as nn
 from . import modules as M
 from .config import UNetConfig
 from .embeddings import sine_pos_2d, sinusoidal_pos_1d
-from .hip_ops import RowMap
+from .hip_ops import RowMap, on_model_device
 
 
 class UNet3DConditionOutput:
@@ -117,11 +117,20 @@ class MVUNetMotionModel(nn.Module):
         for i, b in enumerate(self.up_blocks):
             yield f"up_blocks.{i}", b, list(reversed(self.config.block_out_channels))[i]
 
+    def _block_levels(self):
+        """(block, channels, resolution level) — level l works on latents of size >> l."""
+        nlev = len(self.config.block_out_channels)
+        for i, b in enumerate(self.down_blocks):
+            yield b, self.config.block_out_channels[i], i
+        yield self.mid_block, self.config.block_out_channels[-1], nlev - 1
+        for i, b in enumerate(self.up_blocks):
+            yield b, list(reversed(self.config.block_out_channels))[i], nlev - 1 - i
+
     def _install_default_processors(self):
         """inference.py:90-174 by layer ROLE (attn1 / attn2 / motion_modules), not by diffusers class
         identity.  ``to_q_i2v := to_q`` and ``to_out_i2v := 0`` as inference.py:161-165."""
         cfg = self.config
-        for _, blk, c in self._blocks():
+        for blk, c, lvl in self._block_levels():
             if blk.has_cross_attention:
                 for t in blk.attentions:
                     tb = t.transformer_blocks[0]
@@ -139,8 +148,12 @@ class MVUNetMotionModel(nn.Module):
             for m in blk.motion_modules:
                 tb = m.transformer_blocks[0]
                 for a in (tb.attn1, tb.attn2):
-                    sp = M.SpatioTemporalI2VAttnProcessor(c, cfg.motion_spatial_attn, cfg.motion_use_spatial_encoding,
-                                                          cfg.motion_use_alpha_blender, cfg.motion_max_seq_length)
+                    sp = M.SpatioTemporalI2VAttnProcessor(
+                        c, cfg.motion_spatial_attn, cfg.motion_use_spatial_encoding, cfg.motion_use_alpha_blender,
+                        cfg.motion_max_seq_length, image_attn=cfg.motion_image_attn, use_camera_encoding=cfg.motion_use_camera_encoding,
+                        spatial_encoding_type=cfg.motion_spatial_encoding_type, camera_encoding_type=cfg.motion_camera_encoding_type,
+                        feature_size=max(1, (cfg.sample_size or 32) >> lvl),      # table rows of the learnable encoding (inference.py:93-105)
+                        num_views=self.num_views)
                     a.set_processor(sp)
 
     # ------------------------------------------------------------------ diffusers-style surface
@@ -204,6 +217,18 @@ class MVUNetMotionModel(nn.Module):
                 sd.update({k: v for k, v in motion_adapter.state_dict().items()
                            if re.match(r"^((down_blocks|up_blocks)\.\d+|mid_block)\.motion_modules\.", k)})
             model.load_state_dict(sd, strict=False)
+            # inference.py:161-165 initialises the I2V branch AFTER from_unet2d, from the PRETRAINED to_q (a plain 2-D UNet
+            # carries no to_q_i2v): the construction-time copy took the random initialisation, so redo it for every
+            # processor the source did not supply (a source that has the key wins, as in the reference's from_unet2d)
+            with torch.no_grad():
+                for name, blk, _c in model._blocks():
+                    if blk.has_cross_attention:
+                        for j, t in enumerate(blk.attentions):
+                            tb = t.transformer_blocks[0]
+                            key = f"{name}.attentions.{j}.transformer_blocks.0.attn1.processor.to_q_i2v.weight"
+                            if getattr(tb.attn1.processor, "kind", None) == "mvdream_i2v" and key not in sd:
+                                tb.attn1.processor.to_q_i2v.weight.copy_(tb.attn1.to_q.weight)
+            model._packed = None
         return model
 
     def _load_ip_adapter_weights(self, state_dict):
@@ -327,20 +352,24 @@ class MVUNetMotionModel(nn.Module):
                 pe = pr.time_pos_embed.pe[0]
             else:   # diffusers BasicTransformerBlock.pos_embed (sinusoidal) when the processor holds none
                 pe = sinusoidal_pos_1d(C, self.config.motion_max_seq_length)[0].to(a.to_q.weight.device)
+            proc_pe = hasattr(pr, "time_pos_embed")          # the processor restores the temporal encoding itself (:583-584)
+            ct, cs, ci = pr.blend_coefficients()
             ns = SimpleNamespace(
-                heads=a.heads, spatial=pr.use_spatial_attn, spatial_pe=pr.use_spatial_attn and pr.use_spatial_encoding,
+                heads=a.heads, spatial=pr.use_spatial_attn, image=pr.use_image_attn,
+                spatial_pe=pr.use_spatial_attn and pr.use_spatial_encoding, camera_pe=pr.use_spatial_attn and pr.use_camera_encoding,
                 n=(self._f(ln.weight), self._f(ln.bias)),
                 qkv=self._w(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach(), a.to_v.weight.detach()], 0)),
                 o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)),
-                pe_t=self._w(pe), alpha=None,
-                # diffusers' BasicTransformerBlock.pos_embed stays on (inference.py:176-178 nulls it only when the spatial branch
-                # carries an encoding): the temporal PE then sits on the LayerNorm output that BOTH branches read
-                block_pe=not hasattr(pr, "time_pos_embed"))
+                pe_t=self._w(pe), coef=(ct, cs, ci), proc=pr,
+                # diffusers' BasicTransformerBlock.pos_embed stays on unless the spatial branch carries an encoding
+                # (inference.py:176-178): the temporal PE then sits on the LayerNorm output that EVERY branch reads
+                block_pe=not proc_pe)
             if pr.use_spatial_attn:
                 ns.qkv_sp = self._w(torch.cat([pr.to_k_sp.weight.detach(), pr.to_v_sp.weight.detach(), pr.to_q_sp.weight.detach()], 0))   # [K; V; Q]
                 ns.osp = (self._w(pr.to_out_sp.weight), self._f(pr.to_out_sp.bias))
-                if pr.use_alpha_blender:
-                    ns.alpha = float(torch.sigmoid(pr.alpha_blender.mix_factor.detach().float()).item())
+            if pr.use_image_attn:
+                ns.qkv_img = self._w(torch.cat([pr.to_k_i2v.weight.detach(), pr.to_v_i2v.weight.detach(), pr.to_q_i2v.weight.detach()], 0))
+                ns.oimg = (self._w(pr.to_out_i2v.weight), self._f(pr.to_out_i2v.bias))
             attns.append(ns)
         out = SimpleNamespace(norm=(self._f(m.norm.weight), self._f(m.norm.bias)),
                               pin=(self._w(m.proj_in.weight), self._f(m.proj_in.bias)),
@@ -392,6 +421,37 @@ class MVUNetMotionModel(nn.Module):
         if key not in self._pe_cache:
             self._pe_cache[key] = sine_pos_2d(C // 2, h, w).to(device=self.device, dtype=self.ops.act_dtype).contiguous()
         return self._pe_cache[key]
+
+    def _pe_spatial_general(self, a, C: int, h: int, w: int, n: int, F: int, view0: int = 0):
+        """(table, rows-per-entry divisor) added to the spatial branch's tokens: the 2-D encoding (sinusoid or the processor's
+        learnable row / column tables, embeddings.py:52-157) plus, with camera encoding on, one vector per view
+        (attention_processor.py:565-575).  Without camera encoding the table is [h*w, C] (index = token within the image);
+        with it the index runs over (view, frame, token) of one batch element, [n*F*h*w, C].  ``view0``: first global view
+        of a view shard."""
+        pr = a.proc
+        L = h * w
+        pe = None
+        if a.spatial_pe:
+            if pr.spatial_encoding_type == "learnable":
+                sp = pr.spatial_pos_embed
+                if h > sp.row_embed.weight.shape[0] or w > sp.col_embed.weight.shape[0]:
+                    raise ValueError(f"feature map {(h, w)} exceeds the learnable positional tables "
+                                     f"({sp.row_embed.weight.shape[0]} x {sp.col_embed.weight.shape[0]})")
+                xe = sp.col_embed.weight.detach().float()[:w][None, :, :].expand(h, w, -1)
+                ye = sp.row_embed.weight.detach().float()[:h][:, None, :].expand(h, w, -1)
+                pe = torch.cat([xe, ye], dim=-1).reshape(L, C).to(self.device)
+            else:
+                pe = sine_pos_2d(C // 2, h, w).to(self.device)
+        if not a.camera_pe:
+            return pe.to(self.ops.act_dtype).contiguous(), 1
+        cam = pr.camera_embed.embedding_table.weight if pr.camera_encoding_type == "learnable" else pr.camera_embed.pe[0]
+        cam = cam.detach().float().to(self.device)[view0:view0 + n]
+        if cam.shape[0] != n:
+            raise ValueError(f"camera encoding holds {pr.camera_embed} vectors, the call has views {view0}..{view0 + n}")
+        tab = cam[:, None, None, :].expand(n, F, L, C)
+        if pe is not None:
+            tab = tab + pe[None, None, :, :]
+        return tab.reshape(n * F * L, C).to(self.ops.act_dtype).contiguous(), 1
 
     # ------------------------------------------------------------------ forward pieces
     def _resnet(self, x, B2, H, W, pk, semb, rb_rows):
@@ -460,12 +520,18 @@ class MVUNetMotionModel(nn.Module):
         h = ops.gemm(h, pk.pin[0], pk.pin[1])
         # attn1: multi-view self-attention (+ first-frame attention)
         n1 = ops.layer_norm(h, pk.n1[0], pk.n1[1], 1e-5)
-        a, ai, _ = self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=pk.i2v)
-        if pk.i2v:
-            a = ops.gemm(ai, pk.oi2v[0], pk.oi2v[1], residual=a)          # main + to_out_i2v(i2v)
-        h = ops.gemm(a, pk.o1[0], pk.o1[1], residual=h)
+        h = self._self_attention(n1, h, pk, V, n, F, L)
         # attn2: text + IP-Adapter cross-attention, K/V projected once per video
         n2 = ops.layer_norm(h, pk.n2[0], pk.n2[1], 1e-5)
+        h = self._cross_attention(n2, h, pk, text_rows, ip_rows, T, B2, F, L)
+        h = self._ff(h, pk.ff)
+        return ops.gemm(h, pk.pout[0], pk.pout[1], residual=x)
+
+    def _cross_attention(self, n2, residual, pk, text_rows, ip_rows, T, B2, F, L):
+        """IPAdapter processor (attention_processor.py:169-298) on normalised tokens ``n2``: text attention plus, per adapter,
+        ``scale`` x image-token attention accumulated into the same buffer, then ``to_out`` (+ ``residual`` if given)."""
+        ops = self.ops
+        C = n2.shape[1]
         q2 = ops.gemm(n2, pk.q2)
         kvt = ops.gemm(text_rows, pk.kv_text)
         qc = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
@@ -474,42 +540,65 @@ class MVUNetMotionModel(nn.Module):
             kvi = ops.gemm(ipr, w)
             ops.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), B2, pk.heads, L, nt,
                            out=ca, out_scale=scale, accumulate=True)
-        h = ops.gemm(ca, pk.o2[0], pk.o2[1], residual=h)
-        h = self._ff(h, pk.ff)
-        return ops.gemm(h, pk.pout[0], pk.pout[1], residual=x)
+        return ops.gemm(ca, pk.o2[0], pk.o2[1], residual=residual)
+
+    def _self_attention(self, n1, residual, pk, V, n, F, L):
+        """MVDream(I2V) processor (attention_processor.py:39-126, 325-445) on normalised tokens ``n1``."""
+        ops = self.ops
+        C = n1.shape[1]
+        a, ai, _ = self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=pk.i2v)
+        if pk.i2v:
+            a = ops.gemm(ai, pk.oi2v[0], pk.oi2v[1], residual=a)          # main + to_out_i2v(i2v)
+        return ops.gemm(a, pk.o1[0], pk.o1[1], residual=residual)
+
+    def _motion_attn(self, h, nt, ns, nimg, a, V, n, F, L):
+        """SpatioTemporalI2V processor (attention_processor.py:541-723) + the block's residual: ``nt`` / ``ns`` / ``nimg`` are the
+        inputs of the temporal, spatial and first-frame-image branches (normalised tokens with their encodings); returns
+        ``h + ct * temporal + cs * spatial + ci * image`` with the merge coefficients of the processor."""
+        ops = self.ops
+        C = nt.shape[1]
+        ct, cs, ci = a.coef
+
+        def temporal_branch(nt=nt, a=a):
+            qkv = ops.gemm(nt, a.qkv)
+            return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
+        if a.spatial:
+            # the temporal branch is independent of the multi-view one: it runs while the K|V gather is in flight
+            asp, _, at = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False, overlap=temporal_branch)
+        else:
+            at = temporal_branch()
+        out = ops.gemm(at, a.o[0], a.o[1], residual=h, alpha=ct, beta=1.0)
+        if a.spatial:
+            out = ops.gemm(asp, a.osp[0], a.osp[1], residual=out, alpha=cs, beta=1.0)
+        if a.image:
+            # per-view first-frame attention (:672-698): every image attends to frame 0 of its own video
+            kvq = ops.gemm(nimg, a.qkv_img)
+            qm = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
+            k0 = RowMap(gdiv=F, ga=F * L, gb=0, seg_len=L, seg_stride=0)
+            ai = ops.flash_attn(kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C], qm, k0, V * F, a.heads, L, L)
+            out = ops.gemm(ai, a.oimg[0], a.oimg[1], residual=out, alpha=ci, beta=1.0)
+        return out
 
     def _motion(self, x, V, n, F, H, W, pk):
         ops, g = self.ops, self.config.norm_num_groups
         L, C = H * W, x.shape[1]
         h = ops.group_norm(x, V, F * L, pk.norm[0], pk.norm[1], g, 1e-6, False)     # 3-D GroupNorm per video
         h = ops.gemm(h, pk.pin[0], pk.pin[1])
+        par = self.parallel
+        view0 = par.view_rank * n if (par is not None and par.world > 1) else 0
         for a in pk.attns:
             pe_t = a.pe_t[:F]
-            if a.spatial:
-                if a.spatial_pe:
-                    nt, ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L, pe2=self._pe_spatial(C, H, W), pe2_div=1, two=True)
+            ln = lambda **kw: ops.layer_norm(h, a.n[0], a.n[1], 1e-5, **kw)
+            if a.block_pe:                     # the block adds the temporal encoding to what every branch reads
+                nt = ns = nimg = ln(pe1=pe_t, pe1_div=L)
+            else:                              # the processor adds it to the temporal branch only (:583-584)
+                if a.spatial_pe and not a.camera_pe and a.proc.spatial_encoding_type == "sinusoid":
+                    pe_s, div_s = self._pe_spatial(C, H, W), 1
                 else:
-                    nt = ns = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L) if a.block_pe else ops.layer_norm(h, a.n[0], a.n[1], 1e-5)
-            else:
-                nt = ops.layer_norm(h, a.n[0], a.n[1], 1e-5, pe1=pe_t, pe1_div=L)
-            def temporal_branch(nt=nt, a=a):
-                qkv = ops.gemm(nt, a.qkv)
-                return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
-            if a.spatial:
-                # the temporal branch is independent of the multi-view one: it runs while the K|V gather is in flight
-                asp, _, at = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False, overlap=temporal_branch)
-            else:
-                at = temporal_branch()
-            if a.spatial:
-                al = a.alpha
-                if al is None:                       # plain sum (use_alpha_blender = False)
-                    t1 = ops.gemm(at, a.o[0], a.o[1], residual=h)
-                    h = ops.gemm(asp, a.osp[0], a.osp[1], residual=t1)
-                else:                                # sigma(m) * spatial + (1 - sigma(m)) * temporal, + residual
-                    t1 = ops.gemm(at, a.o[0], a.o[1], residual=h, alpha=1.0 - al, beta=1.0)
-                    h = ops.gemm(asp, a.osp[0], a.osp[1], residual=t1, alpha=al, beta=1.0)
-            else:
-                h = ops.gemm(at, a.o[0], a.o[1], residual=h)
+                    pe_s, div_s = self._pe_spatial_general(a, C, H, W, n, F, view0)
+                nt, ns = ln(pe1=pe_t, pe1_div=L, pe2=pe_s, pe2_div=div_s, two=True)
+                nimg = ln() if a.image else None
+            h = self._motion_attn(h, nt, ns, nimg, a, V, n, F, L)
         h = self._ff(h, pk.ff)
         return ops.gemm(h, pk.pout[0], pk.pout[1], residual=x)
 
@@ -549,6 +638,7 @@ class MVUNetMotionModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    @on_model_device
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], encoder_hidden_states: torch.Tensor,
                 timestep_cond: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 cross_attention_kwargs: Optional[Dict[str, Any]] = None, added_cond_kwargs: Optional[Dict[str, torch.Tensor]] = None,
@@ -569,8 +659,8 @@ class MVUNetMotionModel(nn.Module):
         if V % n != 0:
             raise AssertionError("[UNet] input batch size must be dividable by the processors' num_views!")
         nlev = len(cfg.block_out_channels)
-        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
-            raise ValueError(f"latent size {(H, W)} must be a multiple of {1 << (nlev - 1)}")
+        if min(H, W) < (1 << (nlev - 1)):
+            raise ValueError(f"latent size {(H, W)} is smaller than the {1 << (nlev - 1)}x total down-sampling")
         if F > cfg.motion_max_seq_length:
             raise ValueError(f"num_frames {F} exceeds motion_max_seq_length {cfg.motion_max_seq_length}")
         P = self._packed if self._packed is not None else self._pack()
@@ -638,6 +728,7 @@ class MVUNetMotionModel(nn.Module):
         x = ops.gemm(ops.im2col_in(sample), P.conv_in[0], P.conv_in[1])
         h_, w_ = H, W
         skips = [x]
+        sizes = [(H, W)]                  # feature-map size per level: the forced upsample sizes of :690-698, 831-837
         for pk in P.down:
             for j, rp in enumerate(pk.resnets):
                 x = self._resnet(x, B2, h_, w_, rp, semb, rb_rows)
@@ -648,11 +739,13 @@ class MVUNetMotionModel(nn.Module):
             if pk.down is not None:
                 x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.down[0], pk.down[1], stride=2)
                 skips.append(x)
+                sizes.append((h_, w_))
         pk = P.mid
         x = self._resnet(x, B2, h_, w_, pk.resnets[0], semb, rb_rows)
         x = self._t2d(x, V, n, F, h_, w_, pk.t2d[0], text_rows, ip_rows, T)
         x = self._motion(x, V, n, F, h_, w_, pk.motion[0])
         x = self._resnet(x, B2, h_, w_, pk.resnets[1], semb, rb_rows)
+        lvl = len(sizes) - 1
         for blk, pk in zip(self.up_blocks, P.up):
             for j, rp in enumerate(pk.resnets):
                 x = ops.concat(x, skips.pop())
@@ -661,7 +754,10 @@ class MVUNetMotionModel(nn.Module):
                     x = self._t2d(x, V, n, F, h_, w_, pk.t2d[j], text_rows, ip_rows, T)
                 x = self._motion(x, V, n, F, h_, w_, pk.motion[j])
             if pk.up is not None:
-                x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.up[0], pk.up[1], up2x=True)
+                # the reference passes the next skip's size whenever a latent side is not a multiple of 2^(levels-1);
+                # when it is, that size is the plain 2x, so always naming it is the same arithmetic
+                lvl -= 1
+                x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.up[0], pk.up[1], up2x=True, up_size=sizes[lvl])
         x = ops.group_norm(x, B2, h_ * w_, P.norm_out[0], P.norm_out[1], cfg.norm_num_groups, cfg.norm_eps, True)
         x, _, _ = ops.conv3x3(x, B2, h_, w_, P.conv_out[0], P.conv_out[1])
         out_dtype = sample.dtype if sample.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32

@@ -27,6 +27,9 @@ from typing import Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
+from .denoise import randn_like_reference
+from .hip_ops import on_model_device
+
 
 @dataclass
 class VAEConfig:
@@ -260,6 +263,7 @@ class AutoencoderKLDecoder(_VAEHalf):
         return P
 
     @torch.no_grad()
+    @on_model_device
     def decode(self, z: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """AutoencoderKL.decode(z).sample for z [B, 4, h, w] (any float dtype) -> fp32 image [B, 3, 8h, 8w];
         ``scale`` multiplies z first (decode_latents passes 1 / scaling_factor)."""
@@ -340,6 +344,7 @@ class AutoencoderKLEncoder(_VAEHalf):
         return y.reshape(B, Ho, Wo, Co).flip(1, 2).reshape(B * Ho * Wo, Co).contiguous(), Ho, Wo
 
     @torch.no_grad()
+    @on_model_device
     def encode(self, images: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """AutoencoderKL.encode(x).latent_dist for x [B, 3, H, W] in [-1, 1]: (mean, logvar) fp32 [B, 4, H/8, W/8], logvar
         clamped to [-30, 20] as DiagonalGaussianDistribution does."""
@@ -371,5 +376,5 @@ class AutoencoderKLEncoder(_VAEHalf):
     def encode_latents(self, images: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """pipeline.py:556-560: ``vae.encode(x).latent_dist.sample() * scaling_factor`` -> [B, 4, H/8, W/8] fp32."""
         mean, logvar = self.encode(images)
-        noise = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
+        noise = randn_like_reference(mean.shape, generator, mean.device, mean.dtype)
         return (mean + torch.exp(0.5 * logvar) * noise) * self.config.scaling_factor

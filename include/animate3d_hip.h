@@ -93,7 +93,9 @@ int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const v
 /* 3x3 convolution, padding 1, NHWC, as an implicit GEMM (K = 9*Cin):
  *   Y[b, yo, xo, co] = bias[co] + rowbias[(row) / rb_div][co] + R[...]
  *                      + sum_{ky,kx,ci} X[b, yo*stride+ky-1, xo*stride+kx-1, ci] * Wp[co][ky][kx][ci]
- * up2x != 0 first applies nearest 2x upsampling to X (diffusers Upsample2D) by addressing.
+ * up2x bit 0 first applies nearest 2x upsampling to X (diffusers Upsample2D) by addressing; bits 1 / 2 crop the upsampled
+ * image by its last row / column, which is what F.interpolate(size = (2H-1, 2W-1), mode = "nearest") yields: the forced
+ * upsample size of latents that are not multiples of 8 (unet_motion_mv_model.py:690-698, 831-837).
  * Replaces cuDNN conv2d in diffusers ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D and
  * conv_out (unet_motion_mv_model.py:271,859).  Requires Cin % 64 == 0, Cout % 4 == 0. */
 int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,

@@ -67,6 +67,11 @@ class UNetConfig:
     motion_spatial_attn: bool = True
     motion_use_spatial_encoding: bool = True
     motion_use_alpha_blender: bool = True
+    # switches the released configs leave off (motion_module_attn_cfg.image_attn / spatial_attn.attn_cfg.*, inference.yaml:12-24)
+    motion_image_attn: bool = False
+    motion_use_camera_encoding: bool = False
+    motion_spatial_encoding_type: str = "sinusoid"       # or "learnable"
+    motion_camera_encoding_type: str = "sinusoid"        # or "learnable"
     encoder_hid_dim_type: Optional[str] = "ip_image_proj"
 
     def to_dict(self):
@@ -179,21 +184,64 @@ class AlphaBlender(nn.Module):
         return a * x_spatial + (1.0 - a) * x_temporal
 
 
+class SoftmaxAlphaBlender(nn.Module):
+    """attention_processor.py:727-744: three-way blend, softmax over ``mix_factor``; argument order (spatial, temporal, image)."""
+
+    def __init__(self, alphas=(0.0, 0.0, 0.0)):
+        super().__init__()
+        self.mix_factor = nn.Parameter(torch.tensor(list(alphas), dtype=torch.float32))
+
+    def forward(self, x_spatial, x_temporal, x_image):
+        a = torch.softmax(self.mix_factor, dim=0).to(x_spatial.dtype)
+        return x_spatial * a[0] + x_temporal * a[1] + x_image * a[2]
+
+
+class LearnedPositionalEncoding2D(nn.Module):
+    """embeddings.py:99-157: channels [0, num_feats) = col_embed(x), [num_feats, 2 num_feats) = row_embed(y)."""
+
+    def __init__(self, num_feats: int, row_num_embed: int = 50, col_num_embed: int = 50):
+        super().__init__()
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def table(self, h: int, w: int) -> torch.Tensor:
+        """[h, w, 2 num_feats]"""
+        xe = self.col_embed.weight[:w][None, :, :].expand(h, w, -1)
+        ye = self.row_embed.weight[:h][:, None, :].expand(h, w, -1)
+        return torch.cat([xe, ye], dim=-1)
+
+
+class LabelEmbedding(nn.Module):
+    """diffusers LabelEmbedding(num_classes, hidden_size, dropout_prob = 0): a plain table (attention_processor.py:508)."""
+
+    def __init__(self, num_classes: int, hidden_size: int):
+        super().__init__()
+        self.embedding_table = nn.Embedding(num_classes, hidden_size)
+
+
 # --------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------
 def _sdpa(q, k, v, heads: int):
     """softmax(q k^T / sqrt(d)) v on [B, L, H*D] tensors -> [B, Lq, H*D]  (what
-    xformers.ops.memory_efficient_attention computes at attention_processor.py:103 etc.)."""
+    xformers.ops.memory_efficient_attention computes at attention_processor.py:103 etc.).  The score matrix is
+    materialised per batch chunk (<= 2^28 scores at a time) so that full-size configurations fit in host memory; the
+    arithmetic per batch element does not depend on the chunking."""
     b, lq, c = q.shape
     d = c // heads
-    qh = q.reshape(b, lq, heads, d).transpose(1, 2)
-    kh = k.reshape(b, k.shape[1], heads, d).transpose(1, 2)
-    vh = v.reshape(b, v.shape[1], heads, d).transpose(1, 2)
-    s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
-    p = torch.softmax(s, dim=-1)
-    o = torch.matmul(p, vh)
-    return o.transpose(1, 2).reshape(b, lq, c)
+    lk = k.shape[1]
+    step = max(1, (1 << 28) // max(1, heads * lq * lk))
+    outs = []
+    for i in range(0, b, step):
+        qh = q[i:i + step].reshape(-1, lq, heads, d).transpose(1, 2)
+        kh = k[i:i + step].reshape(-1, lk, heads, d).transpose(1, 2)
+        vh = v[i:i + step].reshape(-1, lk, heads, d).transpose(1, 2)
+        s_ = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
+        p = torch.softmax(s_, dim=-1)
+        outs.append(torch.matmul(p, vh).transpose(1, 2).reshape(-1, lq, c))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 class Attention(nn.Module):
@@ -316,19 +364,25 @@ class IPAdapterProc(nn.Module):
 
 
 class SpatioTemporalProc(nn.Module):
-    """Restates SpatioTemporalI2VXFormersAttnProcessor (attention_processor.py:448-723) for the
-    released switch set: spatial attention on, sinusoid 2-D PE, camera encoding off, image
-    attention off, alpha blender on/off.  Input is ``[(b n h w), f, c]``."""
+    """Restates SpatioTemporalI2VXFormersAttnProcessor (attention_processor.py:448-723): temporal attention, optional
+    multi-view spatial attention (2-D positional encoding sinusoid / learnable, optional per-view camera encoding sinusoid /
+    learnable), optional first-frame image attention, merged by sum, AlphaBlender (two branches) or SoftmaxAlphaBlender
+    (three).  Input is ``[(b n h w), f, c]``."""
 
     def __init__(self, hidden_size: int, feature_size, num_views: int, num_frames: int,
                  spatial_attn: bool = True, use_spatial_encoding: bool = True, use_alpha_blender: bool = True,
-                 max_seq_length: int = 32):
+                 max_seq_length: int = 32, image_attn: bool = False, use_camera_encoding: bool = False,
+                 spatial_encoding_type: str = "sinusoid", camera_encoding_type: str = "sinusoid",
+                 embed_size: Optional[int] = None):
         super().__init__()
         self.hidden_size = hidden_size
         self.feature_hw = (feature_size, feature_size) if isinstance(feature_size, int) else tuple(feature_size)
         self.num_views, self.num_frames = num_views, num_frames
         self.use_spatial_attn = spatial_attn
         self.use_spatial_encoding = use_spatial_encoding
+        self.use_camera_encoding = use_camera_encoding
+        self.spatial_encoding_type, self.camera_encoding_type = spatial_encoding_type, camera_encoding_type
+        self.use_image_attn = image_attn
         self.use_alpha_blender = use_alpha_blender
         if spatial_attn:
             self.to_q_sp = nn.Linear(hidden_size, hidden_size, bias=False)     # :490-493
@@ -337,37 +391,88 @@ class SpatioTemporalProc(nn.Module):
             self.to_out_sp = nn.Linear(hidden_size, hidden_size, bias=True)
             if use_spatial_encoding:
                 self.time_pos_embed = TimePosEmbed(hidden_size, max_seq_length)  # :497
-            if not use_alpha_blender:
-                nn.init.zeros_(self.to_out_sp.weight)                          # :527-531
-                nn.init.zeros_(self.to_out_sp.bias)
-            else:
-                self.alpha_blender = AlphaBlender(0.0)                         # :537
+                if spatial_encoding_type == "learnable":                          # :502-503 (table size = constructor feature_size)
+                    es = embed_size if embed_size is not None else max(self.feature_hw)
+                    self.spatial_pos_embed = LearnedPositionalEncoding2D(hidden_size // 2, es, es)
+                elif spatial_encoding_type != "sinusoid":
+                    raise ValueError(f"Spatial encoding type {spatial_encoding_type} is not supported yet!")
+            if use_camera_encoding:
+                self.time_pos_embed = TimePosEmbed(hidden_size, max_seq_length)  # :508
+                if camera_encoding_type == "learnable":
+                    self.camera_embed = LabelEmbedding(num_views, hidden_size)   # :510
+                elif camera_encoding_type == "sinusoid":
+                    self.camera_embed = TimePosEmbed(hidden_size, num_views)     # :512
+        if image_attn:                                                            # :514-518
+            self.to_q_i2v = nn.Linear(hidden_size, hidden_size, bias=False)
+            self.to_k_i2v = nn.Linear(hidden_size, hidden_size, bias=False)
+            self.to_v_i2v = nn.Linear(hidden_size, hidden_size, bias=False)
+            self.to_out_i2v = nn.Linear(hidden_size, hidden_size, bias=True)
+        num_attn = 1 + int(spatial_attn) + int(image_attn)
+        if not use_alpha_blender:                                                 # :527-536: zero-initialised extra branches
+            for m in ([self.to_out_sp] if spatial_attn else []) + ([self.to_out_i2v] if image_attn else []):
+                nn.init.zeros_(m.weight)
+                nn.init.zeros_(m.bias)
+        elif num_attn == 2:
+            self.alpha_blender = AlphaBlender(0.0)                                # :537
+        elif num_attn == 3:
+            self.alpha_blender = SoftmaxAlphaBlender((0.0, 0.0, 0.0))             # :539
 
     def forward(self, attn: Attention, x, encoder_hidden_states=None, attention_mask=None, **kw):
         n, f = self.num_views, self.num_frames
         fh, fw = self.feature_hw
         assert encoder_hidden_states is None
+        c = x.shape[-1]
         if self.use_spatial_attn:
             s = n * fh * fw
-            bl, ff, c = x.shape
+            bl, ff, _ = x.shape
             assert ff == f and bl % s == 0
             b = bl // s
             sp = x.reshape(b, s, f, c).permute(0, 2, 1, 3).reshape(b * f, s, c)       # :557
-            if self.use_spatial_encoding:
-                pe = sine_pos_2d(c // 2, fh, fw).to(x.dtype)                          # :561-563
-                sp = sp + pe.permute(1, 2, 0).reshape(1, 1, fh * fw, c).expand(1, n, -1, -1).reshape(1, s, c)
-                x = self.time_pos_embed(x)                                            # :583-584
+            if self.use_spatial_encoding:                                             # :559-563
+                if self.spatial_encoding_type == "learnable":
+                    pe = self.spatial_pos_embed.table(fh, fw).to(x.dtype).reshape(fh * fw, c)
+                else:
+                    pe = sine_pos_2d(c // 2, fh, fw).to(x.dtype).permute(1, 2, 0).reshape(fh * fw, c)
+                sp = sp + pe.reshape(1, 1, fh * fw, c).expand(1, n, -1, -1).reshape(1, s, c)
+            if self.use_camera_encoding:                                              # :565-575: one vector per view
+                cam = self.camera_embed.embedding_table.weight[:n] if self.camera_encoding_type == "learnable" \
+                    else self.camera_embed.pe[0, :n]
+                sp = sp + cam.to(x.dtype).reshape(1, n, 1, c).expand(1, n, fh * fw, c).reshape(1, s, c)
+        if self.use_image_attn:                                                       # :578-580 (before the time encoding)
+            li = fh * fw
+            img = x.reshape(-1, li, f, c).permute(0, 2, 1, 3)                         # [(b n), f, l, c]
+        if self.use_spatial_attn and (self.use_spatial_encoding or self.use_camera_encoding):
+            x = self.time_pos_embed(x)                                                # :583-584
         # temporal (AnimateDiff) branch :619-641, unfused softmax in the reference
         t = _sdpa(attn.to_q(x), attn.to_k(x), attn.to_v(x), attn.heads)
         t = attn.to_out[0](t)
-        if not self.use_spatial_attn:
-            return t
-        so = _sdpa(self.to_q_sp(sp), self.to_k_sp(sp), self.to_v_sp(sp), attn.heads)  # :645-660
-        so = self.to_out_sp(so)                                                       # :666
-        so = so.reshape(b, f, s, c).permute(0, 2, 1, 3).reshape(b * s, f, c)          # :669
-        if self.use_alpha_blender:
+        so = io = None
+        if self.use_spatial_attn:
+            so = _sdpa(self.to_q_sp(sp), self.to_k_sp(sp), self.to_v_sp(sp), attn.heads)  # :645-660
+            so = self.to_out_sp(so)                                                       # :666
+            so = so.reshape(b, f, s, c).permute(0, 2, 1, 3).reshape(b * s, f, c)          # :669
+        if self.use_image_attn:                                                       # :672-698: K/V of frame 0, per view
+            v_, _, li, _ = img.shape
+            q_i = self.to_q_i2v(img.reshape(v_ * f, li, c))
+            first = img[:, 0]                                                         # [(b n), l, c]
+            k_i = self.to_k_i2v(first)[:, None].expand(v_, f, li, c).reshape(v_ * f, li, c)
+            v_i = self.to_v_i2v(first)[:, None].expand(v_, f, li, c).reshape(v_ * f, li, c)
+            io = self.to_out_i2v(_sdpa(q_i, k_i, v_i, attn.heads))
+            io = io.reshape(v_, f, li, c).permute(0, 2, 1, 3).reshape(v_ * li, f, c)  # :698
+        if not self.use_alpha_blender:                                                # :700-706
+            out = t
+            if so is not None:
+                out = out + so
+            if io is not None:
+                out = out + io
+            return out
+        if so is not None and io is None:
             return self.alpha_blender(so, t)                                          # :709
-        return t + so                                                                 # :703
+        if io is not None and so is None:
+            return self.alpha_blender(io, t)                                          # :711
+        if so is not None and io is not None:
+            return self.alpha_blender(so, t, io)                                      # :713
+        return t
 
 
 def _bnf_to_bf_nl(x, n, f):
@@ -643,11 +748,15 @@ class MVUNetMotionModelRef(nn.Module):
     def _install_processors(self, latent_hw):
         cfg, n, f = self.cfg, self.num_views, self.num_frames
         nlev = len(cfg.block_out_channels)
-        sizes = [(latent_hw[0] >> i, latent_hw[1] >> i) for i in range(nlev)]
+        sizes = [tuple(latent_hw)]            # feature map per level: each Downsample2D (3x3, stride 2, pad 1) gives ceil(h / 2)
+        for _ in range(nlev - 1):
+            sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
 
-        def motion(c, hw):
+        def motion(c, hw, es):
             return SpatioTemporalProc(c, hw, n, f, cfg.motion_spatial_attn, cfg.motion_use_spatial_encoding,
-                                      cfg.motion_use_alpha_blender, cfg.motion_max_seq_length)
+                                      cfg.motion_use_alpha_blender, cfg.motion_max_seq_length, cfg.motion_image_attn,
+                                      cfg.motion_use_camera_encoding, cfg.motion_spatial_encoding_type,
+                                      cfg.motion_camera_encoding_type, embed_size=es)
 
         def t2d(tr, c):
             blk = tr.transformer_blocks[0]
@@ -662,11 +771,12 @@ class MVUNetMotionModelRef(nn.Module):
             blk.attn1.set_processor(p)
             blk.attn2.set_processor(IPAdapterProc(c, cfg.cross_attention_dim, (cfg.ip_num_tokens,), cfg.ip_scale))
 
-        def mm(m, c, hw):
+        def mm(m, c, hw, lvl):
             blk = m.transformer_blocks[0]
-            blk.attn1.set_processor(motion(c, hw))
-            blk.attn2.set_processor(motion(c, hw))
-            if not (cfg.motion_spatial_attn and cfg.motion_use_spatial_encoding):      # inference.py:176-178: pos_embed is kept
+            es = max(max(hw), (cfg.sample_size or max(hw)) >> lvl)                    # learnable-PE table rows (inference.py:93-105)
+            blk.attn1.set_processor(motion(c, hw, es))
+            blk.attn2.set_processor(motion(c, hw, es))
+            if not (cfg.motion_spatial_attn and (cfg.motion_use_spatial_encoding or cfg.motion_use_camera_encoding)):   # inference.py:176-178: pos_embed is kept
                 table = sinusoidal_pos_1d(c, cfg.motion_max_seq_length)
                 blk.pos_embed = lambda t, table=table: t + table[:, : t.shape[1]].to(t)
 
@@ -675,16 +785,16 @@ class MVUNetMotionModelRef(nn.Module):
             for j in range(len(blk.resnets)):
                 if blk.has_cross_attention:
                     t2d(blk.attentions[j], c)
-                mm(blk.motion_modules[j], c, sizes[i])
+                mm(blk.motion_modules[j], c, sizes[i], i)
         c = cfg.block_out_channels[-1]
         t2d(self.mid_block.attentions[0], c)
-        mm(self.mid_block.motion_modules[0], c, sizes[-1])
+        mm(self.mid_block.motion_modules[0], c, sizes[-1], nlev - 1)
         for i, blk in enumerate(self.up_blocks):
             c = list(reversed(cfg.block_out_channels))[i]
             for j in range(len(blk.resnets)):
                 if blk.has_cross_attention:
                     t2d(blk.attentions[j], c)
-                mm(blk.motion_modules[j], c, sizes[-(i + 1)])
+                mm(blk.motion_modules[j], c, sizes[-(i + 1)], nlev - 1 - i)
 
     @torch.no_grad()
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, camera=None,

@@ -30,6 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import unet_ref as O  # noqa: E402
+from tests.golden.seeded import fill_named, seeded_tensor  # noqa: E402
 
 REF = "/root/reference"
 
@@ -170,6 +171,69 @@ def main():
             out[f"{tag}/y"] = proc(attn, x).numpy().copy()
             save_sd(f"{tag}/attn", attn)
             save_sd(f"{tag}/proc", proc)
+
+        # ---- a9, switch sets the released configs leave off (name-seeded weights, tests/golden/seeded.py): first-frame image
+        #      branch with the 3-way SoftmaxAlphaBlender / 2-way blend / plain sum, camera encodings, learnable 2-D encoding,
+        #      spatial attention without any encoding.  The learnable camera branch calls .cuda() (attention_processor.py:568):
+        #      made a no-op here.
+        def st_case(tag, C_, H_, n_, f_, fs_, blender, spatial=True, image=False, enc=True, enc_type="sinusoid", cam=False,
+                    cam_type="sinusoid", scale=0.2):
+            spatial_cfg = NS(enabled=spatial, attn_cfg=NS(use_spatial_encoding=enc, spatial_encoding_type=enc_type,
+                                                          use_camera_encoding=cam, camera_encoding_type=cam_type))
+            attn = fill_named(O.Attention(C_, None, H_, C_ // H_), f"{tag}/attn", scale)
+            proc = RP.SpatioTemporalI2VXFormersAttnProcessor(hidden_size=C_, feature_size=fs_, num_views=n_, num_frames=f_,
+                                                             spatial_attn=spatial_cfg, image_attn=NS(enabled=image),
+                                                             use_alpha_blender=blender)
+            fill_named(proc, f"{tag}/proc", scale)
+            x = seeded_tensor(f"{tag}/x", (b * n_ * fs_ * fs_, f_, C_))
+            out[f"{tag}/x"] = x.numpy().copy()
+            out[f"{tag}/y"] = proc(attn, x).numpy().copy()
+
+        orig_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            st_case("st_img3", C, H, n, f, fs, True, image=True)
+            st_case("st_imgonly", C, H, n, f, fs, True, spatial=False, image=True)
+            st_case("st_sum3", C, H, n, f, fs, False, image=True)
+            st_case("st_cam_sin", C, H, n, f, fs, True, cam=True, cam_type="sinusoid")
+            st_case("st_cam_learn", C, H, n, f, fs, True, cam=True, cam_type="learnable")
+            st_case("st_camonly", C, H, n, f, fs, True, enc=False, cam=True, cam_type="learnable")
+            st_case("st_learn2d", C, H, n, f, fs, True, enc_type="learnable")
+            st_case("st_noenc", C, H, n, f, fs, True, enc=False)
+        finally:
+            torch.Tensor.cuda = orig_cuda
+
+        # ---- real head dims (D = 40: C = 320, D = 80: C = 640; 8 heads) at a tiny token geometry: vectors the HIP kernels can
+        #      replay directly (tests/test_reference_vectors_gpu.py).  Weights are name-seeded, only x / y are stored.
+        n2, f2, fs2 = 2, 2, 4
+        L2 = fs2 * fs2
+        for C_ in (320, 640):
+            tag = f"mvi2v_c{C_}"
+            attn = fill_named(O.Attention(C_, None, 8, C_ // 8), f"{tag}/attn", C_ ** -0.5)
+            proc = fill_named(RP.MVDreamI2VXFormersAttnProcessor(hidden_size=C_, num_views=n2, num_frames=f2), f"{tag}/proc", C_ ** -0.5)
+            x = seeded_tensor(f"{tag}/x", (b * n2 * f2, L2, C_))
+            out[f"{tag}/x"], out[f"{tag}/y"] = x.numpy().copy(), proc(attn, x).numpy().copy()
+
+            tag = f"ip_c{C_}"
+            attn = fill_named(O.Attention(C_, 768, 8, C_ // 8), f"{tag}/attn", 0.04)
+            proc = fill_named(RP.IPAdapterXFormersAttnProcessor(hidden_size=C_, cross_attention_dim=768, num_tokens=(4,), scale=0.7),
+                              f"{tag}/proc", 0.04)
+            x = seeded_tensor(f"{tag}/x", (b * n2 * f2, L2, C_))
+            text, ip = seeded_tensor(f"{tag}/text", (b * n2 * f2, 77, 768)), seeded_tensor(f"{tag}/ip", (b * n2 * f2, 4, 768))
+            # the product projects text / IP tokens once per VIDEO: make the per-frame copies identical, as the UNet does (:754,763)
+            text = text.reshape(b * n2, f2, 77, 768)[:, :1].expand(-1, f2, -1, -1).reshape(b * n2 * f2, 77, 768).contiguous()
+            ip = ip.reshape(b * n2, f2, 4, 768)[:, :1].expand(-1, f2, -1, -1).reshape(b * n2 * f2, 4, 768).contiguous()
+            out[f"{tag}/x"], out[f"{tag}/text"], out[f"{tag}/ip"] = x.numpy().copy(), text[::f2].numpy().copy(), ip[::f2].numpy().copy()
+            out[f"{tag}/y"] = proc(attn, x, encoder_hidden_states=(text, [ip])).numpy().copy()
+
+            st_case(f"st_c{C_}", C_, 8, n2, f2, fs2, True, scale=C_ ** -0.5)
+            st_case(f"st_img3_c{C_}", C_, 8, n2, f2, fs2, True, image=True, scale=C_ ** -0.5)
+        out["meta_real"] = np.array([b, n2, f2, fs2], dtype=np.int64)
+
+        # ---- embeddings.LearnedPositionalEncoding2D (embeddings.py:99-157) on a non-square map
+        from animatediff.models.embeddings import LearnedPositionalEncoding2D
+        lp = fill_named(LearnedPositionalEncoding2D(C // 2, row_num_embed=6, col_num_embed=7), "learned2d", 1.0)
+        out["learned2d/3x5"] = lp._forward(torch.zeros(1, 3, 5))[0].numpy().copy()
 
         # ---- pipeline.get_camera (pipeline.py:127-190): torch-only helpers, extracted by exec of
         #      just those three function definitions (the module itself imports diffusers/torchvision).

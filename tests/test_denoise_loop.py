@@ -187,3 +187,42 @@ def test_denoise_loop_matches_oracle_loop():
     rel = ((got.cpu() - want).norm() / want.norm()).item()
     print(f"[parity] 3-step denoise loop: rel_l2={rel:.3e}")
     assert rel <= 3e-2
+
+
+@pytest.mark.gpu
+def test_free_init_on_the_gpu_with_a_cpu_generator():
+    """pipeline.py:987-999 (FreeInit, on in the released config: inference.yaml:27-28) with the HIP UNet: 2 iterations x 2 DDIM
+    steps on the device, the re-noising drawn from a CPU generator (the diffusers idiom: ``randn_tensor`` draws on the
+    generator's device and moves — a CUDA-side draw would raise), against the oracle wrapper over the CPU oracle UNet fed by an
+    identically seeded generator.  The frequency mix itself (rocFFT vs CPU FFT) is compared on identical tensors first."""
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.denoise import denoise_free_init, free_init_filter, free_init_mix
+    from animate3d_amd.unet import MVUNetMotionModel
+    from oracle import unet_ref as O
+    g = torch.Generator().manual_seed(4)
+    a, b_ = torch.randn(2, 4, 15, 16, 16, generator=g), torch.randn(2, 4, 15, 16, 16, generator=g)
+    filt = free_init_filter((1, 4, 15, 16, 16))
+    d = (free_init_mix(a.cuda(), b_.cuda(), filt.cuda()).cpu() - free_init_mix(a, b_, filt)).abs().max().item()
+    print(f"[parity] FreeInit frequency mix, rocFFT vs CPU FFT: max |diff| {d:.3e}")
+    assert d <= 1e-5
+
+    arch = dict(block_out_channels=(320, 640), down_has_attn=(True, False), layers_per_block=1)
+    n, F, hw = 2, 4, (16, 16)
+    ocfg = O.UNetConfig(**arch)
+    ref = O.build_fast(ocfg, n, F, hw, seed=1)
+    hip = MVUNetMotionModel(UNetConfig(**arch), num_views=n, device="cuda")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(torch.bfloat16).eval()
+    inp = O.synthetic_inputs(ocfg, 2 * n, n, F, hw, seed=3, cfg_doubled=True)
+    g0 = torch.Generator().manual_seed(5)
+    first = 0.18215 * torch.randn(n, 4, 1, *hw, generator=g0)
+    latents = torch.cat([first, torch.randn(n, 4, F - 1, *hw, generator=g0)], dim=2)
+    args = dict(prompt_embeds=inp["encoder_hidden_states"], image_embeds=inp["added_cond_kwargs"]["image_embeds"], camera=inp["camera"][:n])
+    want = denoise_free_init_ref(ref, latents, first, num_iters=2, generator=torch.Generator().manual_seed(9), num_inference_steps=2, **args)
+    got = denoise_free_init(hip, latents.cuda(), first.cuda(), num_iters=2, generator=torch.Generator().manual_seed(9),
+                            num_inference_steps=2, **{k: v.cuda() for k, v in args.items()})
+    assert got.is_cuda and got.shape == want.shape and torch.isfinite(got).all()
+    assert torch.equal(got[:, :, 0].cpu(), first[:, :, 0])
+    rel = ((got.cpu() - want).norm() / want.norm()).item()
+    print(f"[parity] FreeInit 2 iterations x 2 DDIM steps, HIP vs oracle: rel_l2={rel:.3e}")
+    assert rel <= 3e-2

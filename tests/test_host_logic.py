@@ -63,6 +63,39 @@ def test_forward_cond_time_zero_and_tuple_return():
     assert not np.allclose(y.numpy(), model(**inp).sample.numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize("hw", [(12, 20), (9, 10), (8, 15)])
+def test_forced_upsample_sizes(hw):
+    """unet_motion_mv_model.py:690-698, 831-837: latents whose sides are not multiples of 8 — every upsampler is told the
+    size of the skip it has to meet (nearest interpolation to 2h - 1 = the 2x upsample minus its last row)."""
+    ocfg, ref, model = _pair(2, 2, hw)
+    inp = O.synthetic_inputs(ocfg, 2, 2, 2, hw, seed=9)
+    y_ref = ref(**inp).sample
+    y = model(**inp).sample
+    assert y.shape == y_ref.shape == (2, 4, 2, hw[0], hw[1])
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=2e-3, atol=2e-4)
+
+
+UNRELEASED_SWITCH_SETS = [
+    dict(motion_image_attn=True),                                          # 3-way SoftmaxAlphaBlender
+    dict(motion_image_attn=True, motion_use_alpha_blender=False),          # plain sum of three branches
+    dict(motion_image_attn=True, motion_spatial_attn=False),               # temporal + image, AlphaBlender(image, temporal)
+    dict(motion_use_camera_encoding=True, motion_camera_encoding_type="sinusoid"),
+    dict(motion_use_camera_encoding=True, motion_camera_encoding_type="learnable", motion_use_spatial_encoding=False),
+    dict(motion_spatial_encoding_type="learnable"),
+    dict(motion_use_spatial_encoding=False),                               # spatial attention, block-level temporal encoding
+    dict(motion_spatial_attn=False),                                       # vanilla AnimateDiff motion modules
+]
+
+
+@pytest.mark.parametrize("kw", UNRELEASED_SWITCH_SETS, ids=lambda kw: ",".join(f"{k[7:]}={v}" for k, v in kw.items()))
+def test_unreleased_motion_switch_sets(kw):
+    """attention_processor.py:514-535, 565-580, 672-713, 727-744; embeddings.py:99-157 (SURVEY §8 a9 beyond the released
+    configuration): the product's host logic against the oracle, whose processor is pinned on the same switch sets."""
+    ocfg, ref, model = _pair(2, 2, (8, 8), **kw)
+    inp = O.synthetic_inputs(ocfg, 2, 2, 2, (8, 8), seed=7)
+    np.testing.assert_allclose(model(**inp).sample.numpy(), ref(**inp).sample.numpy(), rtol=2e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("kw", [dict(mvdream_image_attn=False), dict(motion_use_alpha_blender=False)])
 def test_processor_switches(kw):
     ocfg, ref, model = _pair(2, 2, (8, 8), **kw)
@@ -173,6 +206,14 @@ def test_from_unet2d_copies_what_the_reference_copies():
         elif tag == "untouched":
             assert not torch.equal(got[k], a[k]) and not torch.equal(got[k], b[k]), k
     assert counts["unet"] == 768 and counts["adapter"] == 798 and counts["untouched"] == 4
+    # a plain 2-D UNet has no I2V keys: the branch is then initialised from the LOADED to_q (inference.py:161-165), not from
+    # the construction-time random one
+    class Plain:
+        def state_dict(self):
+            return {k: v for k, v in a.items() if "i2v" not in k}
+    m2 = MVUNetMotionModel.from_unet2d(Plain(), adapter, config=UNetConfig(**small), ops=TorchRefOps(), num_views=2).state_dict()
+    pre = "down_blocks.0.attentions.0.transformer_blocks.0.attn1."
+    assert torch.equal(m2[pre + "processor.to_q_i2v.weight"], a[pre + "to_q.weight"])
     # load_weights=False builds the topology only
     bare = MVUNetMotionModel.from_unet2d(unet2d, adapter, load_weights=False, config=UNetConfig(**small), ops=TorchRefOps(), num_views=2)
     assert not torch.equal(bare.state_dict()["conv_in.weight"], a["conv_in.weight"])

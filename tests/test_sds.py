@@ -80,3 +80,63 @@ def test_sds_batches_and_argument_checks():
         sds_recon_loss(stub_unet, lat, t[:1], text, emb, c2w, **kw)
     with pytest.raises(ValueError):
         sds_recon_loss(stub_unet, lat, t, text[:3], emb, c2w, **kw)
+
+
+@pytest.mark.gpu
+def test_sds_step_config5_over_the_hip_unet():
+    """BASELINE config 5: one 4D-SDS step (animatemv_guidance.py:391-507) over the HIP UNet at the reference's shape — b = 1,
+    4 views x 16 frames, 32 x 32 latent (256 px), everything cast to fp16 on the way in (:339-346), CFG batch in (text, uncond)
+    order — against the same function over the fp32 CPU oracle UNet with the same weights, noise and timestep.
+    Compared: the raw UNet output (bar 3e-2, the UNet's stated tolerance) and, at guidance scale 7.5, the reconstruction, the
+    loss and the gradient (the CFG combine eps_text + s (eps_text - eps_uncond) amplifies the UNet's rounding by ~ s, hence
+    the wider bars; at the reference's s = 100 only finiteness is asserted)."""
+    import os as _os
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.embeddings import get_camera
+    from animate3d_amd.unet import MVUNetMotionModel
+    from oracle import unet_ref as O
+    torch.set_num_threads(max(1, min(96, _os.cpu_count() or 1)))
+    n, F, hw, b = 4, 16, (32, 32), 1
+    ocfg = O.UNetConfig()
+    ref = O.build_fast(ocfg, n, F, hw, seed=0)
+    hip = MVUNetMotionModel(UNetConfig(), num_views=n, device="cuda")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.half().eval()
+    g = torch.Generator().manual_seed(2)
+    lat = 0.18215 * 4 * torch.randn(b * n * F, 4, *hw, generator=g)
+    noise = torch.randn(b, n, F - 1, 4, *hw, generator=g)
+    t = torch.tensor([500])
+    text = torch.randn(2 * b * n, 77, 768, generator=g)
+    emb = torch.randn(b * n, 1024, generator=g)
+    c2w = get_camera(n).reshape(n, 1, 4, 4).expand(n, F, 4, 4).reshape(b * n * F, 4, 4).clone()
+    seen = {}
+
+    def wrap(model, key):
+        def call(*a, **k):
+            out = model(*a, **k)
+            seen[key] = out.sample.detach().float().cpu()
+            return out
+        return call
+
+    kw = dict(n_view=n, n_frame=F, recon_std_rescale=0.5, noise=noise)
+    lr = lat.clone().requires_grad_(True)
+    loss_r, aux_r = sds_recon_loss(wrap(ref, "ref"), lr, t, text, emb, c2w, guidance_scale=7.5, **kw)
+    loss_r.backward()
+    lh = lat.clone().cuda().requires_grad_(True)
+    dev = lambda v: v.cuda()
+    loss_h, aux_h = sds_recon_loss(wrap(hip, "hip"), lh, dev(t), dev(text), dev(emb), dev(c2w), guidance_scale=7.5,
+                                   weights_dtype=torch.float16, **{**kw, "noise": dev(noise)})
+    loss_h.backward()
+    rel = lambda a, b_: ((a.float().cpu() - b_.float().cpu()).norm() / b_.float().cpu().norm()).item()
+    e_unet = rel(seen["hip"], seen["ref"])
+    e_rec, e_grad = rel(aux_h["latents_recon"], aux_r["latents_recon"]), rel(lh.grad, lr.grad)
+    e_loss = abs(loss_h.item() - loss_r.item()) / abs(loss_r.item())
+    print(f"[parity] SDS step config 5 (V=8, F=16, 32x32, fp16 in): UNet output rel_l2={e_unet:.3e}; s=7.5: recon {e_rec:.3e} "
+          f"grad {e_grad:.3e} loss {e_loss:.3e} (loss {loss_r.item():.4e})")
+    assert seen["hip"].shape == (2 * b * n, 4, F, *hw) and e_unet <= 3e-2
+    assert e_rec <= 1e-1 and e_grad <= 1e-1 and e_loss <= 5e-2
+    g6 = lh.grad.reshape(-1, F, *lh.shape[1:])
+    assert float(g6[:, 0].abs().max()) == 0.0
+    loss_100, aux_100 = sds_recon_loss(hip, lat.cuda(), dev(t), dev(text), dev(emb), dev(c2w), guidance_scale=100.0,
+                                       weights_dtype=torch.float16, **{**kw, "noise": dev(noise)})
+    assert torch.isfinite(loss_100) and torch.isfinite(aux_100["latents_recon"]).all()

@@ -97,6 +97,61 @@ def test_forward_parity_config4_geometry(models):
     assert torch.isfinite(y_hip).all() and e_or <= 3e-2, f"HIP vs fp32 oracle: {e_or:.3e}"
 
 
+SWITCH_SETS = [
+    dict(mvdream_image_attn=False),                                        # a7: MVDream processor without the I2V branch
+    dict(motion_use_alpha_blender=False),
+    dict(motion_spatial_attn=False),                                       # vanilla AnimateDiff motion modules
+    dict(motion_use_spatial_encoding=False),
+    dict(motion_image_attn=True),                                          # 3-way SoftmaxAlphaBlender
+    dict(motion_image_attn=True, motion_use_alpha_blender=False),
+    dict(motion_image_attn=True, motion_spatial_attn=False),
+    dict(motion_use_camera_encoding=True, motion_camera_encoding_type="sinusoid"),
+    dict(motion_use_camera_encoding=True, motion_camera_encoding_type="learnable", motion_use_spatial_encoding=False),
+    dict(motion_spatial_encoding_type="learnable"),
+]
+
+
+@pytest.mark.parametrize("kw", SWITCH_SETS, ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_switch_sets_on_the_hip_path(kw):
+    """Every processor switch of inference.yaml:9-24 / attention_processor.py:478-540 that the released configuration leaves
+    at its default, on the HIP kernels: two real-width levels (head dims 40 and 80, both with attention), against the fp32 oracle
+    whose processors are pinned on the same switch sets by reference-generated vectors (tests/test_oracle_golden.py)."""
+    arch = dict(block_out_channels=(320, 640), down_has_attn=(True, True), layers_per_block=1)
+    n, F, hw, V = 2, 3, (16, 16), 2
+    ocfg = O.UNetConfig(**arch, **kw)
+    ref = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
+    O.init_synthetic_weights(ref, seed=0, dense=True)
+    hip = MVUNetMotionModel(UNetConfig(**arch, **kw), num_views=n, device="cuda")
+    missing, unexpected = hip.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected
+    hip = hip.to(torch.bfloat16).eval()
+    inp = O.synthetic_inputs(ocfg, V, n, F, hw, seed=11)
+    y_ref = ref(**inp).sample
+    y = hip(**_cuda(inp)).sample
+    e, mx, sc = _rel(y, y_ref)
+    print(f"[parity] unet switch set {kw}: hip-vs-oracle rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e})")
+    assert torch.isfinite(y).all() and e <= 3e-2
+
+
+@pytest.mark.parametrize("hw", [(12, 20), (9, 10)])
+def test_forced_upsample_sizes_on_the_hip_path(hw):
+    """Latents that are not multiples of 8 (unet_motion_mv_model.py:690-698, 831-837): the cropped nearest-2x upsample of
+    a3d_conv3x3_bf16 (up2x bits 1 / 2) on all four levels, against the oracle (whose forward is pinned on the 12 x 20 case by
+    the reference's own forward, tests/golden/unet_forward.npz)."""
+    n, F, V = 2, 2, 2
+    ocfg = O.UNetConfig()
+    ref = O.build_fast(ocfg, n, F, hw, seed=2)
+    hip = MVUNetMotionModel(UNetConfig(), num_views=n, device="cuda")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(torch.bfloat16).eval()
+    inp = O.synthetic_inputs(ocfg, V, n, F, hw, seed=12)
+    y_ref = ref(**inp).sample
+    y = hip(**_cuda(inp)).sample
+    e, mx, sc = _rel(y, y_ref)
+    print(f"[parity] unet {hw[0]}x{hw[1]} latent (forced upsample sizes): rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e})")
+    assert y.shape == y_ref.shape and torch.isfinite(y).all() and e <= 3e-2
+
+
 def test_output_dtype_and_determinism(models):
     ocfg, ref, hip, _ = models
     inp = _cuda(O.synthetic_inputs(ocfg, 2, N_VIEWS, FRAMES, HW, seed=5))

@@ -66,10 +66,12 @@ class TorchRefOps:
         h, gate = (x.float() @ w.t() + b).chunk(2, dim=-1)
         return self._o(h * F.gelu(gate))
 
-    def conv3x3(self, x, B, H, W, w, bias, *, stride=1, up2x=False, rowbias=None, rb_div=1, residual=None):
+    def conv3x3(self, x, B, H, W, w, bias, *, stride=1, up2x=False, rowbias=None, rb_div=1, residual=None, up_size=None):
         Cin, Cout = x.shape[1], w.shape[0]
         img = x.float().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
-        if up2x:
+        if up2x and up_size is not None:
+            img = F.interpolate(img, size=tuple(up_size), mode="nearest")
+        elif up2x:
             img = F.interpolate(img, scale_factor=2.0, mode="nearest")
         w4 = w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
         y = F.conv2d(img, w4, None if bias is None else bias.float(), stride=stride, padding=1)
