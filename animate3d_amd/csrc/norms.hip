@@ -11,6 +11,7 @@ struct GNParams {
   const uint16_t* X; uint16_t* Y; const float* gamma; const float* beta;
   float* partial;   // [B][nchunk][groups][2]
   float* stats;     // [B][groups][2]  (mean, rstd)
+  double* sums;     // [B][groups][2]  (sum, sum of squares): written INSTEAD of stats when non-null (split call, frame-sharded 3-D norm)
   int B; int64_t rows; int C; int groups; int cg; int nchunk; float eps; int silu;
 };
 
@@ -82,6 +83,11 @@ __global__ void gn_finalize_kernel(const GNParams p) {
   if (sub != 0 || grp >= p.groups) return;
   s = 0.0; q = 0.0;
   for (int k = 0; k < nsub; ++k) { s += sred[((size_t)k * p.groups + grp) * 2]; q += sred[((size_t)k * p.groups + grp) * 2 + 1]; }
+  if (p.sums) {
+    p.sums[((int64_t)b * p.groups + grp) * 2 + 0] = s;
+    p.sums[((int64_t)b * p.groups + grp) * 2 + 1] = q;
+    return;
+  }
   const double n = (double)p.rows * p.cg;
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -317,9 +323,12 @@ extern "C" int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups) {
   return (int64_t)B * gn_nchunk(rows) * groups * 2 + (int64_t)B * groups * 2;
 }
 
-extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
-                                   float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
-  if (!X || !Y || !gamma || !beta || !ws || B <= 0 || rows <= 0 || C <= 0 || groups <= 0) return A3D_EINVAL;
+// mode 0: whole GroupNorm; 1: statistics only (raw fp64 sums); 2: apply only (stats = [B][groups][2] mean, rstd)
+static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                             float* ws, double* sums, const float* stats_in, int B, int64_t rows, int C, int groups, float eps, int silu) {
+  if (!X || B <= 0 || rows <= 0 || C <= 0 || groups <= 0) return A3D_EINVAL;
+  if (mode != 1 && (!Y || !gamma || !beta)) return A3D_EINVAL;
+  if ((mode != 2 && !ws) || (mode == 1 && !sums) || (mode == 2 && !stats_in)) return A3D_EINVAL;
   if (C % 8 != 0 || C % groups != 0 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;
   // a 16-byte chunk (8 channels) must touch at most 2 groups: channels-per-group 4 (chunk = exactly 2 groups) or >= 7
   // (8 channels starting anywhere span <= 2 groups of >= 7); 5 and 6 can straddle 3 groups and are rejected
@@ -330,20 +339,35 @@ extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, 
   p.X = (const uint16_t*)X; p.Y = (uint16_t*)Y; p.gamma = gamma; p.beta = beta;
   p.B = B; p.rows = rows; p.C = C; p.groups = groups; p.cg = C / groups; p.nchunk = gn_nchunk(rows);
   p.eps = eps; p.silu = silu;
-  p.partial = ws; p.stats = ws + (int64_t)B * p.nchunk * groups * 2;
+  p.partial = ws; p.stats = mode == 2 ? const_cast<float*>(stats_in) : ws + (int64_t)B * p.nchunk * groups * 2;
+  p.sums = mode == 1 ? sums : nullptr;
   const int c8 = C / 8;
   int ny = 256 / c8; if (ny < 1) ny = 1; if (ny > 32) ny = 32;
   if (c8 * ny < groups) return A3D_EINVAL;
   const dim3 block(c8, ny), grid(p.nchunk, B);
   hipStream_t s = (hipStream_t)stream;
-  gn_partial_kernel<<<grid, block, (size_t)c8 * ny * 4 * sizeof(float), s>>>(p);
-  {
+  if (mode != 2) {
+    gn_partial_kernel<<<grid, block, (size_t)c8 * ny * 4 * sizeof(float), s>>>(p);
     const int gx = (groups + 31) / 32 * 32;
     int nsub = 1024 / gx; if (nsub > 32) nsub = 32; if (nsub > p.nchunk) nsub = p.nchunk; if (nsub < 1) nsub = 1;
     gn_finalize_kernel<<<dim3(B), dim3(gx, nsub), (size_t)nsub * groups * 2 * sizeof(double), s>>>(p);
   }
-  gn_apply_kernel<<<grid, block, 0, s>>>(p);
+  if (mode != 1) gn_apply_kernel<<<grid, block, 0, s>>>(p);
   return a3d_launch_status();
+}
+
+extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                                   float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
+  return group_norm_launch(0, stream, X, Y, gamma, beta, ws, nullptr, nullptr, B, rows, C, groups, eps, silu);
+}
+
+extern "C" int a3d_group_norm_sums_bf16(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups) {
+  return group_norm_launch(1, stream, X, nullptr, nullptr, nullptr, ws, sums, nullptr, B, rows, C, groups, 0.f, 0);
+}
+
+extern "C" int a3d_group_norm_apply_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                                         const float* stats, int B, int64_t rows, int C, int groups, int silu) {
+  return group_norm_launch(2, stream, X, Y, gamma, beta, nullptr, nullptr, stats, B, rows, C, groups, 0.f, silu);
 }
 
 extern "C" int a3d_layer_norm_bf16(a3d_stream_t stream, const void* X, void* Y1, void* Y2, const float* gamma,

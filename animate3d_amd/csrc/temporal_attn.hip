@@ -21,10 +21,15 @@ constexpr int SL = 40;               // dims per thread slice
 constexpr int NSL = SLAB / SL;       // 8 slices per pixel
 
 struct TAParams {
-  const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ld;
+  const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ld;      // ld: row stride of K and V
+  int64_t ldq;       // row stride of Q
   uint16_t* O; int64_t ldo;
   int videos, frames; int64_t L; int heads; float scale_log2;
   int64_t npix;      // videos * L
+  // frame-sharded call (a3d_temporal_attn_sharded_bf16): Q / O hold only frames [q_f0, q_f0 + q_frames) of every video, rows
+  // ((v*q_frames + f - q_f0)*L + l); K / V hold all frames as kv_fpr frames per rank block: frame f of video v at row
+  // (f / kv_fpr) * kv_rs + (v*kv_fpr + f % kv_fpr)*L + l.  Unsharded: q_f0 = 0, q_frames = kv_fpr = frames, kv_rs = 0.
+  int q_f0, q_frames, kv_fpr; int64_t kv_rs;
 };
 
 A3D_DEV float dot2(uint32_t a, uint32_t b, float c) {
@@ -52,7 +57,13 @@ __global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAP
     int64_t pix = pix0 + px;
     if (pix >= p.npix) pix = p.npix - 1;
     const int64_t v = pix / p.L, l = pix % p.L;
-    return (ten == 0 ? p.Q : (ten == 1 ? p.K : p.V)) + ((v * Fd + f) * p.L + l) * p.ld + c0 + ch * 8;
+    if (ten == 0) {
+      int fq = f - p.q_f0;                       // frames this rank has no query for: any valid row (the lanes are idle later)
+      if (fq < 0 || fq >= p.q_frames) fq = 0;
+      return p.Q + ((v * p.q_frames + fq) * p.L + l) * p.ldq + c0 + ch * 8;
+    }
+    const int64_t row = (int64_t)(f / p.kv_fpr) * p.kv_rs + (v * p.kv_fpr + f % p.kv_fpr) * p.L + l;
+    return (ten == 1 ? p.K : p.V) + row * p.ld + c0 + ch * 8;
   };
   auto dst_of = [&](int it, int Fd) -> uint16_t* {
     const int ch = it % chunks;
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAP
   const int sl = tid % NSL;            // slices of one head are adjacent lanes (shuffle partners xor 1, xor 2)
   const int i = (tid / NSL) % FP;
   const int px = tid / (FP * NSL);
-  const bool active = i < F && pix0 + px < p.npix;
+  const bool active = i >= p.q_f0 && i < p.q_f0 + p.q_frames && pix0 + px < p.npix;
   const int fi = i < F ? i : F - 1;
   const uint16_t* qrow = smem + ((size_t)0 * F + fi) * ROWB + px * SLAB + sl * SL;
   const uint16_t* kbase = smem + ((size_t)1 * F) * ROWB + px * SLAB + sl * SL;
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAP
   if (active) {
     const int64_t pix = pix0 + px;
     const int64_t v = pix / p.L, l = pix % p.L;
-    uint16_t* dst = p.O + ((v * F + i) * p.L + l) * p.ldo + c0 + sl * SL;
+    uint16_t* dst = p.O + ((v * p.q_frames + (i - p.q_f0)) * p.L + l) * p.ldo + c0 + sl * SL;
 #pragma unroll
     for (int c = 0; c < SL / 8; ++c) {
       u32x4_t ov;
@@ -184,20 +195,22 @@ int launch_dp(hipStream_t s, const TAParams& p, int C) {
 
 }  // namespace
 
-extern "C" int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
-                                      void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
-                                      int head_dim, float scale) {
+static int temporal_attn_launch(a3d_stream_t stream, const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldqkv, void* O, int64_t ldo,
+                                int videos, int frames, int64_t L, int heads, int head_dim, float scale,
+                                int q_f0, int q_frames, int kv_fpr, int64_t kv_rs) {
   if (!Q || !K || !V || !O || videos <= 0 || frames <= 0 || frames > 32 || L <= 0 || heads <= 0) return A3D_EINVAL;
-  if (ldqkv % 8 || ldo % 8) return A3D_EINVAL;
+  if (q_f0 < 0 || q_frames <= 0 || q_f0 + q_frames > frames || kv_fpr <= 0 || frames % kv_fpr != 0 || kv_rs < 0) return A3D_EINVAL;
+  if (ldqkv % 8 || ldo % 8 || ldq % 8) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) |
        reinterpret_cast<uintptr_t>(O)) & 15u) return A3D_EINVAL;
   const int C = heads * head_dim;
   if (C % SLAB != 0) return A3D_EUNSUPPORTED;
   TAParams p{};
-  p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.ld = ldqkv;
+  p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.ld = ldqkv; p.ldq = ldq;
   p.O = (uint16_t*)O; p.ldo = ldo; p.videos = videos; p.frames = frames; p.L = L; p.heads = heads;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.npix = (int64_t)videos * L;
+  p.q_f0 = q_f0; p.q_frames = q_frames; p.kv_fpr = kv_fpr; p.kv_rs = kv_rs;
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
     case 40: return launch_dp<1>(s, p, C);
@@ -205,4 +218,18 @@ extern "C" int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const 
     case 160: return launch_dp<4>(s, p, C);
     default: return A3D_EUNSUPPORTED;
   }
+}
+
+extern "C" int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+                                      void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
+                                      int head_dim, float scale) {
+  return temporal_attn_launch(stream, Q, ldqkv, K, V, ldqkv, O, ldo, videos, frames, L, heads, head_dim, scale, 0, frames, frames, 0);
+}
+
+extern "C" int a3d_temporal_attn_sharded_bf16(a3d_stream_t stream, const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldkv,
+                                              void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
+                                              int head_dim, float scale, int q_f0, int q_frames, int kv_frames_per_block,
+                                              int64_t kv_block_stride) {
+  return temporal_attn_launch(stream, Q, ldq, K, V, ldkv, O, ldo, videos, frames, L, heads, head_dim, scale, q_f0, q_frames,
+                              kv_frames_per_block, kv_block_stride);
 }

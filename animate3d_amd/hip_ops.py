@@ -49,8 +49,12 @@ _SIGNATURES = {
     "a3d_tune_flash": (c_int, [c_int]),
     "a3d_tune_gemm": (c_int, [c_int]),
     "a3d_temporal_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
+    "a3d_temporal_attn_sharded_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32,
+                                               c_int, c_int, c_int, c_i64]),
     "a3d_group_norm_ws_floats": (c_i64, [c_int, c_i64, c_int]),
     "a3d_group_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_f32, c_int]),
+    "a3d_group_norm_sums_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int]),
+    "a3d_group_norm_apply_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int]),
     "a3d_layer_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64]),
     "a3d_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "a3d_silu_bf16": (c_int, [c_vp, c_vp, c_vp, c_i64]),
@@ -217,15 +221,24 @@ class HipOps:
         _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
         return o
 
-    def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int):
+    def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int, *, q_f0: int = 0, q_frames: Optional[int] = None):
+        """Unsharded: q / k / v rows ((v F + f) L + l).  Frame-sharded (``q_frames`` < ``frames``): q holds this rank's frames
+        [q_f0, q_f0 + q_frames) only; k / v are the all-gathered tensors ``[frames / q_frames blocks, videos * q_frames * L, C]``."""
         q, k, v = self._act(q, "tattn.q"), self._act(k, "tattn.k"), self._act(v, "tattn.v")
         C = q.shape[1]
         D = C // heads
-        assert q.stride(0) == k.stride(0) == v.stride(0)
+        assert k.stride(0) == v.stride(0)
         o = self.empty(q.shape[0], C)
-        rc = self.lib.a3d_temporal_attn_bf16(self._stream(), _p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0),
-                                             videos, frames, L, heads, D, float(D) ** -0.5)
-        _check(rc, f"a3d_temporal_attn_bf16 videos={videos} frames={frames} L={L} D={D}")
+        if q_frames is None or q_frames == frames:
+            assert q.stride(0) == k.stride(0)
+            rc = self.lib.a3d_temporal_attn_bf16(self._stream(), _p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0),
+                                                 videos, frames, L, heads, D, float(D) ** -0.5)
+        else:
+            assert q.shape[0] == videos * q_frames * L and k.shape[0] == videos * frames * L
+            rc = self.lib.a3d_temporal_attn_sharded_bf16(self._stream(), _p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(o), o.stride(0),
+                                                         videos, frames, L, heads, D, float(D) ** -0.5, q_f0, q_frames, q_frames,
+                                                         videos * q_frames * L)
+        _check(rc, f"a3d_temporal_attn_bf16 videos={videos} frames={frames} L={L} D={D} q_f0={q_f0} q_frames={q_frames}")
         return o
 
     # ---- normalisation
@@ -237,6 +250,26 @@ class HipOps:
         ws = torch.empty(int(self.lib.a3d_group_norm_ws_floats(B, rows, groups)), dtype=torch.float32, device=self.device)
         rc = self.lib.a3d_group_norm_bf16(self._stream(), _p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, rows, C, groups, eps, 1 if silu else 0)
         _check(rc, f"a3d_group_norm_bf16 B={B} rows={rows} C={C}")
+        return y
+
+    def group_norm_sums(self, x, B: int, rows: int, groups: int) -> torch.Tensor:
+        """fp64 [B, groups, 2] = (sum, sum of squares) of this rank's rows (first half of a GroupNorm spread over ranks)."""
+        x = self._act(x, "gn.x")
+        assert x.is_contiguous() and x.shape[0] == B * rows
+        ws = torch.empty(int(self.lib.a3d_group_norm_ws_floats(B, rows, groups)), dtype=torch.float32, device=self.device)
+        sums = torch.empty((B, groups, 2), dtype=torch.float64, device=self.device)
+        _check(self.lib.a3d_group_norm_sums_bf16(self._stream(), _p(x), _p(ws), _p(sums), B, rows, x.shape[1], groups),
+               f"a3d_group_norm_sums_bf16 B={B} rows={rows} C={x.shape[1]}")
+        return sums
+
+    def group_norm_apply(self, x, B: int, rows: int, gamma, beta, groups: int, stats: torch.Tensor, silu: bool):
+        """Second half: ``stats`` fp32 [B, groups, 2] = (mean, rstd)."""
+        x = self._act(x, "gn.x")
+        assert x.is_contiguous() and x.shape[0] == B * rows
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape == (B, groups, 2)
+        y = self.empty(x.shape[0], x.shape[1])
+        _check(self.lib.a3d_group_norm_apply_bf16(self._stream(), _p(x), _p(y), _p(gamma), _p(beta), _p(stats), B, rows, x.shape[1], groups,
+                                                  1 if silu else 0), f"a3d_group_norm_apply_bf16 B={B} rows={rows} C={x.shape[1]}")
         return y
 
     def layer_norm(self, x, gamma, beta, eps: float, pe1=None, pe1_div: int = 1, pe2=None, pe2_div: int = 1, two: bool = False):

@@ -1,71 +1,106 @@
 """Single-node multi-GPU execution of one denoise step: one process per GPU, torch.distributed
 (backend "nccl" = RCCL over xGMI on MI355X; "gloo" for the CPU tests).
 
-The reference has no inference parallelism at all; this is new design (§8e):
+The reference has no inference parallelism at all; this is new design (§8e).  The (b, n, f) = (CFG half /
+batch, view, frame) grid of videos-by-frames is cut along three axes, ``world = cfg_shards x view_shards x frame_shards``:
 
 * axis 1 — CFG / batch halves ``b``: every regrouping in the model keeps ``b`` outermost
   (attention_processor.py:340,557), so different ``b`` never exchange data.  Free.
-* axis 2 — views: rank (c, s) holds ``n/S`` of the ``n`` views of its ``b`` slice, all frames.
-  Temporal attention, the 3-D GroupNorm, convs, GEMMs and cross-attention are local per video; the
-  only exchange is an all-gather over the S ranks of the view group before each multi-view attention — of the
-  attention's normalised input tokens (C wide; K|V are then projected locally for all n views), or optionally of
-  the projected K|V tokens (2C wide, ``gather_tokens = False``) — (16 Transformer2D + 42 motion-module attentions per step; the
-  I2V branch reuses the same gathered K/V).  On the fully connected xGMI mesh the gather among
-  S <= 4 peers uses all S-1 links of a GPU concurrently.
+* axis 2 — views: a rank holds ``n / Sv`` views of its ``b`` slice.  The only exchange is an all-gather over the Sv ranks of
+  the view group before each multi-view attention (16 Transformer2D + 42 motion-module spatial attentions per step) — of the
+  attention's normalised input tokens (C wide; K|V are then projected locally for all n views), or optionally of the
+  projected K|V (2C wide, ``gather_tokens = False``).  The I2V branch reuses the gathered K/V.
+* axis 3 — frames: a rank holds a contiguous range of ``F / Sf`` frames.  Multi-view attention, convs, 2-D norms and
+  cross-attention are local per (b, f); what crosses the frame group is
+    - the temporal attention (attention_processor.py:619-641): all-gather of the projected K|V of every motion attention,
+      queries stay local (``a3d_temporal_attn_sharded_bf16`` reads the rank-major gathered buffer in place);
+    - the motion module's 3-D GroupNorm over (C/32, F, h, w) (diffusers TransformerTemporalModel.norm): fp64 partial sums
+      [videos, 32, 2], one all-reduce (``a3d_group_norm_sums_bf16`` / ``a3d_group_norm_apply_bf16``);
+    - the first-frame K/V of the I2V branches (attention_processor.py:389-397, 672-698): frame 0's normalised tokens are
+      broadcast from the rank that holds frame 0 (1/F of a token tensor).
 
-The model stays SPMD-transparent: every rank calls ``unet(...)`` with the full inputs and receives
-the full ``[V, C, F, h, w]`` output; the shard is cut inside ``forward`` and the (tiny) latent output
-is all-gathered at the end.
+Rank order is (cfg, view, frame) with frame fastest: neighbouring ranks form a frame group.  On the fully connected xGMI mesh
+every gather among S <= 8 peers uses all S-1 links of a GPU concurrently.
+
+The model stays SPMD-transparent: every rank calls ``unet(...)`` with the full inputs and receives the full
+``[V, C, F, h, w]`` output; the shard is cut inside ``forward`` and the (tiny) latent output is all-gathered at the end.
 """
 from __future__ import annotations
 
 import math
-from typing import Dict, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-class ViewParallel:
-    def __init__(self, group=None):
+class ShardPlan:
+    def __init__(self, group=None, layout: Optional[Sequence[int]] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        self._layouts: Dict[Tuple[int, int], Tuple[list, object]] = {}
-        self.cfg_shards = self.view_shards = 1
-        self.cfg_rank = self.view_rank = 0
-        self.view_group = None
-        self.gather_bytes = 0            # bytes received by this rank in all-gathers (telemetry)
+        if group is not None and group is not dist.group.WORLD:
+            # sub-groups are created with dist.new_group (global ranks, collective over the WORLD): a plan over a foreign
+            # group would build wrong rank lists or hang
+            raise ValueError("ShardPlan works on the default process group (one process per GPU of the node)")
+        self.group = None
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.layout_request = tuple(int(v) for v in layout) if layout is not None else None
+        if self.layout_request is not None and (len(self.layout_request) != 3 or math.prod(self.layout_request) != self.world):
+            raise ValueError(f"layout {self.layout_request} must be (cfg_shards, view_shards, frame_shards) with product {self.world}")
+        self._layouts: Dict[Tuple[int, int, int], Tuple[object, object]] = {}
+        self.cfg_shards = self.view_shards = self.frame_shards = 1
+        self.cfg_rank = self.view_rank = self.frame_rank = 0
+        self.view_group = self.frame_group = None
+        self.frame_group_root = self.rank    # global rank holding frame 0 of this rank's frame group
+        self.gather_bytes = 0            # bytes received by this rank in data-path collectives (telemetry)
+        self.collectives = 0
         self.gather_tokens = True        # all-gather the attention's input tokens (C wide) instead of projected K|V (2C wide)
 
-    # ---- layout: world = cfg_shards x view_shards
+    # ---- layout: world = cfg_shards x view_shards x frame_shards
     @staticmethod
-    def choose_layout(world: int, b: int, n: int) -> Tuple[int, int]:
-        cfg = math.gcd(world, b)
-        views = world // cfg
-        if n % views != 0:
-            raise ValueError(f"cannot shard b={b} x n={n} views over {world} ranks (cfg_shards={cfg}, view_shards={views})")
-        return cfg, views
+    def choose_layout(world: int, b: int, n: int, F: Optional[int] = None, request: Optional[Sequence[int]] = None) -> Tuple[int, int, int]:
+        """Default: CFG halves first (free), then views, then frames.  ``request`` = explicit (cfg, views, frames)."""
+        if request is not None:
+            cfg, views, frames = (int(v) for v in request)
+        else:
+            cfg = math.gcd(world, b)
+            views = math.gcd(world // cfg, n)
+            frames = world // (cfg * views)
+        if cfg * views * frames != world or b % cfg or n % views or (frames > 1 and (F is None or F % frames)):
+            raise ValueError(f"cannot shard b={b} x n={n} views x F={F} frames over {world} ranks as "
+                             f"(cfg_shards={cfg}, view_shards={views}, frame_shards={frames})")
+        return cfg, views, frames
 
-    def configure(self, b: int, n: int):
-        """Collective: every rank must call it with the same (b, n).  Creates / reuses the view groups."""
-        cfg, views = self.choose_layout(self.world, b, n)
-        key = (cfg, views)
+    def _global_rank(self, c: int, s: int, r: int) -> int:
+        return (c * self.view_shards + s) * self.frame_shards + r
+
+    def configure(self, b: int, n: int, F: Optional[int] = None):
+        """Collective on first use of a layout: every rank must call it with the same (b, n, F).  Creates / reuses the view
+        and frame groups (``dist.new_group`` is collective over the world — call it explicitly, e.g. through
+        ``shard_unet(unet, shape=(b, n, F))``, if the first forward must not carry that hidden collective)."""
+        cfg, views, frames = self.choose_layout(self.world, b, n, F, self.layout_request)
+        self.cfg_shards, self.view_shards, self.frame_shards = cfg, views, frames
+        r = self.rank
+        self.frame_rank, self.view_rank, self.cfg_rank = r % frames, (r // frames) % views, r // (frames * views)
+        key = (cfg, views, frames)
         if key not in self._layouts:
-            groups = []
-            mine = None
+            vmine = fmine = None
             for c in range(cfg):
-                ranks = [c * views + s for s in range(views)]
-                g = dist.new_group(ranks=ranks) if views > 1 else None     # new_group is collective over the world
-                groups.append(g)
-                if self.rank in ranks:
-                    mine = g
-            self._layouts[key] = (groups, mine)
-        self.cfg_shards, self.view_shards = cfg, views
-        self.cfg_rank, self.view_rank = self.rank // views, self.rank % views
-        self.view_group = self._layouts[key][1]
+                for fr in range(frames):
+                    ranks = [self._global_rank(c, s, fr) for s in range(views)]
+                    g = dist.new_group(ranks=ranks) if views > 1 else None
+                    if self.rank in ranks:
+                        vmine = g
+            for c in range(cfg):
+                for s in range(views):
+                    ranks = [self._global_rank(c, s, fr) for fr in range(frames)]
+                    g = dist.new_group(ranks=ranks) if frames > 1 else None
+                    if self.rank in ranks:
+                        fmine = g
+            self._layouts[key] = (vmine, fmine)
+        self.view_group, self.frame_group = self._layouts[key]
+        self.frame_group_root = self._global_rank(self.cfg_rank, self.view_rank, 0)
         return self
 
     def local_videos(self, V: int, n: int) -> torch.Tensor:
@@ -76,47 +111,95 @@ class ViewParallel:
         ns = torch.arange(self.view_rank * nl, (self.view_rank + 1) * nl)
         return (bs[:, None] * n + ns[None, :]).reshape(-1)
 
-    # ---- collectives
+    def frame_range(self, F: int) -> Tuple[int, int]:
+        """(first frame, number of frames) of this rank."""
+        fl = F // self.frame_shards
+        return self.frame_rank * fl, fl
+
+    def _count(self, received_bytes: int):
+        self.gather_bytes += int(received_bytes)
+        self.collectives += 1
+
+    # ---- view axis
     def all_gather_views_start(self, kv: torch.Tensor):
-        """Launch the all-gather of this rank's projected K|V tokens ``[(b_l n_l f) l, 2C]`` over the view group and
-        return a handle; the collective runs on the backend's own stream (RCCL), so kernels issued on the compute
-        stream before ``all_gather_views_finish`` overlap with it (the Q projection, the temporal branch of a motion
-        module)."""
+        """Launch the all-gather of this rank's tokens (or projected K|V) ``[(b_l n_l f) l, width]`` over the view group and
+        return a handle; the collective runs on the backend's own stream (RCCL), so kernels issued on the compute stream
+        before ``all_gather_views_finish`` overlap with it (the Q projection, the temporal branch of a motion module)."""
         S = self.view_shards
         rows, width = kv.shape
         kv = kv.contiguous()
         out = torch.empty((S * rows, width), dtype=kv.dtype, device=kv.device)
         work = dist.all_gather_into_tensor(out, kv, group=self.view_group, async_op=True)
-        self.gather_bytes += (S - 1) * rows * width * kv.element_size()
+        self._count((S - 1) * rows * width * kv.element_size())
         return work, out, kv
 
     def all_gather_views_finish(self, handle, b_local: int) -> torch.Tensor:
-        """Wait (the compute stream waits, not the host) and return the view group's ``[(b_l N f) l, 2C]`` tokens in
+        """Wait (the compute stream waits, not the host) and return the view group's ``[(b_l N f) l, width]`` tokens in
         unsharded row order."""
         work, out, kv = handle
         work.wait()
         S = self.view_shards
         rows, width = kv.shape
         if b_local == 1:
-            return out                               # [S, n_l F L, 2C] is already (N f) l order
+            return out                               # [S, n_l F L, width] is already (N f) l order
         per_b = rows // b_local
         return out.view(S, b_local, per_b, width).permute(1, 0, 2, 3).reshape(S * rows, width)
 
     def all_gather_views(self, kv: torch.Tensor, b_local: int) -> torch.Tensor:
         return self.all_gather_views_finish(self.all_gather_views_start(kv), b_local)
 
-    def all_gather_output(self, y_local: torch.Tensor, V: int, n: int) -> torch.Tensor:
-        """[V_local, C, F, h, w] on every rank -> full [V, C, F, h, w] in (b n) order on every rank."""
+    # ---- frame axis
+    def all_gather_frames_start(self, kv: torch.Tensor):
+        """All-gather of the temporal K|V ``[(v f_l) l, 2C]`` over the frame group; the result is rank-major
+        ``[Sf, (v f_l) l, 2C]`` and is read in place (frame f of video v sits in block f // f_l)."""
+        S = self.frame_shards
+        rows, width = kv.shape
+        kv = kv.contiguous()
+        out = torch.empty((S * rows, width), dtype=kv.dtype, device=kv.device)
+        work = dist.all_gather_into_tensor(out, kv, group=self.frame_group, async_op=True)
+        self._count((S - 1) * rows * width * kv.element_size())
+        return work, out, kv
+
+    @staticmethod
+    def all_gather_frames_finish(handle) -> torch.Tensor:
+        work, out, _ = handle
+        work.wait()
+        return out
+
+    def broadcast_frame0(self, x0: Optional[torch.Tensor], shape, dtype, device) -> torch.Tensor:
+        """Frame 0's tokens from the rank of the frame group that holds frame 0 (``x0`` there, None elsewhere)."""
+        buf = x0.contiguous() if self.frame_rank == 0 else torch.empty(shape, dtype=dtype, device=device)
+        dist.broadcast(buf, src=self.frame_group_root, group=self.frame_group)
+        if self.frame_rank != 0:
+            self._count(buf.numel() * buf.element_size())
+        return buf
+
+    def all_reduce_frames(self, t: torch.Tensor) -> torch.Tensor:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.frame_group)
+        self._count(2 * (self.frame_shards - 1) * t.numel() * t.element_size() // self.frame_shards)
+        return t
+
+    # ---- output
+    def all_gather_output(self, y_local: torch.Tensor, V: int, n: int, F: Optional[int] = None) -> torch.Tensor:
+        """[V_local, C, F_local, h, w] on every rank -> full [V, C, F, h, w] in (b n) order on every rank."""
         b = V // n
         bl, nl = b // self.cfg_shards, n // self.view_shards
         out = torch.empty((self.world * y_local.shape[0],) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-        dist.all_gather_into_tensor(out, y_local.contiguous(), group=self.group)
-        tail = tuple(y_local.shape[1:])
-        out = out.view(self.cfg_shards, self.view_shards, bl, nl, *tail).permute(0, 2, 1, 3, *range(4, 4 + len(tail)))
-        return out.reshape(V, *tail).contiguous()
+        dist.all_gather_into_tensor(out, y_local.contiguous())
+        C, Fl, h, w = y_local.shape[1:]
+        out = out.view(self.cfg_shards, self.view_shards, self.frame_shards, bl, nl, C, Fl, h, w)
+        out = out.permute(0, 3, 1, 4, 5, 2, 6, 7, 8)                     # cfg, b_l, view, n_l, C, frame shard, F_l, h, w
+        return out.reshape(V, C, self.frame_shards * Fl, h, w).contiguous()
 
 
-def shard_unet(unet, group=None) -> ViewParallel:
-    """Attach a ViewParallel plan to a MVUNetMotionModel (every rank, same order)."""
-    unet.parallel = ViewParallel(group)
+ViewParallel = ShardPlan          # name of the round-1 plan (views only)
+
+
+def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: Optional[Tuple[int, int, int]] = None) -> ShardPlan:
+    """Attach a ShardPlan to a MVUNetMotionModel (every rank, same order).  ``layout`` = (cfg_shards, view_shards,
+    frame_shards) or None for the default (CFG halves, then views, then frames); ``shape`` = (b, n, F) of the calls to come
+    creates the process groups now instead of inside the first forward."""
+    unet.parallel = ShardPlan(group, layout)
+    if shape is not None:
+        unet.parallel.configure(*shape)
     return unet.parallel

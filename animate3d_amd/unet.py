@@ -60,6 +60,7 @@ class MVUNetMotionModel(nn.Module):
         self._packed = None
         self._pe_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.parallel = None                # set by animate3d_amd.parallel.shard_unet
+        self._frames = (0, 0)               # (frames of the call, first frame of this rank): set by forward
         if len(cfg.block_out_channels) != len(cfg.down_has_attn):
             raise ValueError("block_out_channels and down_has_attn must have the same length")
         if 9 * cfg.in_channels > 64:        # conv_in runs as a K = 64 GEMM over 3x3 patches (a3d_im2col_in)
@@ -485,15 +486,34 @@ class MVUNetMotionModel(nn.Module):
         asynchronous: the Q projection and ``overlap()`` (independent work of the caller, e.g. the
         temporal branch of a motion module) are issued while it is in flight.  Returns (a, a_i2v, overlap())."""
         ops, par = self.ops, self.parallel
+        if par is not None and par.world == 1:
+            par = None
         qm, k0 = self._mv_maps(n, F, L)
         b = V // n
-        if par is None or par.view_shards == 1:
+        fsh = par is not None and par.frame_shards > 1
+        vsh = par is not None and par.view_shards > 1
+        N = n * par.view_shards if vsh else n
+
+        def first_frame_kv():
+            """K|V of frame 0 of every b for the I2V branch when this rank may not hold frame 0: its tokens come from the rank
+            of the frame group that does, then (view-sharded) from the other view shards; [b * N * L, 2C], rows (b N) l."""
+            x0 = x.view(V, F, L, C)[:, 0].reshape(V * L, C) if par.frame_rank == 0 else None
+            x0 = par.broadcast_frame0(x0, (V * L, C), x.dtype, x.device)
+            if vsh:
+                x0 = par.all_gather_views(x0, b)
+            return ops.gemm(x0, w_kvq[:2 * C]), RowMap(gdiv=F, ga=N * L, gb=0, seg_len=L, seg_stride=L)
+
+        if not vsh:
             kvq = ops.gemm(x, w_kvq)
             k, v, q = kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C]
             a = ops.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L)
-            ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L) if i2v else None
+            ai = None
+            if i2v and fsh:
+                kv0, km0 = first_frame_kv()
+                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, n * L)
+            elif i2v:
+                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L)
             return a, ai, (overlap() if overlap is not None else None)
-        N = n * par.view_shards
         if par.gather_tokens:
             # gather the (normalised) INPUT tokens [rows_local, C] and project K|V for all N views locally: half the
             # bytes on xGMI for S x the (cheap, HBM-bound) K|V projection
@@ -510,7 +530,12 @@ class MVUNetMotionModel(nn.Module):
         km, km0 = self._mv_maps(N, F, L)
         k, v = kv_all[:, :C], kv_all[:, C:]
         a = ops.flash_attn(qq[:, :C], k, v, qm, km, b * F, heads, n * L, N * L)
-        ai = ops.flash_attn(qq[:, C:2 * C], k, v, qm, km0, b * F, heads, n * L, N * L) if i2v else None
+        ai = None
+        if i2v and fsh:
+            kv0, km0 = first_frame_kv()
+            ai = ops.flash_attn(qq[:, C:2 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, N * L)
+        elif i2v:
+            ai = ops.flash_attn(qq[:, C:2 * C], k, v, qm, km0, b * F, heads, n * L, N * L)
         return a, ai, extra
 
     def _t2d(self, x, V, n, F, H, W, pk, text_rows, ip_rows, T):
@@ -559,9 +584,20 @@ class MVUNetMotionModel(nn.Module):
         C = nt.shape[1]
         ct, cs, ci = a.coef
 
+        par = self.parallel if (self.parallel is not None and self.parallel.world > 1) else None
+        fsh = par is not None and par.frame_shards > 1
+        F_all, f0 = self._frames
+
         def temporal_branch(nt=nt, a=a):
-            qkv = ops.gemm(nt, a.qkv)
-            return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
+            if not fsh:
+                qkv = ops.gemm(nt, a.qkv)
+                return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
+            # frame-sharded: every rank needs the keys / values of ALL frames of its pixels; queries stay local
+            kv = ops.gemm(nt, a.qkv[C:])                      # [rows_local, 2C], contiguous
+            pending = par.all_gather_frames_start(kv)
+            q = ops.gemm(nt, a.qkv[:C])                       # overlaps the gather
+            kv_all = par.all_gather_frames_finish(pending)    # [Sf, (v f_l) l, 2C], read in place
+            return ops.temporal_attn(q, kv_all[:, :C], kv_all[:, C:], V, F_all, L, a.heads, q_f0=f0, q_frames=F)
         if a.spatial:
             # the temporal branch is independent of the multi-view one: it runs while the K|V gather is in flight
             asp, _, at = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False, overlap=temporal_branch)
@@ -572,22 +608,38 @@ class MVUNetMotionModel(nn.Module):
             out = ops.gemm(asp, a.osp[0], a.osp[1], residual=out, alpha=cs, beta=1.0)
         if a.image:
             # per-view first-frame attention (:672-698): every image attends to frame 0 of its own video
-            kvq = ops.gemm(nimg, a.qkv_img)
             qm = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
-            k0 = RowMap(gdiv=F, ga=F * L, gb=0, seg_len=L, seg_stride=0)
-            ai = ops.flash_attn(kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C], qm, k0, V * F, a.heads, L, L)
+            if fsh:                       # frame 0's tokens from the rank that holds them
+                x0 = nimg.view(V, F, L, C)[:, 0].reshape(V * L, C) if par.frame_rank == 0 else None
+                kv0 = ops.gemm(par.broadcast_frame0(x0, (V * L, C), nimg.dtype, nimg.device), a.qkv_img[:2 * C])
+                qi = ops.gemm(nimg, a.qkv_img[2 * C:])
+                ai = ops.flash_attn(qi, kv0[:, :C], kv0[:, C:], qm, RowMap(gdiv=F, ga=L, gb=0, seg_len=L, seg_stride=0), V * F, a.heads, L, L)
+            else:
+                kvq = ops.gemm(nimg, a.qkv_img)
+                k0 = RowMap(gdiv=F, ga=F * L, gb=0, seg_len=L, seg_stride=0)
+                ai = ops.flash_attn(kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C], qm, k0, V * F, a.heads, L, L)
             out = ops.gemm(ai, a.oimg[0], a.oimg[1], residual=out, alpha=ci, beta=1.0)
         return out
 
     def _motion(self, x, V, n, F, H, W, pk):
         ops, g = self.ops, self.config.norm_num_groups
         L, C = H * W, x.shape[1]
-        h = ops.group_norm(x, V, F * L, pk.norm[0], pk.norm[1], g, 1e-6, False)     # 3-D GroupNorm per video
+        par = self.parallel if (self.parallel is not None and self.parallel.world > 1) else None
+        F_all, f0 = self._frames
+        if par is not None and par.frame_shards > 1:
+            # 3-D GroupNorm per video over ALL frames: fp64 partial sums of the local frames, one all-reduce over the frame group
+            sums = par.all_reduce_frames(ops.group_norm_sums(x, V, F * L, g))
+            cnt = float(F_all * L * (C // g))
+            mean = sums[..., 0] / cnt
+            var = (sums[..., 1] / cnt - mean * mean).clamp_min(0.0)
+            stats = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-6)], dim=-1).to(torch.float32).contiguous()
+            h = ops.group_norm_apply(x, V, F * L, pk.norm[0], pk.norm[1], g, stats, False)
+        else:
+            h = ops.group_norm(x, V, F * L, pk.norm[0], pk.norm[1], g, 1e-6, False)     # 3-D GroupNorm per video
         h = ops.gemm(h, pk.pin[0], pk.pin[1])
-        par = self.parallel
-        view0 = par.view_rank * n if (par is not None and par.world > 1) else 0
+        view0 = par.view_rank * n if par is not None else 0
         for a in pk.attns:
-            pe_t = a.pe_t[:F]
+            pe_t = a.pe_t[f0:f0 + F]
             ln = lambda **kw: ops.layer_norm(h, a.n[0], a.n[1], 1e-5, **kw)
             if a.block_pe:                     # the block adds the temporal encoding to what every branch reads
                 nt = ns = nimg = ln(pe1=pe_t, pe1_div=L)
@@ -668,19 +720,21 @@ class MVUNetMotionModel(nn.Module):
         img_embeds = None if added_cond_kwargs is None else added_cond_kwargs.get("image_embeds")
         if torch.is_tensor(timestep) and timestep.numel() not in (1, V):
             raise ValueError(f"timestep must be a scalar or have one entry per video, got {tuple(timestep.shape)}")
-        # multi-GPU: cut this rank's (b, view) shard out of the full call (animate3d_amd.parallel)
+        # multi-GPU: cut this rank's (b, view, frame) shard out of the full call (animate3d_amd.parallel)
         par = self.parallel if (self.parallel is not None and self.parallel.world > 1) else None
-        V_full, n_full = V, n
+        V_full, n_full, F_full, f0 = V, n, F, 0
         if par is not None:
-            par.configure(V // n, n)
+            par.configure(V // n, n, F)
             idx = par.local_videos(V, n).to(dev)
-            sample = sample.index_select(0, idx)
+            f0, F = par.frame_range(F)
+            sample = sample.index_select(0, idx)[:, :, f0:f0 + F]
             encoder_hidden_states = encoder_hidden_states.to(dev).index_select(0, idx)
             camera = None if camera is None else camera.to(dev).index_select(0, idx)
             img_embeds = None if img_embeds is None else img_embeds.to(dev).index_select(0, idx)
             if torch.is_tensor(timestep) and timestep.numel() == V:
                 timestep = timestep.to(dev).reshape(-1).index_select(0, idx)
             V, n = idx.numel(), n // par.view_shards
+        self._frames = (F_full, f0)          # all frames of the call / first frame of this rank (temporal encoding, frame exchange)
         B2 = V * F
 
         # 1. time / camera embedding (unet_motion_mv_model.py:706-752)
@@ -709,7 +763,8 @@ class MVUNetMotionModel(nn.Module):
             semb, rb_rows = ops.silu(emb), F                 # one embedding per video, F images share it
         else:                                               # frame 0 of every video gets the t=0 embedding (:748-752)
             per_img = emb[:, None, :].repeat(1, F, 1)
-            per_img[:, 0] = cond_emb
+            if f0 == 0:
+                per_img[:, 0] = cond_emb
             semb, rb_rows = ops.silu(per_img.reshape(B2, -1).contiguous()), 1
 
         # 2. conditioning tokens, once per video (reference repeats them per frame, :754-764)
@@ -763,7 +818,7 @@ class MVUNetMotionModel(nn.Module):
         out_dtype = sample.dtype if sample.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
         out = ops.unpack_out(x, V, cfg.out_channels, F, H, W, out_dtype)
         if par is not None:
-            out = par.all_gather_output(out, V_full, n_full)
+            out = par.all_gather_output(out, V_full, n_full, F_full)
         if not return_dict:
             return (out,)
         return UNet3DConditionOutput(sample=out)

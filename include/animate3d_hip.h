@@ -122,6 +122,16 @@ int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, co
                            void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
                            int head_dim, float scale);
 
+/* The same attention when the FRAMES of a video are sharded over ranks (frame-parallel denoise step): this
+ * rank holds queries (and writes outputs) only for frames [q_f0, q_f0 + q_frames), rows ((v*q_frames + f - q_f0)*L + l); K / V
+ * are the all-gathered tensors, kv_frames_per_block frames per rank block: frame f of video v sits at row
+ * (f / kv_frames_per_block) * kv_block_stride + (v*kv_frames_per_block + f % kv_frames_per_block)*L + l.
+ * Per-query arithmetic is that of a3d_temporal_attn_bf16 (reference: attention_processor.py:630-636 over all F frames). */
+int a3d_temporal_attn_sharded_bf16(a3d_stream_t stream, const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldkv,
+                                   void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
+                                   int head_dim, float scale, int q_f0, int q_frames, int kv_frames_per_block,
+                                   int64_t kv_block_stride);
+
 /* GroupNorm over `rows` consecutive rows x (C/groups) channels per instance, optional SiLU.
  * 2-D GroupNorm: B = images, rows = H*W.  The motion module's 3-D GroupNorm over
  * (C/32, F, H, W) (diffusers TransformerTemporalModel.norm): B = videos, rows = F*H*W.
@@ -129,6 +139,14 @@ int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, co
 int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups);
 int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                         float* ws, int B, int64_t rows, int C, int groups, float eps, int silu);
+
+/* The two halves of a3d_group_norm_bf16 for a norm whose instance is spread over ranks (the motion module's 3-D GroupNorm of
+ * diffusers TransformerTemporalModel.norm under frame sharding): `sums` receives fp64 [B][groups][2] = (sum, sum of squares)
+ * of this rank's rows; the caller all-reduces them over the frame group, forms (mean, rstd) as fp32 [B][groups][2] and hands
+ * them to the apply half.  ws as above. */
+int a3d_group_norm_sums_bf16(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups);
+int a3d_group_norm_apply_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                              const float* stats, int B, int64_t rows, int C, int groups, int silu);
 
 /* LayerNorm over C, with the positional-embedding adds of the motion-module processor fused:
  *   Y1[m] = LN(X[m]) + pe1[(m / pe1_div) % pe1_mod]     (pe1 may be NULL)

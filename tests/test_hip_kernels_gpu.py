@@ -304,7 +304,50 @@ def test_temporal_attn(ops, ref, D, V, F, L):
     check(f"temporal attn D{D} V{V} F{F} L{L}", ops.temporal_attn(q, k, v, V, F, L, heads), ref.temporal_attn(q, k, v, V, F, L, heads))
 
 
+@pytest.mark.parametrize("D,V,F,shards,L", [(40, 2, 16, 4, 64), (80, 1, 4, 2, 7), (160, 2, 32, 8, 8), (40, 3, 6, 3, 5)])
+def test_temporal_attn_frame_sharded(ops, ref, D, V, F, shards, L):
+    """a3d_temporal_attn_sharded_bf16: every frame shard's output from the rank-major all-gathered K|V must equal its rows of the
+    unsharded kernel's output bit for bit (same per-query arithmetic) and the fp32 reference within the attention bar."""
+    heads = 8
+    C = heads * D
+    qkv = rnd(V * F * L, 3 * C, seed=F + D)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    whole = ops.temporal_attn(q, k, v, V, F, L, heads)
+    check(f"temporal attn D{D} (whole)", whole, ref.temporal_attn(q, k, v, V, F, L, heads))
+    fl = F // shards
+    blocks = lambda t: t.reshape(V, shards, fl, L, -1).permute(1, 0, 2, 3, 4).reshape(V * F * L, -1).contiguous()   # what all_gather_into_tensor builds
+    kv_all = blocks(qkv[:, C:])                                  # [shards, (v f_l) l, 2C]
+    for r in range(shards):
+        q_loc = q.reshape(V, shards, fl, L, C)[:, r].reshape(V * fl * L, C).contiguous()
+        got = ops.temporal_attn(q_loc, kv_all[:, :C], kv_all[:, C:], V, F, L, heads, q_f0=r * fl, q_frames=fl)
+        want = whole.reshape(V, shards, fl, L, C)[:, r].reshape(V * fl * L, C)
+        assert torch.equal(got, want), (r, (got.float() - want.float()).abs().max().item())
+        check(f"temporal attn D{D} shard {r}/{shards} vs fp32", got, ref.temporal_attn(q_loc, kv_all[:, :C], kv_all[:, C:], V, F, L, heads, q_f0=r * fl, q_frames=fl))
+
+
 # ------------------------------------------------------------------ normalisation
+@pytest.mark.parametrize("B,rows,C,shards", [(2, 4 * 64, 320, 4), (3, 2 * 100, 640, 2), (1, 8 * 16, 1280, 8)])
+def test_group_norm_split_halves(ops, ref, B, rows, C, shards):
+    """a3d_group_norm_sums_bf16 + a3d_group_norm_apply_bf16: partial sums of row shards, summed, must reproduce the fused
+    kernel (the frame-sharded 3-D GroupNorm of the motion modules)."""
+    x = rnd(B * rows, C, seed=C) + 0.5
+    gamma = 1 + 0.1 * rnd(C, seed=1, dtype=torch.float32)
+    beta = 0.1 * rnd(C, seed=2, dtype=torch.float32)
+    fused = ops.group_norm(x, B, rows, gamma, beta, 32, 1e-6, False)
+    rl = rows // shards
+    parts = [x.reshape(B, shards, rl, C)[:, r].reshape(B * rl, C).contiguous() for r in range(shards)]
+    sums = sum(ops.group_norm_sums(p_, B, rl, 32) for p_ in parts)
+    want_sums = ref.group_norm_sums(x, B, rows, 32)
+    torch.testing.assert_close(sums, want_sums, rtol=1e-6, atol=1e-6)
+    cnt = float(rows * (C // 32))
+    mean = sums[..., 0] / cnt
+    var = (sums[..., 1] / cnt - mean * mean).clamp_min(0.0)
+    stats = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-6)], dim=-1).float().contiguous()
+    for r, p_ in enumerate(parts):
+        got = ops.group_norm_apply(p_, B, rl, gamma, beta, 32, stats, False)
+        want = fused.reshape(B, shards, rl, C)[:, r].reshape(B * rl, C)
+        check(f"group_norm split shard {r}/{shards} C{C}", got, want, tol=4e-3, max_ulps=2)
+
 @pytest.mark.parametrize("B,rows,C", [(3, 64, 320), (2, 300, 640), (2, 256, 960), (1, 1000, 1280), (2, 64, 1920), (2, 16, 2560), (1, 4, 1280)])
 @pytest.mark.parametrize("silu", [False, True])
 def test_group_norm(ops, ref, B, rows, C, silu):

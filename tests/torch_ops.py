@@ -102,16 +102,34 @@ class TorchRefOps:
             res[flat] = self._o(o.reshape(-1, C))
         return res
 
-    def temporal_attn(self, q, k, v, videos, frames, L, heads):
+    def temporal_attn(self, q, k, v, videos, frames, L, heads, *, q_f0=0, q_frames=None):
         C = q.shape[1]
         D = C // heads
+        fq = frames if q_frames is None else q_frames
 
-        def seq(t):     # [(v f) l, C] -> [v, l, heads, f, D]
-            return t.float().reshape(videos, frames, L, heads, D).permute(0, 2, 3, 1, 4)
+        def seq(t, f):     # [(v f) l, C] -> [v, l, heads, f, D]
+            return t.float().reshape(videos, f, L, heads, D).permute(0, 2, 3, 1, 4)
 
-        p = torch.softmax(seq(q) @ seq(k).transpose(-1, -2) * (D ** -0.5), dim=-1)
-        o = (p @ seq(v)).permute(0, 3, 1, 2, 4).reshape(videos * frames * L, C)
+        if fq != frames:   # k / v: [frames / fq blocks][videos, fq, L] -> (v f) l order
+            nb = frames // fq
+            k = k.reshape(nb, videos, fq, L, C).permute(1, 0, 2, 3, 4).reshape(videos * frames * L, C)
+            v = v.reshape(nb, videos, fq, L, C).permute(1, 0, 2, 3, 4).reshape(videos * frames * L, C)
+        p = torch.softmax(seq(q, fq) @ seq(k, frames).transpose(-1, -2) * (D ** -0.5), dim=-1)
+        o = (p @ seq(v, frames)).permute(0, 3, 1, 2, 4).reshape(videos * fq * L, C)
         return self._o(o)
+
+    def group_norm_sums(self, x, B, rows, groups):
+        C = x.shape[1]
+        t = x.double().reshape(B, rows, groups, C // groups)
+        return torch.stack([t.sum(dim=(1, 3)), (t * t).sum(dim=(1, 3))], dim=-1)
+
+    def group_norm_apply(self, x, B, rows, gamma, beta, groups, stats, silu):
+        C = x.shape[1]
+        t = x.float().reshape(B, rows, groups, C // groups)
+        y = ((t - stats[:, None, :, None, 0]) * stats[:, None, :, None, 1]).reshape(B * rows, C) * gamma.float() + beta.float()
+        if silu:
+            y = F.silu(y)
+        return self._o(y)
 
     def group_norm(self, x, B, rows, gamma, beta, groups, eps, silu):
         C = x.shape[1]
