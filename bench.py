@@ -3,20 +3,28 @@
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W [--layout cfg,views,frames]
 
 One "step" = one MVUNetMotionModel.forward on the CFG-doubled batch exactly as the reference pipeline
-issues it (pipeline.py:1008-1020): V = 2 x 4 views, 16 frames, 64x64 latent (512^2 images), bf16,
-synthetic seeded weights and inputs (no checkpoints / datasets exist offline).  Inputs are resident in
-HBM before the timed region.  For N > 1 the SAME job is sharded over the GPUs (CFG halves x views,
-animate3d_amd/parallel.py) => strong scaling; value = steps/s of the whole job.
+issues it (pipeline.py:1008-1020).  Default workload = BASELINE config 2 (the configuration the metric is quoted on):
+V = 2 x 4 views, 16 frames, 64x64 latent (512^2 images), bf16, synthetic seeded weights and inputs (no checkpoints /
+datasets exist offline).  ``--config 4`` (8 views x 32 frames x 64x64 latent) and ``--config 5`` (the 4D-SDS call:
+4 views x 16 frames x 32x32 latent) run the other single-GPU-sized BASELINE configurations through the same path.
+Inputs are resident in HBM before the timed region.  For N > 1 the SAME job is sharded over the GPUs (CFG halves x views x
+frames, animate3d_amd/parallel.py) => strong scaling; value = steps/s of the whole job.
 
 Rank 0 prints ONE JSON line.  It carries
-  roofline     — the dominant kernel (flash attention, head_dim 40, level-0 multi-view attention):
-                 algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
-                 launch stream inside the timed region, against the dense bf16 MFMA peak;
-  cpu_baseline — the CPU oracle (plain-PyTorch fp32 restatement of the reference forward; the reference
-                 itself cannot be imported offline) timed on this host on BASELINE config 1.
+  roofline     — the dominant kernel as rocprofv3 names it (flash_attn_il_kernel<2, 8, 0>: level-0 multi-view / first-frame
+                 attention, head_dim 40): algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
+                 launch stream inside the timed region, against the dense bf16 MFMA peak; ``ceilings`` adds the second
+                 ceiling that binds at head_dim 40 — the v_exp issue rate measured with tools/ubench_exp.hip — and ``traffic``
+                 the HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (read from
+                 profiles/r2_flash_pmc_traffic.json; null when that file does not describe this launch shape);
+  groups       — per kernel family (attention by head dim, GEMM, fused GEGLU GEMM, 3x3 conv, norms, ...): ms per step and
+                 achieved TFLOP/s or GB/s, from one extra instrumented forward OUTSIDE the timed region;
+  cpu_baseline — the CPU oracle (plain-PyTorch fp32 restatement of the reference forward; the reference itself cannot be
+                 imported offline) timed on this host on BASELINE config 1: seeded weights, 1 warm-up + up to 3 timed forwards
+                 inside a time budget, thread count chosen by a 2-second matmul probe over the CPUs this process may use.
 """
 import argparse
 import json
@@ -30,10 +38,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# HBM traffic of one level-0 attention launch (PMC, not measurable from inside the process): see profiles/r1_flash_pmc_traffic.md
-METRIC = "UNet denoise-steps/sec, 4view\u00d716frame\u00d7512\u00b2 MV-VDM @1/2/4/8 GPU"     # BASELINE.json, verbatim
-TRAFFIC_BYTES_PER_LAUNCH = 2.82e9
+METRIC = "UNet denoise-steps/sec, 4view×16frame×512² MV-VDM @1/2/4/8 GPU"     # BASELINE.json, verbatim
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 GB/s achievable (MI355X_MICROARCH.md)
+# v_exp_f32 issue rate next to the kernel's own MFMA / v_cvt_pk / v_max3 mix, two waves per SIMD (tools/ubench_exp.hip,
+# profiles/r2_ubench_exp.log): 8.5e12 exp/s chip-wide; every score costs one exp and 4 * head_dim MFMA FLOPs
+EXP_PER_S_IN_MIX = 8.5e12
+DOMINANT_KERNEL = "flash_attn_il_kernel<2, 8, 0>"
+
+CONFIGS = {     # BASELINE.json configs that fit one GPU: (views, frames, latent, label)
+    2: (4, 16, 64, "BASELINE config 2: 4 views x 16 frames x 512^2 px (64x64 latent)"),
+    4: (8, 32, 64, "BASELINE config 4 on ONE GPU: 8 views x 32 frames x 512^2 px (64x64 latent)"),
+    5: (4, 16, 32, "BASELINE config 5 (UNet call of one 4D-SDS step): 4 views x 16 frames x 256^2 px (32x32 latent)"),
+}
 
 
 def make_inputs(cfg, V, n, F, hw, device, seed=1):
@@ -51,18 +68,68 @@ def make_inputs(cfg, V, n, F, hw, device, seed=1):
 
 
 class TimedOps:
-    """Delegates to HipOps; brackets every launch of the dominant kernel with HIP events on the stream
-    the kernel is launched on (torch's current stream == the stream handed to the C-ABI)."""
+    """Delegates to HipOps.  ``enabled``: brackets every launch of the dominant kernel with HIP events on the stream the
+    kernel is launched on (torch's current stream == the stream handed to the C-ABI).  ``profile``: brackets EVERY op and
+    books duration + algorithmic work per kernel family (used for one extra forward outside the timed region)."""
 
     def __init__(self, ops, head_dim, min_kv):
         self._ops, self._hd, self._min_kv = ops, head_dim, min_kv
         self.events, self.flops, self.enabled = [], [], False
+        self.profile, self.records = False, []
 
     def __getattr__(self, name):
-        return getattr(self._ops, name)
+        fn = getattr(self._ops, name)
+        if not (self.profile and callable(fn)) or name.startswith("_") or name in ("empty", "interleave_geglu"):
+            return fn
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.records.append((self._family(name, a, k), e0, e1, self._work(name, a, k, out)))
+            return out
+        return timed
+
+    @staticmethod
+    def _family(name, a, k):
+        if name == "gemm":
+            return "gemm"
+        if name == "conv3x3":
+            return "conv3x3 (nearest-2x up)" if k.get("up2x") else "conv3x3"
+        return name
+
+    @staticmethod
+    def _work(name, a, k, out):
+        """(flops, bytes) of one call: algorithmic — operands read once, result written once."""
+        by = lambda *ts: float(sum(t.numel() * t.element_size() for t in ts if torch.is_tensor(t)))
+        if name in ("gemm", "gemm_geglu", "gemm_f32out"):
+            x, w = a[0], a[1]
+            return 2.0 * x.shape[0] * w.shape[0] * x.shape[1], by(x, w, out, k.get("residual"))
+        if name == "conv3x3":
+            x, B, H, W, w = a[:5]
+            y = out[0]
+            return 2.0 * y.shape[0] * w.shape[0] * w.shape[1], by(x, w, y, k.get("residual"))
+        if name == "temporal_attn":
+            q, kk, v, videos, frames, L, heads = a[:7]
+            return 4.0 * frames * q.shape[0] * q.shape[1], by(q, kk, v, out)
+        if name in ("group_norm", "group_norm_apply"):
+            return 0.0, 3.0 * by(a[0])            # statistics pass + apply pass read, one write
+        if name == "layer_norm":
+            return 0.0, by(a[0]) * (3.0 if k.get("two") else 2.0)
+        return 0.0, by(*a) + (by(out) if torch.is_tensor(out) else 0.0)
 
     def flash_attn(self, q, k, v, qmap, kmap, groups, heads, q_len, kv_len, **kw):
         D = q.shape[1] // heads
+        work = 4.0 * groups * q_len * kv_len * heads * D             # QK^T + PV, 1 MAC = 2 FLOP
+        if self.profile:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._ops.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, **kw)
+            e1.record()
+            fam = f"flash_attn D={D}" + (" (cross: text / IP tokens)" if kv_len <= 128 else "")
+            self.records.append((fam, e0, e1, (work, 0.0)))
+            return out
         if not (self.enabled and D == self._hd and kv_len >= self._min_kv):
             return self._ops.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,35 +137,99 @@ class TimedOps:
         out = self._ops.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, **kw)
         e1.record()
         self.events.append((e0, e1))
-        self.flops.append(4.0 * groups * q_len * kv_len * heads * D)     # QK^T + PV, 1 MAC = 2 FLOP
+        self.flops.append(work)
+        return out
+
+    def group_summary(self):
+        agg = {}
+        for fam, e0, e1, (fl, by) in self.records:
+            d = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl; d[3] += by
+        out = {}
+        for fam, (cnt, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            rec = {"launches": cnt, "ms": round(ms, 3)}
+            if fl > 0:
+                rec["tflops"] = round(fl / ms / 1e9, 1)
+            if by > 0 and fl == 0:
+                rec["gbs"] = round(by / ms / 1e6, 0)
+            out[fam] = rec
         return out
 
 
-def cpu_baseline(threads):
-    """Bounded CPU sample: the oracle (plain-PyTorch fp32 restatement of the reference forward) on
-    BASELINE config 1 (1 view x 4 frames x 64x64 latent = 512^2 px, fp32, no CFG; 6.45 TFLOP), one forward timed on
-    `threads` host threads (about 15 s).  The config-2 figure is a FLOP-ratio extrapolation."""
+def _usable_cpus():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                            # cgroup v2 quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def _pick_threads(limit):
+    """Fastest thread count for fp32 GEMM on this host among a few candidates (2-second probe): more threads than the box can
+    actually run is slower, and os.cpu_count() over-reports inside containers."""
+    cands = sorted({t for t in (8, 16, 32, 64, 128, 256) if t <= limit} | {min(limit, 256)})
+    a, b = torch.randn(2048, 2048), torch.randn(2048, 2048)
+    best, best_t, seen = cands[0], float("inf"), {}
+    for t in cands:
+        torch.set_num_threads(t)
+        a @ b
+        t0 = time.perf_counter()
+        a @ b
+        a @ b
+        dt = (time.perf_counter() - t0) / 2
+        seen[t] = round(2 * 2048 ** 3 / dt / 1e9, 1)
+        if dt < best_t * 0.95:
+            best, best_t = t, dt
+        if dt > 3 * best_t:
+            break
+    return best, seen
+
+
+def cpu_baseline(threads, budget_s=75.0):
+    """Bounded CPU sample: the oracle (plain-PyTorch fp32 restatement of the reference forward) on BASELINE config 1
+    (1 view x 4 frames x 64x64 latent = 512^2 px, fp32, no CFG; 6.45 TFLOP): seeded weights, 1 warm-up + up to 3 timed
+    forwards, stopping when the time budget is used.  The config-2 figure is a FLOP-ratio extrapolation."""
     from animate3d_amd.config import UNetConfig
     from animate3d_amd.flops import step_flops
     from oracle import unet_ref as O
+    usable = _usable_cpus()
+    probe = None
+    if not threads:
+        threads, probe = _pick_threads(usable)
     torch.set_num_threads(threads)
     cfg = O.UNetConfig()
     hw = (64, 64)
-    ref = O.build_fast(cfg, 1, 4, hw, seed=None)      # constant weights: timing only
+    ref = O.build_fast(cfg, 1, 4, hw, seed=0)
     inp = O.synthetic_inputs(cfg, 1, 1, 4, hw, seed=1)
-    t0 = time.time()
-    ref(**inp)
-    dt = time.time() - t0
-    f_sample = step_flops(UNetConfig(), 1, 1, 4, *hw)["total"]
+    t_all = time.time()
+    t0 = time.time(); ref(**inp); warm = time.time() - t0
+    runs = []
+    while len(runs) < 3 and (not runs or (time.time() - t_all) + min(runs) < budget_s):
+        t0 = time.time(); ref(**inp); runs.append(time.time() - t0)
+    dt = min(runs)
     f_cfg1 = step_flops(UNetConfig(), 1, 1, 4, 64, 64)["total"]
     f_cfg2 = step_flops(UNetConfig(), 8, 4, 16, 64, 64)["total"]
     return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
-            "sample": f"1 forward of BASELINE config 1: 1 view x 4 frames x 64x64 latent, fp32, no CFG ({f_sample / 1e12:.2f} TFLOP/step); "
-                      f"CPU oracle = plain-PyTorch restatement of the reference forward "
-                      f"(the reference itself needs diffusers/xformers, absent offline); host has {os.cpu_count()} logical CPUs",
-            "seconds_per_step": dt, "tflops": f_sample / dt / 1e12,
-            "config1_equivalent_steps_per_s": (1.0 / dt) * f_sample / f_cfg1,
-            "config2_equivalent_steps_per_s": (1.0 / dt) * f_sample / f_cfg2}
+            "sample": f"BASELINE config 1: 1 view x 4 frames x 64x64 latent, fp32, no CFG ({f_cfg1 / 1e12:.2f} TFLOP/step); seeded weights, "
+                      f"1 warm-up ({warm:.1f} s) + {len(runs)} timed forwards (best of {[round(r, 1) for r in runs]} s); CPU oracle = "
+                      f"plain-PyTorch restatement of the reference forward (the reference itself needs diffusers/xformers, absent "
+                      f"offline); host reports {os.cpu_count()} logical CPUs, {usable} usable by this process",
+            "thread_probe_gflops": probe, "seconds_per_step": dt, "tflops": f_cfg1 / dt / 1e12,
+            "config2_equivalent_steps_per_s": (1.0 / dt) * f_cfg1 / f_cfg2}
+
+
+def _pmc_traffic(S0, groups):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass, if it matches this launch shape."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_flash_pmc_traffic.json")))
+        if rec.get("kernel") == DOMINANT_KERNEL and rec.get("kv_len") == S0 and rec.get("groups") == groups:
+            return rec
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -106,11 +237,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--views", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (default 2: the one the metric is quoted on)")
+    ap.add_argument("--views", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--latent", type=int, default=0)
+    ap.add_argument("--layout", type=str, default="", help="multi-GPU: cfg,views,frames shard counts (default: CFG halves, then views, then frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default min(host CPUs, 16))")
+    ap.add_argument("--no-groups", action="store_true", help="skip the instrumented forward behind the 'groups' object")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,16 +264,22 @@ def main():
     from animate3d_amd.unet import MVUNetMotionModel
 
     cfg = UNetConfig()
-    n, F, hw = args.views, args.frames, (args.latent, args.latent)
+    n0, F0, lat0, label = CONFIGS[args.config]
+    n, F, lat = args.views or n0, args.frames or F0, args.latent or lat0
+    hw = (lat, lat)
+    if (n, F, lat) != (n0, F0, lat0):
+        label = f"custom: {n} views x {F} frames x {lat * 8}^2 px ({lat}x{lat} latent)"
     V = 2 * n
     S0 = n * hw[0] * hw[1]
-    ops = TimedOps(HipOps(dev), head_dim=cfg.block_out_channels[0] // cfg.num_attention_heads, min_kv=S0 if world == 1 else S0)
+    ops = TimedOps(HipOps(dev), head_dim=cfg.block_out_channels[0] // cfg.num_attention_heads, min_kv=S0)
     model = MVUNetMotionModel(cfg, ops=ops, num_views=n, device=dev)
     model.init_synthetic(seed=0)
     model = model.to(torch.bfloat16).eval()
+    par = None
     if world > 1:
         from animate3d_amd.parallel import shard_unet
-        shard_unet(model)
+        layout = tuple(int(v) for v in args.layout.split(",")) if args.layout else None
+        par = shard_unet(model, layout=layout, shape=(V // n, n, F))
     inp = make_inputs(cfg, V, n, F, hw, dev)
 
     def sync():
@@ -147,39 +287,87 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(k):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = model(**inp).sample
+        sync()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = tmax.item()
+        return dt_, out
+
     for _ in range(args.warmup):
         model(**inp)
+    if par is not None:
+        par.gather_bytes = par.collectives = 0
     ops.enabled = True
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = model(**inp).sample
-    sync()
-    dt = time.perf_counter() - t0
+    dt, y = timed_steps(args.steps)
     ops.enabled = False
     assert torch.isfinite(y).all()
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
 
     # dominant kernel, measured live with HIP events on the launch stream
     durs = [a.elapsed_time(b) * 1e-3 for a, b in ops.events]
+    roofline = None
     if durs:
         mean_dur = sum(durs) / len(durs)
         flops = sum(ops.flops) / len(ops.flops)
         achieved = flops / mean_dur / 1e12
-        roofline = {"bound": "mfma", "kernel": "flash_attn_kernel<40,64> (level-0 multi-view / first-frame attention)",
+        D = ops._hd
+        exp_ceiling = EXP_PER_S_IN_MIX * 4.0 * D / 1e12
+        pmc = _pmc_traffic(S0, (V // n) * F) if world == 1 else None
+        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (level-0 multi-view / first-frame attention, head_dim 40)",
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                    "traffic": TRAFFIC_BYTES_PER_LAUNCH if world == 1 else None, "traffic_unit": "HBM bytes per launch",
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2: gfx950 counts 128-B requests as 64 B) and WRITE_SIZE, separate "
-                                      "passes, same launch shape (profiles/r1_flash_pmc_traffic.md); algorithmic bytes 1.34e9",
+                    "ceilings": {"mfma_dense_bf16_tflops": PEAK_BF16_TFLOPS,
+                                 "mfma_after_padding_tflops": round(PEAK_BF16_TFLOPS * 655360 / 917504, 1),
+                                 "exp_issue_tflops_equivalent": round(exp_ceiling, 1), "frac_of_exp_ceiling": achieved / exp_ceiling,
+                                 "note": "head_dim 40: one v_exp_f32 per 160 MFMA FLOPs and 29 % of the issued MFMA work is padding (QK^T contraction "
+                                         "40->48, O^T rows 41->64); the exp ceiling is the v_exp rate measured next to this kernel's MFMA / cvt / max mix "
+                                         "(tools/ubench_exp.hip); the kernel is also clock-limited by power (zero inputs run 22-29 % faster)"},
+                    "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
+                    "traffic_source": (pmc or {}).get("source", "no committed PMC pass for this launch shape"),
+                    "algorithmic_bytes_per_launch": 4.0 * (V // n) * F * S0 * D * 8 * 2,      # Q, K, V read + O written once, bf16
                     "launches_per_step": len(durs) // args.steps, "mean_launch_ms": mean_dur * 1e3,
                     "flop_per_launch": flops, "share_of_step_time": sum(durs) / dt}
-    else:
-        roofline = None
+
+    comm = None
+    if par is not None:      # exposed communication = step time with the data-path collectives replaced by local copies
+        comm = {"layout": {"cfg": par.cfg_shards, "views": par.view_shards, "frames": par.frame_shards},
+                "received_bytes_per_rank_per_step": par.gather_bytes / args.steps, "collectives_per_step": par.collectives / args.steps}
+        import torch.distributed as dist_
+        real = (dist_.all_gather_into_tensor, dist_.broadcast, dist_.all_reduce)
+
+        class _Done:
+            def wait(self):
+                return True
+
+        def fake_gather(out, t, group=None, async_op=False):
+            if group is None:                       # the final output gather stays real
+                return real[0](out, t, group=group, async_op=async_op)
+            out.view(-1, *t.shape)[:] = t
+            return _Done() if async_op else None
+        dist_.all_gather_into_tensor = fake_gather
+        dist_.broadcast = lambda buf, src, group=None: None
+        dist_.all_reduce = lambda t, op=None, group=None: (real[2](t, op=op, group=group) if group is None else None)
+        try:
+            dry, _ = timed_steps(max(1, min(args.steps, 3)))
+        finally:
+            dist_.all_gather_into_tensor, dist_.broadcast, dist_.all_reduce = real
+        comm["ms_per_step_without_collectives"] = dry / max(1, min(args.steps, 3)) * 1e3
+        comm["exposed_communication_ms_per_step"] = ms_per_step - comm["ms_per_step_without_collectives"]
+
+    groups = None
+    if not args.no_groups:
+        ops.profile = True
+        model(**inp)
+        torch.cuda.synchronize()
+        ops.profile = False
+        groups = ops.group_summary()
 
     if rank == 0:
         from animate3d_amd.flops import step_flops
@@ -188,17 +376,22 @@ def main():
             "metric": METRIC, "value": value, "unit": "denoise-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: {n} views x {F} frames x {hw[0] * 8}^2 px ({hw[0]}x{hw[1]} latent), CFG-doubled "
-                                   f"batch V={V} videos, one MVUNetMotionModel.forward per step, SD1.5 MV-VDM UNet 1.53 B params, "
-                                   "seeded synthetic weights",
-                       "parallelism": "single GPU" if world == 1 else f"cfg{model.parallel.cfg_shards} x views{model.parallel.view_shards} (K|V all-gather over RCCL)"},
-            "config2_25_ddim_steps_seconds": 25.0 * ms_per_step / 1e3,
+            "config": {"workload": f"{label}, CFG-doubled batch V={V} videos, one MVUNetMotionModel.forward per step, SD1.5 MV-VDM UNet "
+                                   "1.53 B params, seeded synthetic weights",
+                       "parallelism": "single GPU" if world == 1 else
+                       f"cfg{par.cfg_shards} x views{par.view_shards} x frames{par.frame_shards} (token / K|V all-gathers over RCCL)"},
             "flop_per_step": work, "whole_step_tflops": work * value / 1e12,
             "whole_step_mfma_frac": work * value / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roofline,
         }
+        if args.config == 2 and (n, F, lat) == (n0, F0, lat0):
+            line["config2_25_ddim_steps_seconds"] = 25.0 * ms_per_step / 1e3
+        if groups is not None:
+            line["groups"] = groups
+        if comm is not None:
+            line["communication"] = comm
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(os.cpu_count() or 1, 16))
+            line["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
