@@ -44,29 +44,34 @@ def _digest(path: str) -> str:
     return h.hexdigest()
 
 
+# every kernel source is compiled twice: bf16 storage (as is) and IEEE fp16 storage (-DA3D_STORAGE_F16: the a3d_*_f16 entry points)
+STORAGE_VARIANTS = (("", []), ("_f16", ["-DA3D_STORAGE_F16"]))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     objs, jobs = [], []
     for src in sources():
-        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-        stamp = obj + ".sha"
-        dig = _digest(src)
-        objs.append(obj)
-        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig)
-        if not fresh:
-            jobs.append((src, obj, stamp, dig))
+        for suffix, defs in STORAGE_VARIANTS:
+            obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + suffix + ".o")
+            stamp = obj + ".sha"
+            dig = _digest(src) + suffix
+            objs.append(obj)
+            fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig)
+            if not fresh:
+                jobs.append((src, obj, stamp, dig, defs))
 
     def compile_one(job):
-        src, obj, stamp, dig = job
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        src, obj, stamp, dig, defs = job
+        cmd = [hipcc, *FLAGS, *defs, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[a3d build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         with open(stamp, "w") as f:
             f.write(dig)
 
-    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(10, max(1, len(jobs)))) as ex:
         list(ex.map(compile_one, jobs))
     if jobs or force or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB]
@@ -81,14 +86,20 @@ def build_experiment(macro: str, verbose: bool = True) -> str:
     expdir = os.path.join(LIBDIR, "exp", macro)
     os.makedirs(expdir, exist_ok=True)
     hipcc = _hipcc()
-    objs = []
+    objs, cmds = [], []
     for src in sources():
-        obj = os.path.join(expdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, "-D" + macro, "-c", src, "-o", obj]
+        for suffix, defs in STORAGE_VARIANTS:
+            obj = os.path.join(expdir, os.path.basename(src)[:-4] + suffix + ".o")
+            cmds.append([hipcc, *FLAGS, *defs, "-D" + macro, "-c", src, "-o", obj])
+            objs.append(obj)
+
+    def run(cmd):
         if verbose:
             print("[a3d build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+
+    with ThreadPoolExecutor(max_workers=10) as ex:
+        list(ex.map(run, cmds))
     lib = os.path.join(LIBDIR, "exp", f"libanimate3d_hip_{macro}.so")
     subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", lib], check=True)
     return lib

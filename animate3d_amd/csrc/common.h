@@ -1,36 +1,70 @@
 // Shared device helpers for the gfx950 kernels of libanimate3d_hip.so.
-// Wave = 64 lanes; MFMA shape used throughout: v_mfma_f32_32x32x16_bf16.
+// Wave = 64 lanes; MFMA shape used throughout: v_mfma_f32_32x32x16_{bf16,f16}.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/animate3d_hip.h"
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 #define A3D_DEV static __device__ __forceinline__
 
-// bf16 <-> f32 (round-to-nearest-even on the way down, as torch does)
-A3D_DEV float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// ---- the 16-bit activation / weight type of this build of the kernels
+// Every kernel source is compiled twice (animate3d_amd/build.py): as is for bf16 storage and with -DA3D_STORAGE_F16 for IEEE fp16
+// storage (the dtype the reference's 4D-SDS caller runs the UNet in, animatemv_guidance.py:339-346).  Arithmetic is the same
+// in both: fp32 accumulation, statistics and softmax; only the load / store conversions, the MFMA opcode
+// (v_mfma_f32_32x32x16_bf16 / _f16), the packed dot product of the temporal attention and the bit pattern of 1.0 differ.
+// A3D_FN(name) appends the storage suffix to an entry-point name: a3d_gemm_bf16 / a3d_gemm_f16.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two values per instruction
-A3D_DEV uint32_t pack2bf(float lo, float hi) {
+#ifdef A3D_STORAGE_F16
+#define A3D_FN(base) base##_f16
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+constexpr uint16_t ONE16 = 0x3C00;       // 1.0
+A3D_DEV float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// v_cvt_pk_f16_f32: round-to-nearest-even, two values per instruction
+A3D_DEV uint32_t pack16(float lo, float hi) {
   const f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2_t));
 }
-A3D_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
-A3D_DEV float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
-A3D_DEV float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+A3D_DEV float lo16(uint32_t w) { return (float)__builtin_bit_cast(h16x2_t, w)[0]; }
+A3D_DEV float hi16(uint32_t w) { return (float)__builtin_bit_cast(h16x2_t, w)[1]; }
+#else
+#define A3D_FN(base) base##_bf16
+typedef __bf16 h16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 h16x2_t __attribute__((ext_vector_type(2)));
+constexpr uint16_t ONE16 = 0x3F80;       // 1.0
+// bf16 <-> f32 (round-to-nearest-even on the way down, as torch does)
+A3D_DEV float h2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two values per instruction
+A3D_DEV uint32_t pack16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2_t));
+}
+A3D_DEV float lo16(uint32_t w) { return __uint_as_float(w << 16); }
+A3D_DEV float hi16(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+A3D_DEV uint16_t f2h(float f) { return (uint16_t)(pack16(f, 0.f) & 0xffffu); }
+// caller-side bf16 tensors at the boundary kernels (im2col_in / unpack_out): always bf16, whatever the storage type of the build
+A3D_DEV float bfbits2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+A3D_DEV uint16_t f2bfbits(float f) {
+  typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {f, 0.f};
+  return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, bfx2)) & 0xffffu);
+}
 
-// MFMA 32x32x16 bf16.  Lane l supplies A[i = l&31][k-slots of group l>>5] and
+// MFMA 32x32x16 (bf16 or fp16 inputs, fp32 accumulate).  Lane l supplies A[i = l&31][k-slots of group l>>5] and
 // B[k-slots of group l>>5][j = l&31] (8 bf16 each); the result register r of lane l is
 // D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
 A3D_DEV f32x16_t mfma32(const u32x4_t& a, const u32x4_t& b, const f32x16_t& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#ifdef A3D_STORAGE_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#endif
 }
 // row index inside a 32x32 MFMA result for register r of a lane in half g = lane>>5
 A3D_DEV int mfma_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }

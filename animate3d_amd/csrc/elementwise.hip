@@ -21,13 +21,13 @@ __global__ void geglu_kernel(const uint16_t* X, int64_t ldx, uint16_t* Y, int64_
     float y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float hv = (j & 1) ? hi_bf(h[j >> 1]) : lo_bf(h[j >> 1]);
-      const float gv = (j & 1) ? hi_bf(gt[j >> 1]) : lo_bf(gt[j >> 1]);
+      const float hv = (j & 1) ? hi16(h[j >> 1]) : lo16(h[j >> 1]);
+      const float gv = (j & 1) ? hi16(gt[j >> 1]) : lo16(gt[j >> 1]);
       y[j] = hv * (0.5f * gv * (1.f + erff(gv * 0.70710678118654752f)));
     }
     u32x4_t o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack2bf(y[2 * j], y[2 * j + 1]);
+    for (int j = 0; j < 4; ++j) o[j] = pack16(y[2 * j], y[2 * j + 1]);
     *reinterpret_cast<u32x4_t*>(Y + m * ldy + c * 8) = o;
   }
 }
@@ -38,8 +38,8 @@ __global__ void silu_kernel(const uint16_t* X, uint16_t* Y, int64_t n8) {
     u32x4_t o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = lo_bf(v[j]), b = hi_bf(v[j]);
-      o[j] = pack2bf(a / (1.f + __expf(-a)), b / (1.f + __expf(-b)));
+      const float a = lo16(v[j]), b = hi16(v[j]);
+      o[j] = pack16(a / (1.f + __expf(-a)), b / (1.f + __expf(-b)));
     }
     *reinterpret_cast<u32x4_t*>(Y + i * 8) = o;
   }
@@ -61,15 +61,15 @@ __global__ void timestep_kernel(const float* t, uint16_t* Y, int V, int dim) {
   const int v = i / half, j = i % half;
   const float freq = expf(-9.210340371976184f * (float)j / (float)half);   // ln(10000)
   const float a = t[v] * freq;
-  Y[(int64_t)v * dim + j] = f2bf(cosf(a));
-  Y[(int64_t)v * dim + half + j] = f2bf(sinf(a));
+  Y[(int64_t)v * dim + j] = f2h(cosf(a));
+  Y[(int64_t)v * dim + half + j] = f2h(sinf(a));
 }
 
 A3D_DEV float ld_f32(const float* p, int64_t i) { return p[i]; }
-A3D_DEV float ld_f32(const uint16_t* p, int64_t i) { return bf2f(p[i]); }
+A3D_DEV float ld_f32(const uint16_t* p, int64_t i) { return bfbits2f(p[i]); }      // caller tensor in bf16
 A3D_DEV float ld_f32(const _Float16* p, int64_t i) { return (float)p[i]; }
 A3D_DEV void st_f32(float* p, int64_t i, float v) { p[i] = v; }
-A3D_DEV void st_f32(uint16_t* p, int64_t i, float v) { p[i] = f2bf(v); }
+A3D_DEV void st_f32(uint16_t* p, int64_t i, float v) { p[i] = f2bfbits(v); }       // caller tensor in bf16
 A3D_DEV void st_f32(_Float16* p, int64_t i, float v) { p[i] = (_Float16)v; }
 
 // one thread per output pixel (v, f, y, x): gathers the 3x3xC patch from [V, C, F, H, W]
@@ -101,7 +101,7 @@ __global__ void im2col_in_kernel(const T* S, uint16_t* Y, int V, int C, int F, i
       }
       u32x4_t o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = pack2bf(fv[2 * j], fv[2 * j + 1]);
+      for (int j = 0; j < 4; ++j) o[j] = pack16(fv[2 * j], fv[2 * j + 1]);
       *reinterpret_cast<u32x4_t*>(dst + k8 * 8) = o;
     }
   }
@@ -117,7 +117,7 @@ __global__ void unpack_out_kernel(const uint16_t* X, T* Y, int V, int C, int F, 
     const int c = (int)((i / ((int64_t)W * H * F)) % C);
     const int v = (int)(i / ((int64_t)W * H * F * C));
     const int64_t row = (((int64_t)v * F + f) * H + y) * W + x;
-    st_f32(Y, i, bf2f(X[row * C + c]));
+    st_f32(Y, i, h2f(X[row * C + c]));
   }
 }
 
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* X, int64
   for (int c = lane * 4; c < N; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(x + c);
     u32x2_t o;
-    o[0] = pack2bf(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
-    o[1] = pack2bf(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+    o[0] = pack16(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv);
+    o[1] = pack16(__expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
     *reinterpret_cast<u32x2_t*>(Y + m * ldy + c) = o;
   }
 }
@@ -188,7 +188,17 @@ __global__ void channel_mix_kernel(const float* X, const float* Wm, const float*
 
 }  // namespace
 
-extern "C" int a3d_softmax_rows_f32_bf16(a3d_stream_t stream, const float* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {
+#ifdef A3D_STORAGE_F16
+#define A3D_SOFTMAX_ROWS a3d_softmax_rows_f32_f16
+#define A3D_IM2COL_IN a3d_im2col_in_f16
+#define A3D_UNPACK_OUT a3d_unpack_out_f16
+#else
+#define A3D_SOFTMAX_ROWS a3d_softmax_rows_f32_bf16
+#define A3D_IM2COL_IN a3d_im2col_in
+#define A3D_UNPACK_OUT a3d_unpack_out
+#endif
+
+extern "C" int A3D_SOFTMAX_ROWS(a3d_stream_t stream, const float* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {
   if (!X || !Y || M <= 0 || N <= 0 || N % 4 != 0 || N > 0x7fffffffLL || ldx % 4 != 0 || ldy % 4 != 0) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(X) & 15u) || (reinterpret_cast<uintptr_t>(Y) & 7u)) return A3D_EINVAL;
   const int64_t nblk = (M + 3) / 4;
@@ -197,44 +207,48 @@ extern "C" int a3d_softmax_rows_f32_bf16(a3d_stream_t stream, const float* X, in
   return a3d_launch_status();
 }
 
+#ifndef A3D_STORAGE_F16
 extern "C" int a3d_channel_mix_f32(a3d_stream_t stream, const float* X, const float* W, const float* bias, float* Y,
                                    int B, int Cin, int Cout, int64_t HW, float scale) {
   if (!X || !W || !Y || B <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > 8 || HW <= 0) return A3D_EINVAL;
   channel_mix_kernel<<<dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream>>>(X, W, bias, Y, B, Cin, Cout, HW, scale);
   return a3d_launch_status();
 }
+#endif
 
-extern "C" const char* a3d_version(void) { return "animate3d_hip gfx950 r1"; }
+#ifndef A3D_STORAGE_F16
+extern "C" const char* a3d_version(void) { return "animate3d_hip gfx950 r2 (bf16 + fp16 storage)"; }
+#endif
 
-extern "C" int a3d_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {
+extern "C" int A3D_FN(a3d_geglu)(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {
   if (!X || !Y || M <= 0 || N <= 0 || N % 8 || ldx % 8 || ldy % 8) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
   geglu_kernel<<<grid_for(M * (N / 8)), 256, 0, (hipStream_t)stream>>>((const uint16_t*)X, ldx, (uint16_t*)Y, ldy, M, N / 8);
   return a3d_launch_status();
 }
 
-extern "C" int a3d_silu_bf16(a3d_stream_t stream, const void* X, void* Y, int64_t n) {
+extern "C" int A3D_FN(a3d_silu)(a3d_stream_t stream, const void* X, void* Y, int64_t n) {
   if (!X || !Y || n <= 0 || n % 8) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
   silu_kernel<<<grid_for(n / 8), 256, 0, (hipStream_t)stream>>>((const uint16_t*)X, (uint16_t*)Y, n / 8);
   return a3d_launch_status();
 }
 
-extern "C" int a3d_concat_bf16(a3d_stream_t stream, const void* A, int64_t Ca, const void* Bsrc, int64_t Cb, void* Y, int64_t M) {
+extern "C" int A3D_FN(a3d_concat)(a3d_stream_t stream, const void* A, int64_t Ca, const void* Bsrc, int64_t Cb, void* Y, int64_t M) {
   if (!A || !Bsrc || !Y || M <= 0 || Ca <= 0 || Cb <= 0 || Ca % 8 || Cb % 8) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bsrc) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
   concat_kernel<<<grid_for(M * ((Ca + Cb) / 8)), 256, 0, (hipStream_t)stream>>>((const uint16_t*)A, Ca / 8, (const uint16_t*)Bsrc, Cb / 8, (uint16_t*)Y, M);
   return a3d_launch_status();
 }
 
-extern "C" int a3d_timestep_embed_bf16(a3d_stream_t stream, const float* t, void* Y, int V, int dim) {
+extern "C" int A3D_FN(a3d_timestep_embed)(a3d_stream_t stream, const float* t, void* Y, int V, int dim) {
   if (!t || !Y || V <= 0 || dim <= 0 || dim % 2) return A3D_EINVAL;
   const int total = V * (dim / 2);
   timestep_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, (uint16_t*)Y, V, dim);
   return a3d_launch_status();
 }
 
-extern "C" int a3d_im2col_in(a3d_stream_t stream, const void* sample, int dtype, void* Y, int V, int C, int F, int H, int W) {
+extern "C" int A3D_IM2COL_IN(a3d_stream_t stream, const void* sample, int dtype, void* Y, int V, int C, int F, int H, int W) {
   if (!sample || !Y || V <= 0 || C <= 0 || F <= 0 || H <= 0 || W <= 0 || 9 * C > 64) return A3D_EINVAL;
   const unsigned g = grid_for((int64_t)V * F * H * W);
   hipStream_t s = (hipStream_t)stream;
@@ -247,7 +261,7 @@ extern "C" int a3d_im2col_in(a3d_stream_t stream, const void* sample, int dtype,
   return a3d_launch_status();
 }
 
-extern "C" int a3d_unpack_out(a3d_stream_t stream, const void* X, void* Y, int dtype, int V, int C, int F, int H, int W) {
+extern "C" int A3D_UNPACK_OUT(a3d_stream_t stream, const void* X, void* Y, int dtype, int V, int C, int F, int H, int W) {
   if (!X || !Y || V <= 0 || C <= 0 || F <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
   const unsigned g = grid_for((int64_t)V * C * F * H * W);
   hipStream_t s = (hipStream_t)stream;
@@ -260,6 +274,7 @@ extern "C" int a3d_unpack_out(a3d_stream_t stream, const void* X, void* Y, int d
   return a3d_launch_status();
 }
 
+#ifndef A3D_STORAGE_F16
 extern "C" int a3d_cfg_ddim_step_f32(a3d_stream_t stream, const float* eps_pair, const float* x, const float* first_frame,
                                      float* x_prev, int64_t n, int C, int F, int64_t HW, float guidance,
                                      float alpha_t, float alpha_prev) {
@@ -270,3 +285,4 @@ extern "C" int a3d_cfg_ddim_step_f32(a3d_stream_t stream, const float* eps_pair,
       sqrtf(1.f - alpha_prev));
   return a3d_launch_status();
 }
+#endif

@@ -35,6 +35,13 @@
 
 #include "common.h"
 
+// tuning knobs shared by the bf16 and the fp16 build of this file (defined once, in the bf16 object)
+#ifdef A3D_STORAGE_F16
+extern int g_flash_variant;
+#else
+int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default dispatch, 5 = plain kernel only, 16 = ping-pong instead of interleaved (A/B timing)
+#endif
+
 namespace {
 
 constexpr int OFS_FMA = 0, OFS_PAD = 1, OFS_ACC = 2;
@@ -58,7 +65,7 @@ A3D_DEV int kperm(int i) {
   return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
 }
 
-A3D_DEV float bf16_round(float x) { return lo_bf(pack2bf(x, 0.f)); }
+A3D_DEV float round16(float x) { return lo16(pack16(x, 0.f)); }
 
 // VAR (tuning experiments, a3d_tune_flash): 1 = s_setprio(1) around MFMA groups, 2 = V fragments read before the
 // exps of their sub-tile, 4 = sched_group_barrier pattern {1 MFMA, 4 TRANS, 2 VALU} over the exp/PV section.
@@ -101,11 +108,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     for (int i = tid; i < 2 * BKV * (DK - D); i += 256) {
       const int b = i / (BKV * (DK - D)), rem = i % (BKV * (DK - D));
       const int c = rem % (DK - D);
-      Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + c] = (OFS == OFS_PAD && c == 0) ? 0x3F80 : 0;
+      Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + c] = (OFS == OFS_PAD && c == 0) ? ONE16 : 0;
     }
   }
   if constexpr (ONES) {
-    for (int i = tid; i < 2 * BKV; i += 256) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = 0x3F80;   // bf16 1.0
+    for (int i = tid; i < 2 * BKV; i += 256) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = ONE16;   // bf16 1.0
   }
 
   // ---- Q^T fragments: lane (q = l31, half g) holds Q[q][16*ks + 8*g .. +7] for each of its QT queries
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         u32x4_t w = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + d0);
         if constexpr (OFS != OFS_FMA) {      // fold scale * log2(e) into Q once
 #pragma unroll
-          for (int j = 0; j < 4; ++j) w[j] = pack2bf(lo_bf(w[j]) * p.scale_log2, hi_bf(w[j]) * p.scale_log2);
+          for (int j = 0; j < 4; ++j) w[j] = pack16(lo16(w[j]) * p.scale_log2, hi16(w[j]) * p.scale_log2);
         }
         qf[qs][ks] = w;
       } else {
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
           float delta = first ? mxp : fmaxf(mxp, 0.f);
           float new_off = m_off[qs] + delta;
-          if constexpr (OFS == OFS_PAD) { new_off = bf16_round(new_off); delta = new_off - m_off[qs]; }
+          if constexpr (OFS == OFS_PAD) { new_off = round16(new_off); delta = new_off - m_off[qs]; }
           m_off[qs] = new_off;
 #pragma unroll
           for (int u = 0; u < NU; ++u)
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
               for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
           }
           if constexpr (OFS == OFS_PAD) {
-            if (g == G_PAD) qf[qs][KS_PAD][0] = pack2bf(-new_off, 0.f);     // contraction slot D carries -offset
+            if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);     // contraction slot D carries -offset
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) minit[qs][r] = -new_off;
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pf[qs][h][j] = pack2bf(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
+          for (int j = 0; j < 4; ++j) pf[qs][h][j] = pack16(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
       }
       if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -476,11 +483,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv;
             if (p.accumulate) {
               const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
-              v[0] += lo_bf(prev[0]); v[1] += hi_bf(prev[0]); v[2] += lo_bf(prev[1]); v[3] += hi_bf(prev[1]);
+              v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
             }
             u32x2_t o;
-            o[0] = pack2bf(v[0], v[1]);
-            o[1] = pack2bf(v[2], v[3]);
+            o[0] = pack16(v[0], v[1]);
+            o[1] = pack16(v[2], v[3]);
             *reinterpret_cast<u32x2_t*>(orow + d) = o;
           }
         }
@@ -532,9 +539,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
   for (int i = tid; i < 2 * BKV * (DK - D); i += 512) {
     const int b = i / (BKV * (DK - D)), rem = i % (BKV * (DK - D));
     const int c = rem % (DK - D);
-    Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + c] = (c == 0) ? 0x3F80 : 0;
+    Ks0[b * KS_ELEMS + (rem / (DK - D)) * KROW + D + c] = (c == 0) ? ONE16 : 0;
   }
-  for (int i = tid; i < 3 * BKV; i += 512) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = 0x3F80;
+  for (int i = tid; i < 3 * BKV; i += 512) Vt0[(i / BKV) * VT_ELEMS + D * VROW + (i % BKV)] = ONE16;
 
   // ---- Q^T fragments (pre-scaled), two 32-query sub-tiles per wave
   int q_idx[QT];
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
       if (d0 < D) {
         u32x4_t w = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + d0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack2bf(lo_bf(w[j]) * p.scale_log2, hi_bf(w[j]) * p.scale_log2);
+        for (int j = 0; j < 4; ++j) w[j] = pack16(lo16(w[j]) * p.scale_log2, hi16(w[j]) * p.scale_log2);
         qf[qs][ks] = w;
       } else {
         qf[qs][ks] = u32x4_t{0u, 0u, 0u, 0u};
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
       if (__any(first || ((ABL & 2) == 0 && mx > LAZY_THR))) {
         const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
         float delta = first ? mxp : fmaxf(mxp, 0.f);
-        const float new_off = bf16_round(m_off[qs] + delta);
+        const float new_off = round16(m_off[qs] + delta);
         delta = new_off - m_off[qs];
         m_off[qs] = new_off;
 #pragma unroll
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
         }
-        if (g == G_PAD) qf[qs][KS_PAD][0] = pack2bf(-new_off, 0.f);
+        if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pf[qs][u][h][j] = pack2bf(e[8 * h + 2 * j], e[8 * h + 2 * j + 1]);
+          for (int j = 0; j < 4; ++j) pf[qs][u][h][j] = pack16(e[8 * h + 2 * j], e[8 * h + 2 * j + 1]);
         if constexpr ((ABL & 32) != 0) {     // experiment: pair every two v_exp with the v_cvt_pk of the previous pair
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -785,11 +792,11 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
             for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv;
             if (p.accumulate) {
               const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
-              v[0] += lo_bf(prev[0]); v[1] += hi_bf(prev[0]); v[2] += lo_bf(prev[1]); v[3] += hi_bf(prev[1]);
+              v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
             }
             u32x2_t o;
-            o[0] = pack2bf(v[0], v[1]);
-            o[1] = pack2bf(v[2], v[3]);
+            o[0] = pack16(v[0], v[1]);
+            o[1] = pack16(v[2], v[3]);
             *reinterpret_cast<u32x2_t*>(orow + d) = o;
           }
         }
@@ -863,8 +870,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
   const int64_t hoff = (int64_t)head * D;
 
   // one-time LDS init: K columns 40..47 = (1, 0, ..), V "dimensions" 40..47 = (1, 0, ..), 48..63 = 0
-  for (int i = tid; i < IL_NKB * BKV * 8; i += NT) Ks0[(i >> 3) * KROW + D + (i & 7)] = ((i & 7) == 0) ? 0x3F80 : 0;
-  for (int i = tid; i < IL_NVB * BKV * 24; i += NT) Vs0[(i / 24) * VPITCH + D + (i % 24)] = ((i % 24) == 0) ? 0x3F80 : 0;
+  for (int i = tid; i < IL_NKB * BKV * 8; i += NT) Ks0[(i >> 3) * KROW + D + (i & 7)] = ((i & 7) == 0) ? ONE16 : 0;
+  for (int i = tid; i < IL_NVB * BKV * 24; i += NT) Vs0[(i / 24) * VPITCH + D + (i % 24)] = ((i % 24) == 0) ? ONE16 : 0;
 
   // ---- Q^T fragments (pre-scaled by scale * log2 e)
   u32x4_t qf[QT][KS];
@@ -878,7 +885,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
       if (d0 < D) {
         u32x4_t w = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + d0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack2bf(lo_bf(w[j]) * p.scale_log2, hi_bf(w[j]) * p.scale_log2);
+        for (int j = 0; j < 4; ++j) w[j] = pack16(lo16(w[j]) * p.scale_log2, hi16(w[j]) * p.scale_log2);
         qf[qs][ks] = w;
       } else {
         qf[qs][ks] = u32x4_t{0u, 0u, 0u, 0u};
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
     auto do_cvt = [&](auto c_c) __attribute__((always_inline)) {
       constexpr int c = decltype(c_c)::value;
       constexpr int qs = c / 8, h = (c / 4) % 2, jj = c % 4;
-      if constexpr ((ABL & 128) == 0) pCur[qs][h][jj] = pack2bf(e[2 * c], e[2 * c + 1]);
+      if constexpr ((ABL & 128) == 0) pCur[qs][h][jj] = pack16(e[2 * c], e[2 * c + 1]);
       else pCur[qs][h][jj] = __float_as_uint(e[2 * c]) ^ __float_as_uint(e[2 * c + 1]);
     };
     uint64_t ballot = 0;
@@ -1089,7 +1096,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
           for (int h = 0; h < 2; ++h) pCur[qs][h] = u32x4_t{0u, 0u, 0u, 0u};
           const float mxp = fmaxf(mx[qs][0], __shfl_xor(mx[qs][0], 32));
           float delta = fmaxf(mxp, 0.f);
-          const float new_off = bf16_round(m_off[qs] + delta);
+          const float new_off = round16(m_off[qs] + delta);
           delta = new_off - m_off[qs];
           m_off[qs] = new_off;
           const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -1099,7 +1106,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
-          if (g == G_PAD) qf[qs][KS_PAD][0] = pack2bf(-new_off, 0.f);
+          if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);
         }
       }
     }
@@ -1124,11 +1131,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sA[qs][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float new_off = bf16_round(mx);
+      const float new_off = round16(mx);
       m_off[qs] = new_off;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sA[qs][r] -= new_off;
-      if (g == G_PAD) qf[qs][KS_PAD][0] = pack2bf(-new_off, 0.f);
+      if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const u32x4_t*>(Ksub + 32 * KROW + 16 * ks);    // K sub-tile 1
@@ -1198,11 +1205,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
             for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv;
             if (p.accumulate) {
               const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
-              v[0] += lo_bf(prev[0]); v[1] += hi_bf(prev[0]); v[2] += lo_bf(prev[1]); v[3] += hi_bf(prev[1]);
+              v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
             }
             u32x2_t o;
-            o[0] = pack2bf(v[0], v[1]);
-            o[1] = pack2bf(v[2], v[3]);
+            o[0] = pack16(v[0], v[1]);
+            o[1] = pack16(v[2], v[3]);
             *reinterpret_cast<u32x2_t*>(orow + d) = o;
           }
         }
@@ -1226,7 +1233,6 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld > 0 && m->ld % 8 == 0 && head_dim % 8 == 0;
 }
 
-int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default dispatch, 5 = plain kernel only, 16 = ping-pong instead of interleaved (A/B timing)
 
 template <int D, int BKV, int QT, int OFS, int VAR = 0>
 void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
@@ -1240,6 +1246,7 @@ void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
 
 extern int g_a3d_ta_pix;      // temporal_attn.hip
 
+#ifndef A3D_STORAGE_F16
 extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
 #ifdef A3D_EXP_FLASH80
@@ -1253,8 +1260,9 @@ extern "C" int a3d_tune_flash(int variant) {
   g_flash_variant = variant;
   return A3D_OK;
 }
+#endif
 
-extern "C" int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                                    const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                                    int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
                                    float scale, float out_scale, int accumulate) {

@@ -14,6 +14,24 @@
 // share the same A rows are neighbours => A is fetched from HBM once per XCD, W stays in L2).
 #include "common.h"
 
+// tuning knobs shared by the bf16 and the fp16 build of this file (defined once, in the bf16 object)
+#ifdef A3D_STORAGE_F16
+extern int g_gemm_min_fill;
+extern int g_conv_chunk_major;
+extern int g_gemm_vm_counted;
+extern int g_gemm_persist;
+extern int g_gemm_bk;
+#else
+int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
+                              // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
+int g_conv_chunk_major = 1;  // a3d_tune_gemm(6): tap-major K walk of the 3x3 convs (round 1's order), (7): chunk-major (default since round 2:
+                             // +2-16 % on the level-0 / level-1 convs, profiles/r2_microbench_conv_korder.log; both kernels walk K the same way)
+int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
+int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
+                         // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
+int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -42,9 +60,8 @@ struct GemmParams {
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
-#ifdef A3D_EXP_CHUNK_MAJOR
-  int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
-#endif
+  int chunk_major;      // 3x3 conv: walk K as (64-channel chunk, tap) instead of (tap, chunk): the nine taps of a chunk re-use the
+                        // tile's input rows while they are still in L2 (HBM re-fetch 9.3x -> 1.8x, profiles/r1_gemm_conv_pmc_traffic.md)
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up, He, We;   // He x We: extent of the (virtual) upsampled image of the up2x conv
   int64_t tiles_n, tiles_m;
@@ -141,12 +158,10 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   RegTile rt0, rt1;     // two K-tiles in flight (prefetch distance 2)
   auto load_tile = [&](int64_t k0, RegTile& rt) {
     u32x4_t (&ra)[NPASS] = rt.a; u32x4_t (&rw)[NPASS] = rt.w;
-#ifdef A3D_EXP_CHUNK_MAJOR
     if (CONV == 1 && p.chunk_major) {       // same K walk as the persistent kernel: (64-channel chunk, tap, position in the chunk)
       const int64_t j = k0 >> 6, c = j / 9;
       k0 = (j - c * 9) * p.Cin + c * 64 + (k0 & 63);
     }
-#endif
     if constexpr (CONV != 0) {
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
         for (int e = 0; e < 8; ++e) y[e] = (hv[e] + bh[e]) * gelu_erf(gv[e] + bg[e]);
         u32x4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pack2bf(y[2 * e], y[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) o[e] = pack16(y[2 * e], y[2 * e + 1]);
         *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
       }
     }
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
           if (rb) {
             const u32x4_t t = *reinterpret_cast<const u32x4_t*>(rb);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(t[e]); v[2 * e + 1] += hi_bf(t[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += lo16(t[e]); v[2 * e + 1] += hi16(t[e]); }
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = epi_scale(v[e], p.alpha);
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
             if (rr) {
               const u32x4_t t = rres[j];            // prefetched (epf is true whenever this branch is taken)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo_bf(t[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi_bf(t[e])); }
+              for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo16(t[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi16(t[e])); }
             }
           }
           if (p.out_f32) {
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
           } else {
             u32x4_t o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) o[e] = pack16(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<u32x4_t*>(yy) = o;
           }
         } else {
@@ -367,18 +382,18 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
             float w[4] = {v[4 * hh], v[4 * hh + 1], v[4 * hh + 2], v[4 * hh + 3]};
             if (rb) {
               const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rb + 4 * hh);
-              w[0] += lo_bf(t[0]); w[1] += hi_bf(t[0]); w[2] += lo_bf(t[1]); w[3] += hi_bf(t[1]);
+              w[0] += lo16(t[0]); w[1] += hi16(t[0]); w[2] += lo16(t[1]); w[3] += hi16(t[1]);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = epi_scale(w[e], p.alpha);
             if (rr) {
               const u32x2_t t = *reinterpret_cast<const u32x2_t*>(rr + 4 * hh);
-              w[0] = epi_axpy(w[0], p.beta, lo_bf(t[0])); w[1] = epi_axpy(w[1], p.beta, hi_bf(t[0]));
-              w[2] = epi_axpy(w[2], p.beta, lo_bf(t[1])); w[3] = epi_axpy(w[3], p.beta, hi_bf(t[1]));
+              w[0] = epi_axpy(w[0], p.beta, lo16(t[0])); w[1] = epi_axpy(w[1], p.beta, hi16(t[0]));
+              w[2] = epi_axpy(w[2], p.beta, lo16(t[1])); w[3] = epi_axpy(w[3], p.beta, hi16(t[1]));
             }
             u32x2_t o;
-            o[0] = pack2bf(w[0], w[1]);
-            o[1] = pack2bf(w[2], w[3]);
+            o[0] = pack16(w[0], w[1]);
+            o[1] = pack16(w[2], w[3]);
             *reinterpret_cast<u32x2_t*>(yy + 4 * hh) = o;
           }
         }
@@ -430,11 +445,9 @@ A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
 }
 A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
   unsigned keep;
-#ifdef A3D_EXP_CHUNK_MAJOR
   const uint64_t a = (uint64_t)(uintptr_t)sbase;      // wave-uniform by construction; say so (folds away when already scalar)
   sbase = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
-#endif
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
@@ -532,11 +545,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   };
   auto issue = [&](int buf) {
     const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
-#ifdef A3D_EXP_CHUNK_MAJOR
     int wk = ik0;                       // K column of the weight rows of this K-tile
-#else
-    const int wk = ik0;
-#endif
     if (ik0 == 0) {
       // per-tile epilogue vectors ride along with the first K-tile: bias (fp32, BN floats) and the tile's rowbias row
       // (bf16; rb_div is a multiple of 256 here, so all 256 rows of the tile share it) -> no global loads in the epilogue
@@ -564,13 +573,10 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
         else glds16_s(0u, g_zero_page, d);                   // out-of-image tap: the piece's other lanes still come from X
       }
-#ifdef A3D_EXP_CHUNK_MAJOR
       if (p.chunk_major) {
         wk = __builtin_amdgcn_readfirstlane(itap * p.Cin + ici0);
         if (++itap == 9) { itap = 0; ici0 += 64; }
-      } else
-#endif
-      {
+      } else {
         ici0 += 64;
         if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
       }
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
           for (int e = 0; e < 8; ++e) y[e] = (hv[e] + bh[e]) * gelu_erf(gv[e] + bg[e]);
           u32x4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pack2bf(y[2 * e], y[2 * e + 1]);
+          for (int e = 0; e < 4; ++e) o[e] = pack16(y[2 * e], y[2 * e + 1]);
           *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
         }
       } else {
@@ -752,18 +758,18 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
           for (int e = 0; e < 8; ++e) v[e] += bv[e];
           if (p.rowbias) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += lo_bf(tb[e]); v[2 * e + 1] += hi_bf(tb[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += lo16(tb[e]); v[2 * e + 1] += hi16(tb[e]); }
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = epi_scale(v[e], p.alpha);
           if constexpr (RES) {
             const u32x4_t tr = rres[pi & 1][j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo_bf(tr[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi_bf(tr[e])); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo16(tr[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi16(tr[e])); }
           }
           u32x4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+          for (int e = 0; e < 4; ++e) o[e] = pack16(v[2 * e], v[2 * e + 1]);
           *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + n) = o;
         }
       }
@@ -775,15 +781,6 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   }
 }
 
-int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
-                              // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
-#ifdef A3D_EXP_CHUNK_MAJOR
-int g_conv_chunk_major = 0;  // experiment builds (-DA3D_EXP_CHUNK_MAJOR) only: a3d_tune_gemm(6) tap-major K walk (= the shipped order, the
-                             // summation order of the 128x128 kernel), (7) chunk-major (fewer L2 misses, different fp32 summation order)
-#endif
-int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
-int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
-                         // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
 
 template <int CONV, int EPI, int NB, bool RES, int VAR = 0>
 int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
@@ -835,7 +832,6 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   }
 }
 
-int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
 
 template <int CONV, int EPI, int BKT, bool RES>
 int launch_res(hipStream_t stream, GemmParams& p, int64_t nblk) {
@@ -877,7 +873,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+extern "C" int A3D_FN(a3d_gemm)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                              const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                              void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
@@ -896,7 +892,7 @@ extern "C" int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, co
   return launch<0>((hipStream_t)stream, p);
 }
 
-extern "C" int a3d_gemm_bf16_f32out(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+extern "C" int A3D_FN(a3d_gemm_f32out)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                                     const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
   if (K % 64 != 0 || N % 8 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 4 != 0) return A3D_EINVAL;
@@ -909,7 +905,7 @@ extern "C" int a3d_gemm_bf16_f32out(a3d_stream_t stream, const void* X, int64_t 
   return launch<0>((hipStream_t)stream, p);
 }
 
-extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
                                 const void* rowbias, int64_t rb_div, const void* R, void* Y,
                                 int B, int H, int W, int Cin, int Cout, int stride, int up2x) {
   if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
@@ -931,13 +927,11 @@ extern "C" int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* 
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
   p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
-#ifdef A3D_EXP_CHUNK_MAJOR
   p.chunk_major = up2x ? 0 : g_conv_chunk_major;       // both kernels walk K the same way, so they stay bit-identical
-#endif
   return up2x ? launch<2>((hipStream_t)stream, p) : launch<1>((hipStream_t)stream, p);
 }
 
-extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+extern "C" int A3D_FN(a3d_gemm_geglu)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                                    const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K) {
   if (!X || !W || !Y || M <= 0 || N2 <= 0 || K <= 0) return A3D_EINVAL;
   if (K % 64 != 0 || N2 % 64 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 8 != 0) return A3D_EINVAL;
@@ -949,14 +943,14 @@ extern "C" int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t l
   return launch<0, EPI_GEGLU>((hipStream_t)stream, p);
 }
 
+#ifndef A3D_STORAGE_F16
 extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
   if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
-#ifdef A3D_EXP_CHUNK_MAJOR
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
-#endif
   if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;
   return A3D_OK;
 }
+#endif

@@ -31,7 +31,7 @@ __global__ void gn_partial_kernel(const GNParams p) {
   auto accum = [&](const u32x4_t& v) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float f = (j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1]);
+      const float f = (j & 1) ? hi16(v[j >> 1]) : lo16(v[j >> 1]);
       if (j < split) { s_lo += f; q_lo += f * f; } else { s_hi += f; q_hi += f * f; }
     }
   };
@@ -116,12 +116,12 @@ __global__ void gn_apply_kernel(const GNParams p) {
     float f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      f[j] = ((j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1])) * sc[j] + sh[j];
+      f[j] = ((j & 1) ? hi16(v[j >> 1]) : lo16(v[j >> 1])) * sc[j] + sh[j];
       if (p.silu) f[j] = f[j] / (1.f + __expf(-f[j]));
     }
     u32x4_t o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+    for (int j = 0; j < 4; ++j) o[j] = pack16(f[2 * j], f[2 * j + 1]);
     *reinterpret_cast<u32x4_t*>(p.Y + off + r * p.C) = o;
   };
   int64_t r = r0 + ry;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const LNParams p) {
     if (c < nch) {
       const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p.X + m * p.C + c * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { f[i][j] = (j & 1) ? hi_bf(v[j >> 1]) : lo_bf(v[j >> 1]); sum += f[i][j]; }
+      for (int j = 0; j < 8; ++j) { f[i][j] = (j & 1) ? hi16(v[j >> 1]) : lo16(v[j >> 1]); sum += f[i][j]; }
     }
   }
 #pragma unroll
@@ -194,11 +194,11 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const LNParams p) {
         if (e1) {
           const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e1 + c * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi16(ev[j >> 1]) : lo16(ev[j >> 1]);
         }
         u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        for (int j = 0; j < 4; ++j) o[j] = pack16(z[2 * j], z[2 * j + 1]);
         *reinterpret_cast<u32x4_t*>(p.Y1 + m * p.C + c * 8) = o;
       }
       if (p.Y2) {
@@ -208,11 +208,11 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const LNParams p) {
         if (e2) {
           const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e2 + c * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi16(ev[j >> 1]) : lo16(ev[j >> 1]);
         }
         u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        for (int j = 0; j < 4; ++j) o[j] = pack16(z[2 * j], z[2 * j + 1]);
         *reinterpret_cast<u32x4_t*>(p.Y2 + m * p.C + c * 8) = o;
       }
     }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) 
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { f[i][j] = (j & 1) ? hi_bf(raw[i][j >> 1]) : lo_bf(raw[i][j >> 1]); sum += f[i][j]; }
+      for (int j = 0; j < 8; ++j) { f[i][j] = (j & 1) ? hi16(raw[i][j >> 1]) : lo16(raw[i][j >> 1]); sum += f[i][j]; }
 #pragma unroll
     for (int o = LPR / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum * inv_c;
@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) 
         if (e1) {
           const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e1 + c * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi16(ev[j >> 1]) : lo16(ev[j >> 1]);
         }
         u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        for (int j = 0; j < 4; ++j) o[j] = pack16(z[2 * j], z[2 * j + 1]);
         if (ok) *reinterpret_cast<u32x4_t*>(p.Y1 + m * p.C + c * 8) = o;
       }
       if (p.Y2) {
@@ -294,11 +294,11 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) 
         if (e2) {
           const u32x4_t ev = *reinterpret_cast<const u32x4_t*>(e2 + c * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi_bf(ev[j >> 1]) : lo_bf(ev[j >> 1]);
+          for (int j = 0; j < 8; ++j) z[j] += (j & 1) ? hi16(ev[j >> 1]) : lo16(ev[j >> 1]);
         }
         u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = pack2bf(z[2 * j], z[2 * j + 1]);
+        for (int j = 0; j < 4; ++j) o[j] = pack16(z[2 * j], z[2 * j + 1]);
         if (ok) *reinterpret_cast<u32x4_t*>(p.Y2 + m * p.C + c * 8) = o;
       }
     }
@@ -319,9 +319,11 @@ inline int gn_nchunk(int64_t rows) { return (int)((rows + GN_ROWS_PER_BLOCK - 1)
 
 }  // namespace
 
+#ifndef A3D_STORAGE_F16
 extern "C" int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups) {
   return (int64_t)B * gn_nchunk(rows) * groups * 2 + (int64_t)B * groups * 2;
 }
+#endif
 
 // mode 0: whole GroupNorm; 1: statistics only (raw fp64 sums); 2: apply only (stats = [B][groups][2] mean, rstd)
 static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
@@ -356,21 +358,21 @@ static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void*
   return a3d_launch_status();
 }
 
-extern "C" int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+extern "C" int A3D_FN(a3d_group_norm)(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                                    float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
   return group_norm_launch(0, stream, X, Y, gamma, beta, ws, nullptr, nullptr, B, rows, C, groups, eps, silu);
 }
 
-extern "C" int a3d_group_norm_sums_bf16(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups) {
+extern "C" int A3D_FN(a3d_group_norm_sums)(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups) {
   return group_norm_launch(1, stream, X, nullptr, nullptr, nullptr, ws, sums, nullptr, B, rows, C, groups, 0.f, 0);
 }
 
-extern "C" int a3d_group_norm_apply_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+extern "C" int A3D_FN(a3d_group_norm_apply)(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                                          const float* stats, int B, int64_t rows, int C, int groups, int silu) {
   return group_norm_launch(2, stream, X, Y, gamma, beta, nullptr, nullptr, stats, B, rows, C, groups, 0.f, silu);
 }
 
-extern "C" int a3d_layer_norm_bf16(a3d_stream_t stream, const void* X, void* Y1, void* Y2, const float* gamma,
+extern "C" int A3D_FN(a3d_layer_norm)(a3d_stream_t stream, const void* X, void* Y1, void* Y2, const float* gamma,
                                    const float* beta, int64_t M, int C, float eps,
                                    const void* pe1, int64_t pe1_div, int64_t pe1_mod,
                                    const void* pe2, int64_t pe2_div, int64_t pe2_mod) {

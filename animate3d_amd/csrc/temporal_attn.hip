@@ -12,7 +12,11 @@
 // Every token byte is read from HBM exactly once (the first version re-read K/V F times through L1).
 #include "common.h"
 
+#ifdef A3D_STORAGE_F16
+extern int g_a3d_ta_pix;     // one set of tuning knobs for both builds (defined in the bf16 object)
+#else
 int g_a3d_ta_pix = 1;        // pixels per workgroup at <= 16 frames (a3d_tune_flash(10 + pix), diagnostics; 1 measured fastest)
+#endif
 
 namespace {
 
@@ -33,7 +37,11 @@ struct TAParams {
 };
 
 A3D_DEV float dot2(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+#ifdef A3D_STORAGE_F16
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2_t, a), __builtin_bit_cast(h16x2_t, b), c, false);          // v_dot2_f32_f16
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(h16x2_t, a), __builtin_bit_cast(h16x2_t, b), c, false);   // v_dot2c_f32_bf16
+#endif
 }
 
 // FP = frames padded to 16 or 32 (register array size), PIX = pixels per workgroup, DP = 40-dim slices per head
@@ -151,8 +159,8 @@ __global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAP
         const u32x4_t w = *reinterpret_cast<const u32x4_t*>(vbase + (size_t)j * ROWB + c * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o[8 * c + 2 * e] = fmaf(pj, lo_bf(w[e]), o[8 * c + 2 * e]);
-          o[8 * c + 2 * e + 1] = fmaf(pj, hi_bf(w[e]), o[8 * c + 2 * e + 1]);
+          o[8 * c + 2 * e] = fmaf(pj, lo16(w[e]), o[8 * c + 2 * e]);
+          o[8 * c + 2 * e + 1] = fmaf(pj, hi16(w[e]), o[8 * c + 2 * e + 1]);
         }
       }
     }
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(PIX * NSL * FP) void temporal_attn_kernel(const TAP
     for (int c = 0; c < SL / 8; ++c) {
       u32x4_t ov;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = pack2bf(o[8 * c + 2 * e] * inv, o[8 * c + 2 * e + 1] * inv);
+      for (int e = 0; e < 4; ++e) ov[e] = pack16(o[8 * c + 2 * e] * inv, o[8 * c + 2 * e + 1] * inv);
       *reinterpret_cast<u32x4_t*>(dst + c * 8) = ov;
     }
   }
@@ -220,13 +228,13 @@ static int temporal_attn_launch(a3d_stream_t stream, const void* Q, int64_t ldq,
   }
 }
 
-extern "C" int a3d_temporal_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+extern "C" int A3D_FN(a3d_temporal_attn)(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
                                       void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
                                       int head_dim, float scale) {
   return temporal_attn_launch(stream, Q, ldqkv, K, V, ldqkv, O, ldo, videos, frames, L, heads, head_dim, scale, 0, frames, frames, 0);
 }
 
-extern "C" int a3d_temporal_attn_sharded_bf16(a3d_stream_t stream, const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldkv,
+extern "C" int A3D_FN(a3d_temporal_attn_sharded)(a3d_stream_t stream, const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldkv,
                                               void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
                                               int head_dim, float scale, int q_f0, int q_frames, int kv_frames_per_block,
                                               int64_t kv_block_stride) {

@@ -62,11 +62,17 @@ _SIGNATURES = {
     "a3d_timestep_embed_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int]),
     "a3d_im2col_in": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int]),
     "a3d_unpack_out": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "a3d_gemm_bf16_f32out": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32]),
+    "a3d_gemm_f32out_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32]),
     "a3d_softmax_rows_f32_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "a3d_channel_mix_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_f32]),
     "a3d_cfg_ddim_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_f32, c_f32, c_f32]),
 }
+# fp16-storage twins (include/animate3d_hip.h, last section): same signatures
+for _name in list(_SIGNATURES):
+    if _name.endswith("_bf16"):
+        _SIGNATURES[_name[:-5] + "_f16"] = _SIGNATURES[_name]
+    elif _name in ("a3d_im2col_in", "a3d_unpack_out"):
+        _SIGNATURES[_name + "_f16"] = _SIGNATURES[_name]
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -117,16 +123,35 @@ def on_model_device(method):
     return wrapper
 
 
+class _Entry:
+    """Entry points of one storage type: attribute ``a3d_gemm_bf16`` resolves to ``a3d_gemm_f16`` for an fp16 op set."""
+
+    def __init__(self, lib, f16: bool):
+        self._lib, self._f16 = lib, f16
+
+    def __getattr__(self, name):
+        if self._f16:
+            if name.endswith("_bf16"):
+                name = name[:-5] + "_f16"
+            elif name in ("a3d_im2col_in", "a3d_unpack_out"):
+                name = name + "_f16"
+        return getattr(self._lib, name)
+
+
 class HipOps:
-    """The op set of the denoise step, executed by the gfx950 kernels.  All activations are 2-D
-    ``[rows, C]`` bf16 CUDA tensors (NHWC images flattened to rows)."""
+    """The op set of the denoise step, executed by the gfx950 kernels.  All activations are 2-D ``[rows, C]`` CUDA tensors
+    (NHWC images flattened to rows) in the op set's storage type: bf16 (default) or IEEE fp16 (``act_dtype=torch.float16``:
+    what a model cast with ``.half()`` gets, as the reference's 4D-SDS caller does, animatemv_guidance.py:339-346).  Both use
+    fp32 accumulation, statistics and softmax; an fp16 model keeps 11 significant bits where bf16 keeps 8."""
 
-    act_dtype = torch.bfloat16
-
-    def __init__(self, device: Optional[torch.device] = None):
+    def __init__(self, device: Optional[torch.device] = None, act_dtype: torch.dtype = torch.bfloat16):
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a visible MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
-        self.lib = load_library()
+        if act_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError(f"storage type {act_dtype} is not supported (bfloat16 or float16)")
+        self.raw_lib = load_library()
+        self.act_dtype = act_dtype
+        self.lib = _Entry(self.raw_lib, act_dtype == torch.float16)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
     # ---- helpers
@@ -134,12 +159,12 @@ class HipOps:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _act(self, t: torch.Tensor, name: str):
-        if t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
-            raise RuntimeError(f"{name}: expected a 2-D bf16 CUDA tensor with contiguous rows, got {t.dtype} {tuple(t.shape)} {t.device} strides {t.stride()}")
+        if t.dtype != self.act_dtype or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"{name}: expected a 2-D {self.act_dtype} CUDA tensor with contiguous rows, got {t.dtype} {tuple(t.shape)} {t.device} strides {t.stride()}")
         return t
 
     def empty(self, rows: int, cols: int) -> torch.Tensor:
-        return torch.empty((rows, cols), dtype=torch.bfloat16, device=self.device)
+        return torch.empty((rows, cols), dtype=self.act_dtype, device=self.device)
 
     # ---- GEMM family
     def gemm(self, x, w, bias=None, *, residual=None, alpha: float = 1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None):
@@ -340,8 +365,8 @@ class HipOps:
         N = w.shape[0]
         assert x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _check(self.lib.a3d_gemm_bf16_f32out(self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, K, alpha),
-               f"a3d_gemm_bf16_f32out M={M} N={N} K={K}")
+        _check(self.lib.a3d_gemm_f32out_bf16(self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(y), N, M, N, K, alpha),
+               f"a3d_gemm_f32out M={M} N={N} K={K}")
         return y
 
     def softmax_rows(self, x, out=None):

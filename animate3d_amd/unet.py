@@ -57,6 +57,7 @@ class MVUNetMotionModel(nn.Module):
         self.sample_size = cfg.sample_size
         self.num_views = num_views          # processors' view count; None => taken from forward(num_views=)
         self._ops = ops
+        self._ops_auto = False
         self._packed = None
         self._pe_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.parallel = None                # set by animate3d_amd.parallel.shard_unet
@@ -200,6 +201,8 @@ class MVUNetMotionModel(nn.Module):
     def _apply(self, fn, *a, **k):
         self._packed = None
         self._pe_cache = {}
+        if getattr(self, "_ops_auto", False):       # .half() / .to(bfloat16) / .to(device): the op set follows the model
+            self._ops, self._ops_auto = None, False
         return super()._apply(fn, *a, **k)
 
     @classmethod
@@ -282,7 +285,9 @@ class MVUNetMotionModel(nn.Module):
     def ops(self):
         if self._ops is None:
             from .hip_ops import HipOps      # raises without an MI355X or without the built library
-            self._ops = HipOps(self.device)
+            # storage type of the kernels = the model's: fp16 for a .half() model (animatemv_guidance.py:339-346), bf16 otherwise
+            self._ops = HipOps(self.device, torch.float16 if self.dtype == torch.float16 else torch.bfloat16)
+            self._ops_auto = True
         return self._ops
 
     def _w(self, t: torch.Tensor) -> torch.Tensor:        # kernel weight: act dtype, contiguous

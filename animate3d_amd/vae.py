@@ -134,6 +134,7 @@ class _VAEHalf(nn.Module):
             raise ValueError("only the single-head mid-block attention of the SD VAE is implemented")
         self.config = cfg
         self._ops = ops
+        self._ops_auto = False
         self._packed = None
 
     # ------------------------------------------------------------------ plumbing
@@ -149,7 +150,8 @@ class _VAEHalf(nn.Module):
     def ops(self):
         if self._ops is None:
             from .hip_ops import HipOps          # raises without an MI355X or without the built library
-            self._ops = HipOps(self.device)
+            self._ops = HipOps(self.device, torch.float16 if self.dtype == torch.float16 else torch.bfloat16)
+            self._ops_auto = True
         return self._ops
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -158,6 +160,8 @@ class _VAEHalf(nn.Module):
 
     def _apply(self, fn, *a, **kw):
         self._packed = None
+        if getattr(self, "_ops_auto", False):
+            self._ops, self._ops_auto = None, False
         return super()._apply(fn, *a, **kw)
 
     def init_synthetic(self, seed: int = 0):

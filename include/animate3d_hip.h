@@ -71,7 +71,7 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
  * not be rounded to bf16: the single-head 512-wide self-attention of the VAE mid block (diffusers AutoencoderKL, used by
  * pipeline.py:566-579 decode_latents) computes S = Q K^T / sqrt(512) with this, a3d_softmax_rows_f32_bf16, and two more GEMMs.
  * Requires K % 64 == 0, N % 8 == 0, 16-byte aligned rows. */
-int a3d_gemm_bf16_f32out(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+int a3d_gemm_f32out_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
 
 /* Tuning knob (diagnostics / A-B measurements; results are bit-identical in every mode):
@@ -194,6 +194,53 @@ int a3d_channel_mix_f32(a3d_stream_t stream, const float* X, const float* W, con
 int a3d_cfg_ddim_step_f32(a3d_stream_t stream, const float* eps_pair, const float* x, const float* first_frame,
                           float* x_prev, int64_t n, int C, int F, int64_t HW, float guidance,
                           float alpha_t, float alpha_prev);
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * fp16-storage twins.  Every entry point above that reads or writes 16-bit activations / weights exists a second time with
+ * IEEE fp16 as the storage type (same signature, same semantics, same fp32 accumulation / statistics / softmax; the MFMA is
+ * v_mfma_f32_32x32x16_f16): the dtype the reference's 4D-SDS caller runs the UNet in (animatemv_guidance.py:339-346 casts
+ * the model and every input to fp16; BASELINE.json configs 4 and 5).  Built from the same sources with -DA3D_STORAGE_F16
+ * (animate3d_amd/build.py).  a3d_im2col_in_f16 / a3d_unpack_out_f16: the CALLER tensor's dtype is still the `dtype` argument,
+ * the activation side is fp16.
+ * --------------------------------------------------------------------------------------------------------------------- */
+int a3d_gemm_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                  const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                  void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
+int a3d_gemm_f32out_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                         const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
+int a3d_gemm_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                        const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K);
+int a3d_conv3x3_f16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                     const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                     int B, int H, int W, int Cin, int Cout, int stride, int up2x);
+int a3d_flash_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                        const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                        int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                        float scale, float out_scale, int accumulate);
+int a3d_temporal_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+                           void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
+                           int head_dim, float scale);
+int a3d_temporal_attn_sharded_f16(a3d_stream_t stream, const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldkv,
+                                   void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
+                                   int head_dim, float scale, int q_f0, int q_frames, int kv_frames_per_block,
+                                   int64_t kv_block_stride);
+int a3d_group_norm_f16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                        float* ws, int B, int64_t rows, int C, int groups, float eps, int silu);
+int a3d_group_norm_sums_f16(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups);
+int a3d_group_norm_apply_f16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
+                              const float* stats, int B, int64_t rows, int C, int groups, int silu);
+int a3d_layer_norm_f16(a3d_stream_t stream, const void* X, void* Y1, void* Y2, const float* gamma,
+                        const float* beta, int64_t M, int C, float eps,
+                        const void* pe1, int64_t pe1_div, int64_t pe1_mod,
+                        const void* pe2, int64_t pe2_div, int64_t pe2_mod);
+int a3d_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N);
+int a3d_silu_f16(a3d_stream_t stream, const void* X, void* Y, int64_t n);
+int a3d_concat_f16(a3d_stream_t stream, const void* A, int64_t Ca, const void* Bsrc, int64_t Cb, void* Y, int64_t M);
+int a3d_timestep_embed_f16(a3d_stream_t stream, const float* t, void* Y, int V, int dim);
+int a3d_im2col_in_f16(a3d_stream_t stream, const void* sample, int dtype, void* Y, int V, int C, int F, int H, int W);
+int a3d_unpack_out_f16(a3d_stream_t stream, const void* X, void* Y, int dtype, int V, int C, int F, int H, int W);
+int a3d_softmax_rows_f32_f16(a3d_stream_t stream, const float* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N);
 
 #ifdef __cplusplus
 }

@@ -412,3 +412,85 @@ def test_bad_arguments_raise(ops):
     q = rnd(64, 8 * 48)
     with pytest.raises(RuntimeError):
         ops.flash_attn(q, q, q, RowMap(1, 64, 0, 64, 0), RowMap(1, 64, 0, 64, 0), 1, 8, 64, 64)   # head_dim 48
+
+
+# ------------------------------------------------------------------ fp16 storage (the a3d_*_f16 twins)
+@pytest.fixture(scope="module")
+def ops16():
+    from animate3d_amd.hip_ops import HipOps
+    return HipOps(act_dtype=torch.float16)
+
+
+H16 = torch.float16
+
+
+def test_fp16_storage_gemm_conv(ops16, ref):
+    """Same kernels compiled with IEEE fp16 as the storage type (v_mfma_f32_32x32x16_f16, fp32 accumulate).  The reference is
+    fp32 arithmetic on the SAME fp16 inputs, so what differs is the summation order and the final fp16 rounding (2^-11 = 4.9e-4):
+    bar 1e-3 relative L2 (the bf16 bar is 4e-3)."""
+    for (M, N, K) in [(300, 320, 320), (4096, 1280, 320), (389, 1280, 640), (130, 2560, 1280)]:
+        x, w = rnd(M, K, seed=1, dtype=H16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=H16)
+        bias, res = rnd(N, seed=3, dtype=torch.float32), rnd(M, N, seed=4, dtype=H16)
+        check(f"f16 gemm {M}x{N}x{K}", ops16.gemm(x, w, bias, residual=res, alpha=0.7), ref.gemm(x, w, bias, residual=res, alpha=0.7), tol=1e-3)
+    x, w = rnd(2048, 320, seed=5, dtype=H16), rnd(2560, 320, seed=6, scale=320 ** -0.5, dtype=H16)
+    bias = rnd(2560, seed=7, dtype=torch.float32)
+    il = ops16.interleave_geglu
+    check("f16 gemm+geglu", ops16.gemm_geglu(x, il(w), il(bias)), ref.gemm_geglu(x, il(w), il(bias)), tol=1e-3)
+    for (B, H, W, Cin, Cout, st, up) in [(2, 8, 12, 64, 128, 1, False), (3, 8, 8, 128, 64, 2, False), (2, 6, 4, 64, 320, 1, True), (4, 16, 16, 320, 320, 1, False)]:
+        xc, wc = rnd(B * H * W, Cin, seed=1, dtype=H16), rnd(Cout, 9 * Cin, seed=2, scale=(9 * Cin) ** -0.5, dtype=H16)
+        bc = rnd(Cout, seed=3, dtype=torch.float32)
+        y, Ho, Wo = ops16.conv3x3(xc, B, H, W, wc, bc, stride=st, up2x=up)
+        yr, _, _ = ref.conv3x3(xc, B, H, W, wc, bc, stride=st, up2x=up)
+        check(f"f16 conv {B}x{H}x{W} {Cin}->{Cout} s{st} up{int(up)}", y, yr, tol=1e-3)
+
+
+@pytest.mark.parametrize("D", [40, 80, 160])
+def test_fp16_storage_attention(ops16, ref, D):
+    heads = 8
+    C = heads * D
+    for (b, n, F, L) in [(1, 2, 3, 64), (1, 4, 2, 256), (1, 3, 2, 100)]:          # 4 x 256: the interleaved kernel at D = 40
+        qkv = rnd(b * n * F * L, 3 * C, seed=D + L, dtype=H16)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        qm, k0 = _mv_maps(n, F, L)
+        S = n * L
+        check(f"f16 mv attn D{D} n{n} F{F} L{L}", ops16.flash_attn(q, k, v, qm, qm, b * F, heads, S, S), ref.flash_attn(q, k, v, qm, qm, b * F, heads, S, S), tol=1.5e-3)
+        check(f"f16 i2v attn D{D} n{n} F{F} L{L}", ops16.flash_attn(q, k, v, qm, k0, b * F, heads, S, S), ref.flash_attn(q, k, v, qm, k0, b * F, heads, S, S), tol=1.5e-3)
+    if D == 40:                                  # rescale path of the interleaved kernel with fp16 offsets / probabilities
+        L = 512
+        q, k, v = rnd(L, C, seed=1, dtype=H16), rnd(L, C, seed=2, dtype=H16), rnd(L, C, seed=3, dtype=H16)
+        for t, row in enumerate((3, 70, 200, 450)):
+            k[row] = q[5 + t] * (3.0 + 1.5 * t)
+        m = RowMap(1, L, 0, L, 0)
+        check("f16 attn rescale spikes", ops16.flash_attn(q, k, v, m, m, 1, heads, L, L), ref.flash_attn(q, k, v, m, m, 1, heads, L, L), tol=1.5e-3)
+    V, F, L = 2, 16, 64
+    qkv = rnd(V * F * L, 3 * C, seed=F + D, dtype=H16)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    check(f"f16 temporal attn D{D}", ops16.temporal_attn(q, k, v, V, F, L, heads), ref.temporal_attn(q, k, v, V, F, L, heads), tol=1.5e-3)
+
+
+def test_fp16_storage_norms_and_elementwise(ops16, ref):
+    x = rnd(2 * 300, 640, seed=3, dtype=H16) + 0.5
+    gamma, beta = 1 + 0.1 * rnd(640, seed=1, dtype=torch.float32), 0.1 * rnd(640, seed=2, dtype=torch.float32)
+    ulp = lambda got, want, n: (got.float() - want.float()).abs().max().item() <= n * want.float().abs().max().item() * 2.0 ** -10
+    for silu in (False, True):
+        got, want = ops16.group_norm(x, 2, 300, gamma, beta, 32, 1e-5, silu), ref.group_norm(x, 2, 300, gamma, beta, 32, 1e-5, silu)
+        assert ulp(got, want, 3), ("group_norm", silu)
+    got, want = ops16.layer_norm(x, gamma, beta, 1e-5), ref.layer_norm(x, gamma, beta, 1e-5)
+    assert ulp(got, want, 3)
+    pe1, pe2 = rnd(3, 640, seed=3, dtype=H16), rnd(5, 640, seed=4, dtype=H16)
+    y1, y2 = ops16.layer_norm(x, gamma, beta, 1e-5, pe1=pe1, pe1_div=4, pe2=pe2, pe2_div=1, two=True)
+    r1, r2 = ref.layer_norm(x, gamma, beta, 1e-5, pe1=pe1, pe1_div=4, pe2=pe2, pe2_div=1, two=True)
+    assert ulp(y1, r1, 3) and ulp(y2, r2, 3)
+    u = rnd(100, 2560, seed=5, dtype=H16)
+    assert ulp(ops16.geglu(u), ref.geglu(u), 3) and ulp(ops16.silu(u), ref.silu(u), 3)
+    a, b = rnd(64, 640, seed=6, dtype=H16), rnd(64, 320, seed=7, dtype=H16)
+    assert torch.equal(ops16.concat(a, b), torch.cat([a, b], 1))
+    t = torch.tensor([1.0, 501.0, 999.0], device="cuda")
+    assert ulp(ops16.timestep_embed(t, 320), ref.timestep_embed(t, 320), 3)
+    for src in (torch.float32, torch.bfloat16, torch.float16):
+        smp = rnd(2, 4, 3, 8, 8, seed=8, dtype=src)
+        rows = ops16.im2col_in(smp)
+        assert rows.dtype == H16 and ulp(rows, ref.im2col_in(smp), 2)
+        xr = rnd(2 * 3 * 8 * 8, 4, seed=9, dtype=H16)
+        out = ops16.unpack_out(xr, 2, 4, 3, 8, 8, src)
+        assert out.dtype == src and ulp(out, ref.unpack_out(xr, 2, 4, 3, 8, 8, src), 3)

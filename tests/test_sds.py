@@ -87,9 +87,10 @@ def test_sds_step_config5_over_the_hip_unet():
     """BASELINE config 5: one 4D-SDS step (animatemv_guidance.py:391-507) over the HIP UNet at the reference's shape — b = 1,
     4 views x 16 frames, 32 x 32 latent (256 px), everything cast to fp16 on the way in (:339-346), CFG batch in (text, uncond)
     order — against the same function over the fp32 CPU oracle UNet with the same weights, noise and timestep.
-    Compared: the raw UNet output (bar 3e-2, the UNet's stated tolerance) and, at guidance scale 7.5, the reconstruction, the
-    loss and the gradient (the CFG combine eps_text + s (eps_text - eps_uncond) amplifies the UNet's rounding by ~ s, hence
-    the wider bars; at the reference's s = 100 only finiteness is asserted)."""
+    The ``.half()`` model runs on the fp16-storage kernels (a3d_*_f16), as the reference runs its UNet in fp16.
+    Compared: the raw UNet output (bar 6e-3, the fp16 tolerance of tests/test_unet_gpu.py) and, at guidance scale 7.5, the
+    reconstruction, the loss and the gradient (the CFG combine eps_text + s (eps_text - eps_uncond) amplifies the UNet's
+    rounding by ~ s, hence the wider bar 2.5e-2; at the reference's s = 100 only finiteness is asserted)."""
     import os as _os
     from animate3d_amd.config import UNetConfig
     from animate3d_amd.embeddings import get_camera
@@ -133,8 +134,9 @@ def test_sds_step_config5_over_the_hip_unet():
     e_loss = abs(loss_h.item() - loss_r.item()) / abs(loss_r.item())
     print(f"[parity] SDS step config 5 (V=8, F=16, 32x32, fp16 in): UNet output rel_l2={e_unet:.3e}; s=7.5: recon {e_rec:.3e} "
           f"grad {e_grad:.3e} loss {e_loss:.3e} (loss {loss_r.item():.4e})")
-    assert seen["hip"].shape == (2 * b * n, 4, F, *hw) and e_unet <= 3e-2
-    assert e_rec <= 1e-1 and e_grad <= 1e-1 and e_loss <= 5e-2
+    assert hip.ops.act_dtype == torch.float16
+    assert seen["hip"].shape == (2 * b * n, 4, F, *hw) and e_unet <= 6e-3
+    assert e_rec <= 2.5e-2 and e_grad <= 2.5e-2 and e_loss <= 1e-2
     g6 = lh.grad.reshape(-1, F, *lh.shape[1:])
     assert float(g6[:, 0].abs().max()) == 0.0
     loss_100, aux_100 = sds_recon_loss(hip, lat.cuda(), dev(t), dev(text), dev(emb), dev(c2w), guidance_scale=100.0,

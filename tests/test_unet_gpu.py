@@ -162,15 +162,17 @@ def test_output_dtype_and_determinism(models):
 
 
 def test_fp16_model_and_inputs(models):
-    """BASELINE configs 4/5 run the UNet in fp16 (animatemv_guidance.py:339-346 casts everything, incl. t, to fp16).
-    fp16 weights / inputs are accepted at the boundary; arithmetic is bf16 storage + fp32 accumulate (stated in DESIGN.md),
-    the output comes back in fp16."""
+    """BASELINE configs 4/5 run the UNet in fp16 (animatemv_guidance.py:339-346 casts everything, incl. t, to fp16).  A model
+    cast with ``.half()`` runs on the fp16-storage kernels (a3d_*_f16: v_mfma_f32_32x32x16_f16, fp32 accumulate) and returns
+    fp16.  fp16 keeps 11 significant bits where bf16 keeps 8, so the bar against the fp32 oracle is 5x tighter than bf16's
+    (6e-3 instead of 3e-2 relative L2); the same weights through the bf16 kernels are printed next to it."""
     ocfg, ref, hip, _ = models
     inp = O.synthetic_inputs(ocfg, 2, N_VIEWS, FRAMES, HW, seed=9)
     y_ref = ref(**inp).sample
     h16 = MVUNetMotionModel(UNetConfig(), num_views=N_VIEWS, device="cuda")
     h16.load_state_dict(ref.state_dict(), strict=True)
     h16 = h16.half().eval()
+    assert h16.ops.act_dtype == torch.float16 and hip.ops.act_dtype == torch.bfloat16
     ci = _cuda(inp)
     ci["sample"] = ci["sample"].half()
     ci["encoder_hidden_states"] = ci["encoder_hidden_states"].half()
@@ -180,8 +182,12 @@ def test_fp16_model_and_inputs(models):
     y = h16(**ci).sample
     assert y.dtype == torch.float16
     e, mx, sc = _rel(y, y_ref)
-    print(f"[parity] unet fp16 boundary: rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e})")
-    assert e <= 3e-2
+    e_bf, _, _ = _rel(hip(**_cuda(inp)).sample, y_ref)
+    print(f"[parity] unet fp16 storage: rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e}); same weights, bf16 storage: {e_bf:.3e}")
+    assert torch.isfinite(y).all() and e <= 6e-3
+    # the op set follows the model: back to bf16 storage after .to(bfloat16)
+    h16 = h16.to(torch.bfloat16)
+    assert h16.ops.act_dtype == torch.bfloat16
 
 
 def test_baseline_config1_shape():
