@@ -45,6 +45,19 @@ __global__ void silu_kernel(const uint16_t* X, uint16_t* Y, int64_t n8) {
   }
 }
 
+// mode 1: QuickGELU x * sigmoid(1.702 x) (CLIP text tower); mode 2: exact GELU (erf; CLIP ViT-H vision tower)
+template <int MODE>
+__global__ void act_kernel(const uint16_t* X, uint16_t* Y, int64_t n8) {
+  auto f = [](float a) { return MODE == 1 ? a / (1.f + __expf(-1.702f * a)) : 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); };
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(X + i * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack16(f(lo16(v[j])), f(hi16(v[j])));
+    *reinterpret_cast<u32x4_t*>(Y + i * 8) = o;
+  }
+}
+
 __global__ void concat_kernel(const uint16_t* A, int64_t Ca8, const uint16_t* B, int64_t Cb8, uint16_t* Y, int64_t M) {
   const int64_t C8 = Ca8 + Cb8, total = M * C8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -231,6 +244,16 @@ extern "C" int A3D_FN(a3d_silu)(a3d_stream_t stream, const void* X, void* Y, int
   if (!X || !Y || n <= 0 || n % 8) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
   silu_kernel<<<grid_for(n / 8), 256, 0, (hipStream_t)stream>>>((const uint16_t*)X, (uint16_t*)Y, n / 8);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_activation)(a3d_stream_t stream, const void* X, void* Y, int64_t n, int mode) {
+  if (!X || !Y || n <= 0 || n % 8 != 0 || mode < 0 || mode > 2) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) silu_kernel<<<grid_for(n / 8), 256, 0, s>>>((const uint16_t*)X, (uint16_t*)Y, n / 8);
+  else if (mode == 1) act_kernel<1><<<grid_for(n / 8), 256, 0, s>>>((const uint16_t*)X, (uint16_t*)Y, n / 8);
+  else act_kernel<2><<<grid_for(n / 8), 256, 0, s>>>((const uint16_t*)X, (uint16_t*)Y, n / 8);
   return a3d_launch_status();
 }
 

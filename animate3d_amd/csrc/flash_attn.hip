@@ -52,6 +52,7 @@ struct AttnParams {
   a3d_rowmap qm, km, om;
   int heads; int q_len, kv_len;
   float scale_log2, out_scale; int accumulate;
+  int causal;      // key s may only be seen by queries >= s of the same group (CLIP text tower); generic kernel only
 };
 
 A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
@@ -88,9 +89,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   constexpr int KS_PAD = D / 16, G_PAD = (D % 16) / 8;    // fragment slot of contraction index D (OFS_PAD)
   static_assert((KROW / 8) % 2 == 1 && (VROW / 8) % 2 == 1, "LDS row strides must be an odd number of 16-B slots");
   static_assert(OFS != OFS_PAD || (DK > D && D % 8 == 0), "OFS_PAD needs a spare contraction slot");
-#ifndef A3D_EXP_FLASH80
-  static_assert(OFS != OFS_FMA || QT == 1, "the fma variant keeps one query sub-tile per wave");
-#endif
 
   __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (KS_ELEMS + VT_ELEMS)];
   uint16_t* const Ks0 = smem;
@@ -289,10 +287,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             for (int qs = 0; qs < QT; ++qs) sacc[qs][u][r] = -INFINITY;
           }
     }
+    if (p.causal) {            // wave-uniform flag: keys after the query's own position
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) > q_idx[qs]) sacc[qs][u][r] = -INFINITY;
+    }
 
-#ifdef A3D_EXP_FLASH80
-    if constexpr (OFS == OFS_FMA) {
-      // ---- scores are raw; running max in raw units, lazy by LAZY_THR / scale_log2 (any number of query sub-tiles)
+    if constexpr (OFS == OFS_FMA && QT > 1) {
+      // ---- D = 80 with two query sub-tiles per wave: scores are raw; running max in raw units, lazy by LAZY_THR / scale_log2
 #pragma unroll
       for (int qs = 0; qs < QT; ++qs) {
         float mx = sacc[qs][0][0];
@@ -317,8 +323,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[qs][u][r] = fmaf(sacc[qs][u][r], p.scale_log2, mneg);
       }
-#else
-    if constexpr (OFS == OFS_FMA) {
+    } else if constexpr (OFS == OFS_FMA) {
       // ---- D = 160: scores are raw; running max in raw units, lazy by LAZY_THR / scale_log2
       float mx = sacc[0][0][0];
 #pragma unroll
@@ -341,7 +346,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[0][u][r] = fmaf(sacc[0][u][r], p.scale_log2, mneg);
-#endif
     } else {
       // ---- lazy offset update: the common path is max + compare + one wave vote per query sub-tile; the slow
       //      path re-bases S', rescales O and moves the offset
@@ -1249,9 +1253,7 @@ extern int g_a3d_ta_pix;      // temporal_attn.hip
 #ifndef A3D_STORAGE_F16
 extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
-#ifdef A3D_EXP_FLASH80
-  if (variant == 8 || variant == 9) { g_flash_variant = variant; return A3D_OK; }
-#endif
+  if (variant == 8 || variant == 17) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
 #ifdef A3D_ABLATIONS
   if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && (variant < 1000 || variant >= 1512)) return A3D_EINVAL;
 #else
@@ -1275,7 +1277,8 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
   p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.O = (uint16_t*)O;
   p.qm = *qmap; p.km = *kmap; p.om = *omap;
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len;
-  p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate;
+  p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate & 1; p.causal = (accumulate >> 1) & 1;
+  if (p.causal && head_dim != 64 && head_dim != 160) return A3D_EUNSUPPORTED;     // offered on the raw-score (fma) kernels only
   const int bkv = head_dim == 160 ? 32 : 64;
   const bool aligned = (kmap->seg_len % bkv == 0) || (kv_len <= kmap->seg_len);
   hipStream_t s = (hipStream_t)stream;
@@ -1323,12 +1326,13 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
       launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p);
       break;
     case 80:
-#ifdef A3D_EXP_FLASH80   // two query sub-tiles per wave at head dim 80 (every K / V^T fragment feeds two MFMAs): a3d_tune_flash(8 | 9)
-      if (g_flash_variant == 8) { launch<80, 32, 2, OFS_FMA>(aligned, groups, s, p); break; }
-      if (g_flash_variant == 9) { launch<80, 64, 2, OFS_FMA>(aligned, groups, s, p); break; }
-#endif
+      // long sequences (level 1 of the 512-px configurations): two query sub-tiles per wave, 32-key tiles — every K / V^T
+      // fragment read feeds two MFMAs, which relieves the LDS port that bounds the one-sub-tile kernel (+4-8 %,
+      // profiles/r2_microbench_flash80_ab.log); short ones keep one sub-tile per wave (more workgroups).  a3d_tune_flash(8 | 17) forces either.
+      if (g_flash_variant == 8 || (g_flash_variant != 17 && q_len >= 2048 && kv_len >= 2048)) { launch<80, 32, 2, OFS_FMA>(aligned, groups, s, p); break; }
       launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p);
       break;
+    case 64: launch<64, 64, 1, OFS_FMA>(aligned, groups, s, p); break;        // CLIP text tower (12 heads of 64)
     case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;
     default: return A3D_EUNSUPPORTED;
   }

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "a3d_layer_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64]),
     "a3d_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "a3d_silu_bf16": (c_int, [c_vp, c_vp, c_vp, c_i64]),
+    "a3d_activation_bf16": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int]),
     "a3d_concat_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]),
     "a3d_timestep_embed_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int]),
     "a3d_im2col_in": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int]),
@@ -234,7 +235,7 @@ class HipOps:
 
     # ---- attention
     def flash_attn(self, q, k, v, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
-                   out=None, out_scale: float = 1.0, accumulate: bool = False):
+                   out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False):
         q, k, v = self._act(q, "attn.q"), self._act(k, "attn.k"), self._act(v, "attn.v")
         C = q.shape[1]
         D = C // heads
@@ -242,7 +243,7 @@ class HipOps:
         o = out if out is not None else self.empty(q.shape[0], C)
         qm, km, om = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(o.stride(0))
         rc = self.lib.a3d_flash_attn_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
-                                          groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, 1 if accumulate else 0)
+                                          groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, (1 if accumulate else 0) | (2 if causal else 0))
         _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
         return o
 
@@ -327,6 +328,14 @@ class HipOps:
         assert x.is_contiguous()
         y = torch.empty_like(x)
         _check(self.lib.a3d_silu_bf16(self._stream(), _p(x), _p(y), x.numel()), "a3d_silu_bf16")
+        return y
+
+    def activation(self, x, kind: str):
+        """``kind``: "silu", "quick_gelu" (x * sigmoid(1.702 x)) or "gelu" (erf)."""
+        x = self._act(x, "act.x")
+        assert x.is_contiguous()
+        y = torch.empty_like(x)
+        _check(self.lib.a3d_activation_bf16(self._stream(), _p(x), _p(y), x.numel(), {"silu": 0, "quick_gelu": 1, "gelu": 2}[kind]), f"a3d_activation {kind}")
         return y
 
     def concat(self, a, b):

@@ -105,7 +105,9 @@ int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const f
 /* softmax(Q K^T * scale) V per (group, head), flash-style (no score matrix in memory).
  *   O[row_o(g,s), h*D + d] = out_scale * attn(...)   (+ previous O contents if accumulate)
  * Replaces xformers.ops.memory_efficient_attention at attention_processor.py:103,233,268,
- * 405,416,656.  head_dim in {40, 80, 160}.  K and V share kmap. */
+ * 405,416,656.  head_dim in {40, 80, 160} (the SD1.5 UNet levels) and 64 (CLIP text tower of pipeline.py:345-524).  K and V share
+ * kmap.  `accumulate` bit 0: add to the previous O contents; bit 1: causal mask (key s visible to queries >= s of its group;
+ * head_dim 64 / 160 only) — transformers' CLIPTextModel causal attention. */
 int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
@@ -162,6 +164,10 @@ int a3d_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int
 
 /* Y = X * sigmoid(X), n elements (n % 8 == 0). */
 int a3d_silu_bf16(a3d_stream_t stream, const void* X, void* Y, int64_t n);
+
+/* Elementwise activation on n elements (n % 8 == 0): mode 0 SiLU, 1 QuickGELU x * sigmoid(1.702 x) (transformers CLIPTextModel of
+ * pipeline.py:345-524 encode_prompt), 2 exact GELU (CLIP ViT-H image encoder of pipeline.py:527-538 encode_image). */
+int a3d_activation_bf16(a3d_stream_t stream, const void* X, void* Y, int64_t n, int mode);
 
 /* Y[m] = [A[m, 0:Ca] | B[m, 0:Cb]]  (torch.cat([x, skip], dim=1) of the up blocks). */
 int a3d_concat_bf16(a3d_stream_t stream, const void* A, int64_t Ca, const void* Bsrc, int64_t Cb, void* Y, int64_t M);
@@ -236,6 +242,7 @@ int a3d_layer_norm_f16(a3d_stream_t stream, const void* X, void* Y1, void* Y2, c
                         const void* pe2, int64_t pe2_div, int64_t pe2_mod);
 int a3d_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N);
 int a3d_silu_f16(a3d_stream_t stream, const void* X, void* Y, int64_t n);
+int a3d_activation_f16(a3d_stream_t stream, const void* X, void* Y, int64_t n, int mode);
 int a3d_concat_f16(a3d_stream_t stream, const void* A, int64_t Ca, const void* Bsrc, int64_t Cb, void* Y, int64_t M);
 int a3d_timestep_embed_f16(a3d_stream_t stream, const float* t, void* Y, int V, int dim);
 int a3d_im2col_in_f16(a3d_stream_t stream, const void* sample, int dtype, void* Y, int V, int C, int F, int H, int W);

@@ -278,6 +278,28 @@ def test_flash_attn_interleaved_rescale_paths(ops, ref, spikes, L, q_len):
           ref.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L))
 
 
+def test_flash_attn_d80_kernel_variants(ops, ref):
+    """Head dim 80: the two-sub-tile kernel (long sequences, default from 2048 tokens) and the one-sub-tile kernel, forced both
+    ways on a long and a ragged short shape, each against the fp32 reference; the forced spike exercises the two-sub-tile
+    kernel's rescale path."""
+    heads, D = 8, 80
+    C = heads * D
+    try:
+        for (n, F, L, spike) in [(4, 1, 512, True), (3, 2, 100, False)]:
+            qkv = rnd(n * F * L, 3 * C, seed=L)
+            q, k, v = qkv[:, :C].contiguous(), qkv[:, C:2 * C].contiguous(), qkv[:, 2 * C:]
+            if spike:
+                k[700] = q[9] * 4.0
+                k[1500] = q[11] * 6.0
+            qm, k0 = _mv_maps(n, F, L)
+            want = ref.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L)
+            for var in (0, 8, 17):
+                assert ops.lib.a3d_tune_flash(var) == 0
+                check(f"D80 n{n} L{L} kernel variant {var}", ops.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L), want)
+    finally:
+        ops.lib.a3d_tune_flash(0)
+
+
 def test_flash_attn_kernel_variants_agree(ops, ref):
     """The interleaved (default), ping-pong and plain D = 40 kernels on one long multi-view shape, each against the fp32 reference."""
     heads, D, b, n, F, L = 8, 40, 1, 4, 2, 256

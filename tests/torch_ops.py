@@ -84,7 +84,7 @@ class TorchRefOps:
             y = y + residual.float()
         return self._o(y), Ho, Wo
 
-    def flash_attn(self, q, k, v, qmap, kmap, groups, heads, q_len, kv_len, *, out=None, out_scale=1.0, accumulate=False):
+    def flash_attn(self, q, k, v, qmap, kmap, groups, heads, q_len, kv_len, *, out=None, out_scale=1.0, accumulate=False, causal=False):
         C = q.shape[1]
         D = C // heads
         qi = rowmap_indices(qmap, groups, q_len).to(q.device)
@@ -92,7 +92,10 @@ class TorchRefOps:
         qg = q.float()[qi].reshape(groups, q_len, heads, D).transpose(1, 2)
         kg = k.float()[ki].reshape(groups, kv_len, heads, D).transpose(1, 2)
         vg = v.float()[ki].reshape(groups, kv_len, heads, D).transpose(1, 2)
-        p = torch.softmax(qg @ kg.transpose(-1, -2) * (D ** -0.5), dim=-1)
+        sc = qg @ kg.transpose(-1, -2) * (D ** -0.5)
+        if causal:
+            sc = sc.masked_fill(torch.arange(kv_len, device=q.device)[None, :] > torch.arange(q_len, device=q.device)[:, None], float("-inf"))
+        p = torch.softmax(sc, dim=-1)
         o = (p @ vg).transpose(1, 2).reshape(groups, q_len, C) * out_scale
         res = out if out is not None else torch.zeros((q.shape[0], C), dtype=self.act_dtype, device=q.device)
         flat = qi.reshape(-1)
@@ -156,6 +159,11 @@ class TorchRefOps:
 
     def silu(self, x):
         return self._o(F.silu(x.float()))
+
+    def activation(self, x, kind):
+        xf = x.float()
+        y = {"silu": F.silu, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t), "gelu": F.gelu}[kind](xf)
+        return self._o(y)
 
     def concat(self, a, b):
         return torch.cat([a, b], dim=1)
