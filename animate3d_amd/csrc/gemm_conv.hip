@@ -24,8 +24,10 @@ extern int g_gemm_bk;
 #else
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
                               // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
-int g_conv_chunk_major = 1;  // a3d_tune_gemm(6): tap-major K walk of the 3x3 convs (round 1's order), (7): chunk-major (default since round 2:
-                             // +2-16 % on the level-0 / level-1 convs, profiles/r2_microbench_conv_korder.log; both kernels walk K the same way)
+int g_conv_chunk_major = 0;  // experiment builds (-DA3D_EXP_CHUNK_MAJOR) only: a3d_tune_gemm(6) tap-major K walk (= the shipped order), (7)
+                             // chunk-major.  Round 2: inside the experiment build chunk-major wins 0-7 % (profiles/r2_microbench_conv_korder.log),
+                             // but the build itself (scalarised DMA bases, K offset no longer a constant) makes every persistent GEMM / conv
+                             // 2-10 % slower than the shipped one in the full step (profiles/README.md): not shipped
 int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
@@ -60,8 +62,9 @@ struct GemmParams {
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
-  int chunk_major;      // 3x3 conv: walk K as (64-channel chunk, tap) instead of (tap, chunk): the nine taps of a chunk re-use the
-                        // tile's input rows while they are still in L2 (HBM re-fetch 9.3x -> 1.8x, profiles/r1_gemm_conv_pmc_traffic.md)
+#ifdef A3D_EXP_CHUNK_MAJOR
+  int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
+#endif
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up, He, We;   // He x We: extent of the (virtual) upsampled image of the up2x conv
   int64_t tiles_n, tiles_m;
@@ -158,10 +161,12 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   RegTile rt0, rt1;     // two K-tiles in flight (prefetch distance 2)
   auto load_tile = [&](int64_t k0, RegTile& rt) {
     u32x4_t (&ra)[NPASS] = rt.a; u32x4_t (&rw)[NPASS] = rt.w;
+#ifdef A3D_EXP_CHUNK_MAJOR
     if (CONV == 1 && p.chunk_major) {       // same K walk as the persistent kernel: (64-channel chunk, tap, position in the chunk)
       const int64_t j = k0 >> 6, c = j / 9;
       k0 = (j - c * 9) * p.Cin + c * 64 + (k0 & 63);
     }
+#endif
     if constexpr (CONV != 0) {
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
@@ -445,9 +450,11 @@ A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
 }
 A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
   unsigned keep;
+#ifdef A3D_EXP_CHUNK_MAJOR
   const uint64_t a = (uint64_t)(uintptr_t)sbase;      // wave-uniform by construction; say so (folds away when already scalar)
   sbase = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+#endif
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
@@ -545,7 +552,11 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   };
   auto issue = [&](int buf) {
     const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
+#ifdef A3D_EXP_CHUNK_MAJOR
     int wk = ik0;                       // K column of the weight rows of this K-tile
+#else
+    const int wk = ik0;
+#endif
     if (ik0 == 0) {
       // per-tile epilogue vectors ride along with the first K-tile: bias (fp32, BN floats) and the tile's rowbias row
       // (bf16; rb_div is a multiple of 256 here, so all 256 rows of the tile share it) -> no global loads in the epilogue
@@ -573,10 +584,13 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
         else glds16_s(0u, g_zero_page, d);                   // out-of-image tap: the piece's other lanes still come from X
       }
+#ifdef A3D_EXP_CHUNK_MAJOR
       if (p.chunk_major) {
         wk = __builtin_amdgcn_readfirstlane(itap * p.Cin + ici0);
         if (++itap == 9) { itap = 0; ici0 += 64; }
-      } else {
+      } else
+#endif
+      {
         ici0 += 64;
         if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
       }
@@ -927,7 +941,9 @@ extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const voi
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
   p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
+#ifdef A3D_EXP_CHUNK_MAJOR
   p.chunk_major = up2x ? 0 : g_conv_chunk_major;       // both kernels walk K the same way, so they stay bit-identical
+#endif
   return up2x ? launch<2>((hipStream_t)stream, p) : launch<1>((hipStream_t)stream, p);
 }
 
@@ -947,7 +963,9 @@ extern "C" int A3D_FN(a3d_gemm_geglu)(a3d_stream_t stream, const void* X, int64_
 extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
   if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
+#ifdef A3D_EXP_CHUNK_MAJOR
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
+#endif
   if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;

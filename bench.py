@@ -252,12 +252,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # A3D_BENCH_SHARE_GPU=1 (testing the multi-rank code path on a one-GPU box): all ranks on device 0, collectives over gloo
+    share = os.environ.get("A3D_BENCH_SHARE_GPU") == "1"
+    dev_id = 0 if share else local_rank
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from animate3d_amd.config import UNetConfig
     from animate3d_amd.hip_ops import HipOps

@@ -287,7 +287,7 @@ def test_flash_attn_d80_kernel_variants(ops, ref):
     try:
         for (n, F, L, spike) in [(4, 1, 512, True), (3, 2, 100, False)]:
             qkv = rnd(n * F * L, 3 * C, seed=L)
-            q, k, v = qkv[:, :C].contiguous(), qkv[:, C:2 * C].contiguous(), qkv[:, 2 * C:]
+            q, k, v = qkv[:, :C].contiguous(), qkv[:, C:2 * C].contiguous(), qkv[:, 2 * C:].contiguous()
             if spike:
                 k[700] = q[9] * 4.0
                 k[1500] = q[11] * 6.0
