@@ -1154,10 +1154,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
       constexpr int s = decltype(s_c)::value;
       if constexpr ((ABL & 4) == 0) {
         if constexpr (STORE && s == 1) store_tile(t + 2);
-        if constexpr (LOAD && s == 2) load_tile();
+        if constexpr (LOAD && s == 2 && (ABL & 256) == 0) load_tile();
       }
     };
-    auto no_hook = [&](auto) __attribute__((always_inline)) {};
+    auto odd_hook = [&](auto s_c) __attribute__((always_inline)) {      // experiment (ABL bit 256): request the next tile from the odd step
+      constexpr int s = decltype(s_c)::value;
+      if constexpr ((ABL & 4) == 0 && (ABL & 256) != 0 && LOAD && s == 1) load_tile();
+    };
     const uint16_t* const Kn = Ks0 + ((t + 1) % IL_NKB) * KS_ELEMS + krow_off;
     const uint16_t* const Vp = Vs0 + ((t + IL_NVB - 1) % IL_NVB) * V_ELEMS + vlane_off;
     const uint16_t* const Vt = Vs0 + (t % IL_NVB) * V_ELEMS + vlane_off;
@@ -1168,8 +1171,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flash_attn_il_kernel(const At
     // odd step j = 2t+1: S(2t+2) from K(t+1) keys 0..31 (in kf), O += V(t)[0..31] P(2t), P(2t+1) from S(2t+1);
     //                    fetches K(t+1) keys 32..63 for the next even step
     step(std::integral_constant<bool, !LAST>{}, std::true_type{}, std::integral_constant<bool, !LAST>{}, sB, sA, pB, pA,
-         Kn + 32 * KROW, Vt, Vt + 32 * VPITCH, no_hook);
-    if constexpr (!LAST && (ABL & 8) == 0) __syncthreads();
+         Kn + 32 * KROW, Vt, Vt + 32 * VPITCH, odd_hook);
+    if constexpr (!LAST && (ABL & 8) == 0) {
+      if constexpr ((ABL & 512) != 0) {      // experiment: LDS writes drained, global loads left in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        __syncthreads();
+      }
+    }
   };
   constexpr std::true_type Y{};
   constexpr std::false_type N{};
@@ -1255,7 +1264,7 @@ extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
   if (variant == 8 || variant == 17) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
 #ifdef A3D_ABLATIONS
-  if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && (variant < 1000 || variant >= 1512)) return A3D_EINVAL;
+  if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && (variant < 1000 || variant >= 2024)) return A3D_EINVAL;
 #else
   if (variant != 0 && variant != 5 && variant != 6 && variant != 7 && variant != 13 && variant != 15 && variant != 16) return A3D_EINVAL;
 #endif
@@ -1286,13 +1295,14 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
     case 40:
       if (q_len <= 128) { launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p); break; }
 #ifdef A3D_ABLATIONS
-      if (g_flash_variant >= 1000) {      // timing ablations of the interleaved kernel: 1000 + 256 * (4 waves) + ABL bits
-        const int a = (g_flash_variant - 1000) & 255;
-        const bool w4 = g_flash_variant >= 1256;
+      if (g_flash_variant >= 1000) {      // timing ablations / experiments of the interleaved kernel: 1000 + ABL bits
+        const int a = g_flash_variant - 1000;
+        const bool w4 = false;
         int rc = A3D_EUNSUPPORTED;
 #define A3D_IL_ABL(X) if (a == X) rc = w4 ? launch_il<2, 4, X>(groups, s, p) : launch_il<2, 8, X>(groups, s, p);
         A3D_IL_ABL(0) A3D_IL_ABL(1) A3D_IL_ABL(2) A3D_IL_ABL(4) A3D_IL_ABL(8) A3D_IL_ABL(12) A3D_IL_ABL(16) A3D_IL_ABL(32) A3D_IL_ABL(48)
         A3D_IL_ABL(64) A3D_IL_ABL(76) A3D_IL_ABL(129) A3D_IL_ABL(131) A3D_IL_ABL(207) A3D_IL_ABL(124)
+        A3D_IL_ABL(256) A3D_IL_ABL(512) A3D_IL_ABL(768)
 #undef A3D_IL_ABL
         if (rc != A3D_OK) return rc;
         break;

@@ -228,6 +228,28 @@ def test_full_size_batch_independence():
     assert full.shape == (8, 4, 16, 64, 64)
 
 
+def test_config4_full_size_fp16():
+    """BASELINE config 4 at FULL size on one GPU: 8 views x 32 frames x 64x64 latent, CFG-doubled V = 16, fp16 model and inputs
+    (2.58 PFLOP per step, ~100 GB working set).  The oracle cannot run this; checked instead: finite output of the right shape,
+    and the CFG halves do not exchange data (the first half alone reproduces its rows bit for bit)."""
+    from bench import make_inputs
+    cfg = UNetConfig()
+    m = MVUNetMotionModel(cfg, num_views=8, device="cuda")
+    m.init_synthetic(seed=1)
+    m = m.half().eval()
+    inp = make_inputs(cfg, 16, 8, 32, (64, 64), torch.device("cuda"))
+    inp["sample"] = inp["sample"].half()
+    full = m(**inp).sample
+    assert full.shape == (16, 4, 32, 64, 64) and full.dtype == torch.float16 and torch.isfinite(full).all()
+    half = dict(inp)
+    half["sample"] = inp["sample"][:8]
+    half["encoder_hidden_states"] = inp["encoder_hidden_states"][:8]
+    half["camera"] = inp["camera"][:8]
+    half["added_cond_kwargs"] = {"image_embeds": inp["added_cond_kwargs"]["image_embeds"][:8]}
+    part = m(**half).sample
+    assert torch.equal(full[:8], part), (full[:8].float() - part.float()).abs().max().item()
+
+
 def test_loaded_native_library():
     """The .so that ran must be the in-tree one (no silent fallback)."""
     import os

@@ -68,7 +68,8 @@ def bench_il_abl(ops):
     names = {0: "full", 1: "no exp", 2: "no max/vote", 4: "no staging", 8: "no barrier", 12: "no staging, no barrier", 16: "no QK mfma", 32: "no PV mfma",
              48: "no mfma", 64: "no frag reads", 76: "no frag reads/staging/barrier", 129: "no exp, no cvt", 131: "no exp/cvt/max",
              207: "mfma only (no exp/cvt/max/staging/barrier/frag reads)", 124: "no mfma/frag/staging/barrier: exp+cvt+max only"}
-    for base, tag in ((1000, "8 waves"), (1256, "4 waves")):
+    names = {0: "full", 256: "tile request in the odd step", 512: "barrier without vmcnt wait", 768: "both", 4: "no staging", 8: "no barrier"}
+    for base, tag in ((1000, "8 waves"), (1000, "8 waves (second pass)")):
         for a, nm in names.items():
             if ops.lib.a3d_tune_flash(base + a) != 0:
                 continue
