@@ -3,7 +3,7 @@ UNet host code is written against.
 
 torch is used here only for device memory (``torch.empty``), the current HIP stream handle and
 pointer extraction; every arithmetic op goes through the C-ABI.  There is NO fallback: if the
-library is missing, fails to load, or a tensor is not a bf16 CUDA tensor, these calls raise.
+library is missing, fails to load, or a tensor is not a CUDA tensor of the op set's 16-bit storage type, these calls raise.
 """
 from __future__ import annotations
 
