@@ -20,7 +20,7 @@
 //         48 anyway, so K gets a constant-1 column and Q carries -m in that slot (OFS_PAD); for D = 80 the
 //         offset enters as the MFMA's C operand (OFS_ACC).  P = exp2(S') needs no fma;
 //       - the max is lazy: the offset only moves (exchange with lane^32, rescale O, re-base S') when some score
-//         exceeds it by more than 2^3 — one wave vote per tile on the common path;
+//         exceeds it by more than 2^6 (LAZY_THR) — one wave vote per tile on the common path;
 //       - row sums come out of the matrix pipe: a spare V^T row holds ones, so O^T[row D] = sum_k P.
 //   * O^T accumulators keep the query in lane&31 too, so the (rare) rescale is a plain per-lane multiply.
 //   * K/V images are double-buffered in LDS: tile t+1 is written (from registers filled during the previous
@@ -45,7 +45,7 @@ int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default dispatch, 5 = plain 
 namespace {
 
 constexpr int OFS_FMA = 0, OFS_PAD = 1, OFS_ACC = 2;
-constexpr float LAZY_THR = 3.0f;     // log2 units: P may reach 2^3 before the offset moves
+constexpr float LAZY_THR = 6.0f;     // log2 units: P may reach 2^6 before the offset moves
 
 struct AttnParams {
   const uint16_t* Q; const uint16_t* K; const uint16_t* V; uint16_t* O;
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 //   step j:   MFMA  | QK^T(j+1) (3·QT)                 | PV(j-1) (4·QT)                          |
 //             VALU  | exp/cvt of S(j), first part       | exp/cvt of S(j), rest; max of S(j+1)    | vote
 //
-// Lazy offset as in the kernels above (the offset rides in the spare contraction slot, P may reach 2^3); the vote of
+// Lazy offset as in the kernels above (the offset rides in the spare contraction slot, P may reach 2^6); the vote of
 // step j covers S(j+1), i.e. it precedes the exponentiation of S(j+1).  When it fires (rare) everything still relative
 // to the old offset is folded into O first — P(j) is accumulated at once and cleared so that the regular PV(j) of the
 // next step adds zero — then O is rescaled, S(j+1) re-based and the Q slot rewritten.
