@@ -1,0 +1,370 @@
+"""Differentiable view of the op set (training path).
+
+The reference trains the motion modules and the ``*_i2v`` projections with plain torch autograd
+(``train.py:576-590``: ``unet(...)`` under autocast, ``loss.backward()``).  The drop-in keeps that contract:
+``AutogradOps(base)`` exposes the same methods as ``HipOps`` (``animate3d_amd/unet.py`` is written against them), each one a
+``torch.autograd.Function`` whose forward is the inference kernel and whose backward is built from the backward kernels of
+``include/animate3d_hip.h`` ("Training path") plus the forward GEMM / conv kernels on transposed operands:
+
+    gemm            dX = dY W            (a3d_gemm on W^T),  dW = dY^T X (a3d_transpose x2 + a3d_gemm),  db = a3d_colsum
+    conv3x3         dX = conv(dY, flipped W^T) (+ a3d_zero_insert2x for stride 2, a3d_upsample2x_bwd behind the up-sampler)
+    gemm_geglu      projection recomputed, a3d_geglu_bwd, then as gemm
+    flash_attn      a3d_flash_attn_bwd     temporal_attn  a3d_temporal_attn_bwd
+    group_norm      a3d_group_norm_sums + a3d_group_norm_bwd        layer_norm  a3d_layer_norm_bwd
+
+torch's autograd engine only walks the graph (and sums the gradients of tensors that feed several branches); no arithmetic of
+the backward pass is left to eager torch except those sums, the column slices of fused projections and the merge-coefficient
+reduction over a weight-sized tensor (see ``_Gemm.backward``).  ``base`` is ``HipOps`` in the product; the CPU tests run the same
+class over ``tests/torch_ops.TorchRefOps`` to check every formula against autograd of the oracle without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .hip_ops import RowMap
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.contiguous()
+
+
+class _Gemm(torch.autograd.Function):
+    """Y = alpha (X W^T + bias + rowbias) + beta R;  ``alpha_t``: optional 0-dim tensor the float ``alpha`` was read from (the
+    AlphaBlender merge weight of attention_processor.py:700-713, a trainable scalar)."""
+
+    @staticmethod
+    def forward(ctx, aops, x, w, bias, residual, rowbias, alpha_t, alpha, beta, rb_div):
+        base = aops.base
+        ctx.aops, ctx.alpha, ctx.beta = aops, alpha, beta
+        ctx.save_for_backward(x, w, bias)
+        return base.gemm(x, w, bias, residual=residual, alpha=alpha, beta=beta, rowbias=rowbias, rb_div=rb_div)
+
+    @staticmethod
+    def backward(ctx, dy):
+        aops, base = ctx.aops, ctx.aops.base
+        x, w, bias = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if need[5]:
+            raise NotImplementedError("gradient of a GEMM row-bias (time-embedding projection) is not part of the training path")
+        dx = dw = db = dres = dalpha = None
+        if need[1]:
+            dx = base.gemm(dy, aops.transposed_weight(w), alpha=ctx.alpha)
+        if need[6]:
+            # d alpha = sum dY * (X W^T + bias) = sum W * (dY^T X) + bias . colsum(dY): the wgrad product in fp32 (a3d_gemm_f32out), then a
+            # weight-sized reduction — heavy cancellation, so the 16-bit rounding of dW must not come first
+            dw_u = base.gemm_f32out(base.transpose(dy), base.transpose(x))          # dY^T X  [N, K] fp32
+            db_u = base.colsum(dy) if bias is not None else None
+            dalpha = (w.float() * dw_u).sum()
+            if db_u is not None:
+                dalpha = dalpha + (bias.float() * db_u).sum()
+            if need[2]:
+                dw = (dw_u * ctx.alpha).to(w.dtype)
+            if need[3]:
+                db = db_u * ctx.alpha
+        elif need[2]:
+            dw = base.gemm(base.transpose(dy), base.transpose(x), alpha=ctx.alpha)  # dY^T X  [N, K]
+            if need[3]:
+                db = base.colsum(dy, ctx.alpha)
+        elif need[3]:
+            db = base.colsum(dy, ctx.alpha)
+        if need[4]:
+            dres = dy if ctx.beta == 1.0 else base.scaled(_c(dy), ctx.beta)
+        return None, dx, dw, db, dres, None, dalpha, None, None, None
+
+
+class _GemmGeglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, x, w_il, b_il):
+        ctx.aops = aops
+        ctx.save_for_backward(x, w_il, b_il)
+        return aops.base.gemm_geglu(x, w_il, b_il)
+
+    @staticmethod
+    def backward(ctx, dy):
+        aops, base = ctx.aops, ctx.aops.base
+        x, w_il, b_il = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        proj = base.gemm(x, w_il, b_il)                     # recomputed: the forward keeps only its input
+        dp = base.geglu_bwd(proj, _c(dy))
+        dx = base.gemm(dp, aops.transposed_weight(w_il)) if need[1] else None
+        dw = base.gemm(base.transpose(dp), base.transpose(x)) if need[2] else None
+        db = base.colsum(dp) if need[3] else None
+        return None, dx, dw, db
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, x, w, bias, residual, rowbias, B, H, W, stride, up2x, rb_div, up_size):
+        ctx.aops, ctx.geom = aops, (B, H, W, stride, up2x, up_size)
+        ctx.save_for_backward(w)
+        ctx.cin = x.shape[1]
+        y, _, _ = aops.base.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up2x, rowbias=rowbias, rb_div=rb_div, residual=residual, up_size=up_size)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        aops, base = ctx.aops, ctx.aops.base
+        (w,) = ctx.saved_tensors
+        B, H, W, stride, up2x, up_size = ctx.geom
+        need = ctx.needs_input_grad
+        if need[2] or need[3] or need[5]:
+            raise NotImplementedError("no 3x3 convolution is trainable in the reference's configuration (train.yaml: trainable_modules = "
+                                      "'i2v.', 'motion_modules.'); weight / bias / row-bias gradients of a3d_conv3x3 are not built")
+        dy = _c(dy)
+        dx = None
+        if need[1]:
+            if dy.shape[1] % 8 != 0:          # conv_out: 4 output channels -> the im2col + K=64 GEMM route of conv_in
+                assert stride == 1 and not up2x
+                img = dy.reshape(B, 1, H, W, dy.shape[1]).permute(0, 4, 1, 2, 3).contiguous()
+                dx = base.gemm(base.im2col_in(img), aops.dgrad_weight_small(w, ctx.cin))
+            else:
+                wd = aops.dgrad_weight(w, ctx.cin)
+                if up2x:
+                    He, We = (2 * H, 2 * W) if up_size is None else (int(up_size[0]), int(up_size[1]))
+                    du, _, _ = base.conv3x3(dy, B, He, We, wd, None)
+                    dx = base.upsample2x_bwd(du, B, H, W, He, We)
+                elif stride == 2:
+                    dx, _, _ = base.conv3x3(base.zero_insert2x(dy, B, H, W), B, H, W, wd, None)
+                else:
+                    dx, _, _ = base.conv3x3(dy, B, H, W, wd, None)
+        dres = dy if need[4] else None
+        return None, dx, None, None, dres, None, None, None, None, None, None, None, None
+
+
+class _FlashAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, q, k, v, out_in, qmap, kmap, groups, heads, q_len, kv_len, out_scale):
+        ctx.aops, ctx.args = aops, (qmap, kmap, groups, heads, q_len, kv_len, out_scale)
+        ctx.save_for_backward(q, k, v)
+        if out_in is None:
+            return aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out_scale=out_scale)
+        aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out=out_in, out_scale=out_scale, accumulate=True)
+        ctx.mark_dirty(out_in)
+        return out_in
+
+    @staticmethod
+    def backward(ctx, dy):
+        base = ctx.aops.base
+        q, k, v = ctx.saved_tensors
+        qmap, kmap, groups, heads, q_len, kv_len, out_scale = ctx.args
+        need = ctx.needs_input_grad
+        dq = dk = dv = None
+        if need[1] or need[2] or need[3]:
+            # query groups that differ only in g % gdiv read the same K/V rows when the map ignores that index (gb == 0):
+            # the F frames of a video in the first-frame branches
+            g_share = kmap.gdiv if (kmap.gb == 0 and kmap.gdiv > 1 and groups % kmap.gdiv == 0) else 1
+            dq, dk, dv = base.flash_attn_bwd(q, k, v, _c(dy), qmap, kmap, groups, heads, q_len, kv_len, q_per_kv=g_share, do_scale=out_scale,
+                                             need_dq=need[1], need_dkv=need[2] or need[3])
+        return None, dq, dk, dv, (dy if need[4] else None), None, None, None, None, None, None, None
+
+
+class _TemporalAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, q, k, v, videos, frames, L, heads):
+        ctx.aops, ctx.args = aops, (videos, frames, L, heads)
+        ctx.save_for_backward(q, k, v)
+        return aops.base.temporal_attn(q, k, v, videos, frames, L, heads)
+
+    @staticmethod
+    def backward(ctx, dy):
+        q, k, v = ctx.saved_tensors
+        C = q.shape[1]
+        d = ctx.aops.base.temporal_attn_bwd(q, k, v, _c(dy), *ctx.args)
+        return None, d[:, :C], d[:, C:2 * C], d[:, 2 * C:], None, None, None, None
+
+
+class _TemporalAttnFused(torch.autograd.Function):
+    """Same, with Q | K | V the three column ranges of ONE projection output: the gradient is written as one [rows, 3C] buffer."""
+
+    @staticmethod
+    def forward(ctx, aops, qkv, videos, frames, L, heads):
+        ctx.aops, ctx.args = aops, (videos, frames, L, heads)
+        ctx.save_for_backward(qkv)
+        C = qkv.shape[1] // 3
+        return aops.base.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], videos, frames, L, heads)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (qkv,) = ctx.saved_tensors
+        C = qkv.shape[1] // 3
+        return None, ctx.aops.base.temporal_attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], _c(dy), *ctx.args), None, None, None, None
+
+
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, x, gamma, beta, B, rows, groups, eps, silu):
+        ctx.aops, ctx.args = aops, (B, rows, groups, eps, silu)
+        ctx.save_for_backward(x, gamma, beta)
+        return aops.base.group_norm(x, B, rows, gamma, beta, groups, eps, silu)
+
+    @staticmethod
+    def backward(ctx, dy):
+        base = ctx.aops.base
+        x, gamma, beta = ctx.saved_tensors
+        B, rows, groups, eps, silu = ctx.args
+        need = ctx.needs_input_grad
+        stats = base.group_norm_stats(x, B, rows, groups, eps)
+        dx, dg, db = base.group_norm_bwd(x, _c(dy), B, rows, gamma, beta, groups, stats, silu, need_param=need[2] or need[3])
+        return None, (dx if need[1] else None), (dg if need[2] else None), (db if need[3] else None), None, None, None, None, None
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, x, gamma, beta, eps, pe1, pe1_div, pe2, pe2_div, two):
+        ctx.aops, ctx.eps = aops, eps
+        ctx.save_for_backward(x, gamma)
+        ctx.set_materialize_grads(False)
+        out = aops.base.layer_norm(x, gamma, beta, eps, pe1=pe1, pe1_div=pe1_div, pe2=pe2, pe2_div=pe2_div, two=two)
+        return out if two else out
+
+    @staticmethod
+    def backward(ctx, *dys):
+        base = ctx.aops.base
+        x, gamma = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dys = [d for d in dys if d is not None]
+        if not dys:
+            return (None,) * 10
+        d = _c(dys[0])
+        if len(dys) > 1:                     # both outputs of a two-encoding call were used: their gradients add
+            d = base.axpby_(_c(dys[1]), d.clone(), 1.0, 1.0)
+        dx, dg, db = base.layer_norm_bwd(x, d, gamma, ctx.eps, need_param=need[2] or need[3])
+        return None, (dx if need[1] else None), (dg if need[2] else None), (db if need[3] else None), None, None, None, None, None, None
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, a, b):
+        ctx.ca = a.shape[1]
+        return aops.base.concat(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, dy[:, :ctx.ca], dy[:, ctx.ca:]
+
+
+class _UnpackOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aops, x, V, C, F, H, W, dtype):
+        ctx.dt = x.dtype
+        return aops.base.unpack_out(x, V, C, F, H, W, dtype)
+
+    @staticmethod
+    def backward(ctx, dout):      # [V, C, F, H, W] -> rows ((v f) h w), C: a layout change of a 4-channel tensor
+        return None, dout.permute(0, 2, 3, 4, 1).reshape(-1, dout.shape[1]).to(ctx.dt).contiguous(), None, None, None, None, None, None
+
+
+class AutogradOps:
+    """``HipOps``-compatible op set whose results carry autograd history.  Anything not listed here (``empty``, ``act_dtype``,
+    ``timestep_embed``, ``im2col_in`` ... — ops whose inputs never require a gradient) is forwarded to ``base`` unchanged."""
+
+    def __init__(self, base):
+        self.base = base
+        self._persistent = {}       # data_ptr -> (weight, derived operand): frozen weights of the persistent pack only
+
+    def __getattr__(self, name):
+        return getattr(self.base, name)
+
+    # ---- derived weight operands of the dgrad products
+    def _cached(self, w, tag, make):
+        if getattr(w, "_a3d_persistent", False) and not w.requires_grad:
+            key = (w.data_ptr(), tuple(w.shape), tag)
+            hit = self._persistent.get(key)
+            if hit is None:
+                hit = (w, make())
+                self._persistent[key] = hit
+            return hit[1]
+        return make()
+
+    def transposed_weight(self, w):
+        """W [N, K] -> W^T [K, N] (the ``weight`` operand of dX = dY W)."""
+        return self._cached(w, "t", lambda: self.base.transpose(w.detach(), pad=1))
+
+    def dgrad_weight(self, w, cin: int):
+        """Packed conv weight [Cout, (ky, kx, ci)] -> [Cin, (2-ky, 2-kx, co)]: the same kernel computes the input gradient."""
+        def make():
+            cout = w.shape[0]
+            return w.detach().reshape(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
+        return self._cached(w, "d", make)
+
+    def dgrad_weight_small(self, w, cin: int):
+        """Same for a conv with < 8 output channels (conv_out): [Cin, 64] over im2col patches of the output gradient."""
+        def make():
+            cout = w.shape[0]
+            wd = w.detach().reshape(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout)
+            out = torch.zeros((cin, 64), dtype=w.dtype, device=w.device)
+            out[:, : 9 * cout] = wd
+            return out
+        return self._cached(w, "ds", make)
+
+    # ---- the op set
+    def gemm(self, x, w, bias=None, *, residual=None, alpha=1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None):
+        if out is not None:
+            raise NotImplementedError("gemm(out=...) has no autograd form")
+        alpha_t = alpha if torch.is_tensor(alpha) else None
+        return _Gemm.apply(self, x, w, bias, residual, rowbias, alpha_t, float(alpha.detach()) if alpha_t is not None else float(alpha), beta, rb_div)
+
+    def gemm_geglu(self, x, w_il, bias_il):
+        return _GemmGeglu.apply(self, x, w_il, bias_il)
+
+    def conv3x3(self, x, B, H, W, w, bias, *, stride: int = 1, up2x: bool = False, rowbias=None, rb_div: int = 1, residual=None, up_size=None):
+        y = _Conv3x3.apply(self, x, w, bias, residual, rowbias, B, H, W, stride, up2x, rb_div, up_size)
+        He, We = ((2 * H, 2 * W) if up_size is None else (int(up_size[0]), int(up_size[1]))) if up2x else (H, W)
+        return y, (He - 1) // stride + 1, (We - 1) // stride + 1
+
+    def flash_attn(self, q, k, v, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
+                   out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False):
+        if causal:
+            raise NotImplementedError("causal attention (CLIP text tower) is not on the training path")
+        if (out is None) != (not accumulate):
+            raise NotImplementedError("flash_attn(out=...) is differentiable only as an accumulation into an existing result")
+        return _FlashAttn.apply(self, q, k, v, out, qmap, kmap, groups, heads, q_len, kv_len, out_scale)
+
+    def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int, *, q_f0: int = 0, q_frames=None):
+        if q_frames is not None and q_frames != frames:
+            raise NotImplementedError("the frame-sharded temporal attention has no backward (training shards the batch, not the frames)")
+        base = q._base
+        C = q.shape[1]
+        if (base is not None and k._base is base and v._base is base and base.dim() == 2 and base.shape[1] == 3 * C and base.is_contiguous()
+                and q.storage_offset() == base.storage_offset() and k.storage_offset() == base.storage_offset() + C
+                and v.storage_offset() == base.storage_offset() + 2 * C and q.stride() == k.stride() == v.stride() == base.stride()):
+            return _TemporalAttnFused.apply(self, base, videos, frames, L, heads)
+        return _TemporalAttn.apply(self, q, k, v, videos, frames, L, heads)
+
+    def group_norm(self, x, B, rows, gamma, beta, groups, eps, silu):
+        return _GroupNorm.apply(self, x, gamma, beta, B, rows, groups, eps, silu)
+
+    def layer_norm(self, x, gamma, beta, eps, pe1=None, pe1_div: int = 1, pe2=None, pe2_div: int = 1, two: bool = False):
+        return _LayerNorm.apply(self, x, gamma, beta, eps, pe1, pe1_div, pe2, pe2_div, two)
+
+    def concat(self, a, b):
+        return _Concat.apply(self, a, b)
+
+    def unpack_out(self, x, V, C, F, H, W, dtype):
+        return _UnpackOut.apply(self, x, V, C, F, H, W, dtype)
+
+    def _no_grad_op(self, name, x, *args):
+        if torch.is_tensor(x) and x.requires_grad:
+            raise NotImplementedError(f"{name} has no backward on the training path (its input never requires a gradient in the reference's "
+                                      "configuration: the time / camera embeddings are frozen)")
+        return getattr(self.base, name)(x, *args)
+
+    def silu(self, x):
+        return self._no_grad_op("silu", x)
+
+    def activation(self, x, kind):
+        return self._no_grad_op("activation", x, kind)
+
+    def geglu(self, x):
+        return self._no_grad_op("geglu", x)
+
+    def group_norm_apply(self, *a, **k):
+        raise NotImplementedError("the rank-split GroupNorm has no backward (training shards the batch, not the frames)")
+
+    def softmax_rows(self, *a, **k):
+        raise NotImplementedError("softmax_rows has no backward on the training path")
+
+    def gemm_f32out(self, *a, **k):
+        raise NotImplementedError("gemm_f32out has no backward on the training path")

@@ -1,0 +1,569 @@
+// Backward / optimiser kernels of the training path (reference train.py:576-601 runs these through torch autograd
+// and torch.optim.AdamW).  All HBM-bound elementwise / reduction work: 16-byte accesses, fp32 arithmetic, 16-bit storage (bf16 / fp16
+// build); the matrix products of the backward pass reuse the forward GEMM / conv kernels on transposed operands.
+#include "common.h"
+
+namespace {
+
+A3D_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------ transpose (weights and activations of the wgrad GEMMs)
+// Y[c][r] = X[r][c], r < rows, c < cols; Y columns rows .. rows_pad-1 are zero (the wgrad contraction needs K % 64 == 0).
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ X, int64_t ldx, uint16_t* __restrict__ Y, int64_t ldy,
+                                                         int64_t rows, int64_t cols, int64_t rows_pad) {
+  __shared__ uint16_t tile[64][66];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? X[r * ldx + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows_pad) Y[c * ldy + r] = tile[tx][i];
+  }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients): out[c] += alpha * sum_r X[r][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ X, int64_t ldx, int64_t rows, int64_t cols,
+                                                      int64_t rows_per_block, float* __restrict__ out, float alpha) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r_end = min(rows, r_beg + rows_per_block);
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = r_beg + ty; r < r_end; r += 4) s += h2f(X[r * ldx + c]);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < cols) atomicAdd(out + c, alpha * (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]));
+}
+
+// ------------------------------------------------------------------ GEGLU backward on the interleaved projection
+// P [M, 2N]: column blocks of 64 = [32 h | 32 gate] (HipOps.interleave_geglu); y = h * gelu(gate);  dP = [dY gelu(gate) | dY h gelu'(gate)]
+A3D_DEV float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+A3D_DEV float gelu_grad(float g) {
+  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restrict__ P, int64_t ldp, const uint16_t* __restrict__ dY, int64_t lddy,
+                                                         uint16_t* __restrict__ dP, int64_t lddp, int64_t M, int64_t N) {
+  const int64_t chunks = N / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * chunks) return;
+  const int64_t m = idx / chunks, ch = idx % chunks;
+  const int64_t blk = ch / 4, sub = ch % 4;
+  const int64_t pc = blk * 64 + sub * 8;
+  const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(P + m * ldp + pc);
+  const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(P + m * ldp + pc + 32);
+  const u32x4_t dv = *reinterpret_cast<const u32x4_t*>(dY + m * lddy + ch * 8);
+  u32x4_t dh, dg;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float h0 = lo16(hv[j]), h1 = hi16(hv[j]), g0 = lo16(gv[j]), g1 = hi16(gv[j]), d0 = lo16(dv[j]), d1 = hi16(dv[j]);
+    dh[j] = pack16(d0 * gelu_f(g0), d1 * gelu_f(g1));
+    dg[j] = pack16(d0 * h0 * gelu_grad(g0), d1 * h1 * gelu_grad(g1));
+  }
+  *reinterpret_cast<u32x4_t*>(dP + m * lddp + pc) = dh;
+  *reinterpret_cast<u32x4_t*>(dP + m * lddp + pc + 32) = dg;
+}
+
+// ------------------------------------------------------------------ y = a * x + b * y
+__global__ __launch_bounds__(256) void axpby_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int64_t n8, float a, float b) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const u32x4_t x = reinterpret_cast<const u32x4_t*>(X)[i];
+  u32x4_t y = u32x4_t{0u, 0u, 0u, 0u};
+  if (b != 0.f) y = reinterpret_cast<const u32x4_t*>(Y)[i];
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack16(a * lo16(x[j]) + b * lo16(y[j]), a * hi16(x[j]) + b * hi16(y[j]));
+  reinterpret_cast<u32x4_t*>(Y)[i] = o;
+}
+
+// ------------------------------------------------------------------ LayerNorm backward: one wave per row, CPL channels per lane
+struct LNBParams {
+  const uint16_t* X; const uint16_t* dY; const float* gamma; uint16_t* dX; float* dgamma; float* dbeta;
+  int64_t M; int C; float eps;
+};
+template <int CPL>
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const LNBParams p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int C = p.C;
+  const float invC = 1.f / (float)C;
+  float gam[CPL], dg[CPL], db[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int c = lane + 64 * k;
+    gam[k] = c < C ? p.gamma[c] : 0.f;
+    dg[k] = 0.f; db[k] = 0.f;
+  }
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wid; m < p.M; m += (int64_t)gridDim.x * 4) {
+    float x[CPL], dy[CPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      x[k] = c < C ? h2f(p.X[m * C + c]) : 0.f;
+      dy[k] = c < C ? h2f(p.dY[m * C + c]) : 0.f;
+      s += x[k];
+    }
+    const float mean = wave_sum(s) * invC;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      const float d = c < C ? x[k] - mean : 0.f;
+      v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(v) * invC + p.eps);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      x[k] = c < C ? (x[k] - mean) * rstd : 0.f;            // x-hat
+      const float g = dy[k] * gam[k];
+      a += g; b += g * x[k];
+      dg[k] += dy[k] * x[k]; db[k] += dy[k];
+    }
+    a = wave_sum(a) * invC; b = wave_sum(b) * invC;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) p.dX[m * C + c] = f2h(rstd * (dy[k] * gam[k] - a - x[k] * b));
+    }
+  }
+  if (p.dgamma) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) { atomicAdd(p.dgamma + c, dg[k]); atomicAdd(p.dbeta + c, db[k]); }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ GroupNorm (+SiLU) backward, channel-last [B][rows][C]
+struct GNBParams {
+  const uint16_t* X; const uint16_t* dY; const float* gamma; const float* beta; const float* stats;   // stats [B][groups][2] = mean, rstd
+  uint16_t* dX; float* ws;      // ws [B][C][2]: per-channel sums of g and g * x-hat (zeroed by the entry point)
+  float* dgamma; float* dbeta;
+  int B; int64_t rows; int C, groups, cg, silu; int64_t rows_per_block;
+};
+A3D_DEV float gn_upstream(float dy, float xh, float gam, float bet, int silu) {
+  if (!silu) return dy;
+  const float z = fmaf(xh, gam, bet);
+  const float sg = 1.f / (1.f + __expf(-z));
+  return dy * sg * (1.f + z * (1.f - sg));
+}
+// pass 1: per-(b, channel) sums over a chunk of rows; thread = channel (coalesced rows), atomics into ws
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GNBParams p) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  const int grp = c / p.cg;
+  const float mean = p.stats[((int64_t)b * p.groups + grp) * 2], rstd = p.stats[((int64_t)b * p.groups + grp) * 2 + 1];
+  const float gam = p.gamma[c], bet = p.beta[c];
+  const int64_t r_beg = (int64_t)blockIdx.y * p.rows_per_block, r_end = min(p.rows, r_beg + p.rows_per_block);
+  const uint16_t* x = p.X + ((int64_t)b * p.rows) * p.C + c;
+  const uint16_t* dy = p.dY + ((int64_t)b * p.rows) * p.C + c;
+  float sa = 0.f, sb = 0.f;
+  for (int64_t r = r_beg; r < r_end; ++r) {
+    const float xh = (h2f(x[r * p.C]) - mean) * rstd;
+    const float g = gn_upstream(h2f(dy[r * p.C]), xh, gam, bet, p.silu);
+    sa += g; sb += g * xh;
+  }
+  atomicAdd(p.ws + ((int64_t)b * p.C + c) * 2, sa);
+  atomicAdd(p.ws + ((int64_t)b * p.C + c) * 2 + 1, sb);
+}
+// pass 2: dx = rstd * (g gamma - s1/n - x-hat s2/n) with the group sums s1 = sum_c gamma_c A_c, s2 = sum_c gamma_c B_c
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNBParams p) {
+  __shared__ float gs[2][64];
+  const int b = blockIdx.y;
+  if (threadIdx.x < p.groups) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x * p.cg; c < (threadIdx.x + 1) * p.cg; ++c) {
+      const float gam = p.gamma[c];
+      s1 += gam * p.ws[((int64_t)b * p.C + c) * 2];
+      s2 += gam * p.ws[((int64_t)b * p.C + c) * 2 + 1];
+    }
+    const float inv_n = 1.f / ((float)p.rows * (float)p.cg);
+    gs[0][threadIdx.x] = s1 * inv_n; gs[1][threadIdx.x] = s2 * inv_n;
+  }
+  __syncthreads();
+  const int chunks = p.C / 8;
+  const int64_t total = p.rows * chunks;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / chunks;
+    const int c0 = (int)(idx % chunks) * 8;
+    const int64_t off = ((int64_t)b * p.rows + r) * p.C + c0;
+    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(p.X + off);
+    const u32x4_t dv = *reinterpret_cast<const u32x4_t*>(p.dY + off);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      const int grp = c / p.cg;
+      const float mean = p.stats[((int64_t)b * p.groups + grp) * 2], rstd = p.stats[((int64_t)b * p.groups + grp) * 2 + 1];
+      const float xr = (e & 1) ? hi16(xv[e >> 1]) : lo16(xv[e >> 1]);
+      const float dr = (e & 1) ? hi16(dv[e >> 1]) : lo16(dv[e >> 1]);
+      const float xh = (xr - mean) * rstd;
+      const float gam = p.gamma[c];
+      const float g = gn_upstream(dr, xh, gam, p.beta[c], p.silu);
+      o[e] = rstd * (g * gam - gs[0][grp] - xh * gs[1][grp]);
+    }
+    u32x4_t ov;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ov[j] = pack16(o[2 * j], o[2 * j + 1]);
+    *reinterpret_cast<u32x4_t*>(p.dX + off) = ov;
+  }
+}
+// affine gradients: dgamma_c += sum_b B_c, dbeta_c += sum_b A_c
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const GNBParams p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  float a = 0.f, bb = 0.f;
+  for (int b = 0; b < p.B; ++b) { a += p.ws[((int64_t)b * p.C + c) * 2]; bb += p.ws[((int64_t)b * p.C + c) * 2 + 1]; }
+  p.dbeta[c] += a; p.dgamma[c] += bb;
+}
+
+// ------------------------------------------------------------------ conv helpers
+// stride-2 conv dgrad = stride-1 conv of the zero-stuffed gradient: Z[b][2oy][2ox] = dY[b][oy][ox], zero elsewhere
+__global__ __launch_bounds__(256) void zero_insert_kernel(const uint16_t* __restrict__ dY, uint16_t* __restrict__ Z, int B, int H, int W, int Ho, int Wo, int C) {
+  const int chunks = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * H * W * chunks) return;
+  const int ch = (int)(idx % chunks);
+  const int64_t pix = idx / chunks;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+  u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+  if ((x & 1) == 0 && (y & 1) == 0 && (y >> 1) < Ho && (x >> 1) < Wo)
+    v = *reinterpret_cast<const u32x4_t*>(dY + (((int64_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + ch * 8);
+  *reinterpret_cast<u32x4_t*>(Z + pix * C + ch * 8) = v;
+}
+// nearest-2x upsample backward: dX[b][y][x] = sum of dU[b][2y+dy][2x+dx] inside the (possibly forced 2H-1 / 2W-1) extent
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const uint16_t* __restrict__ dU, uint16_t* __restrict__ dX, int B, int H, int W, int He, int We, int C) {
+  const int chunks = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * H * W * chunks) return;
+  const int ch = (int)(idx % chunks);
+  const int64_t pix = idx / chunks;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int uy = 2 * y + dy, ux = 2 * x + dx;
+      if (uy < He && ux < We) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(dU + (((int64_t)b * He + uy) * We + ux) * C + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[2 * j] += lo16(v[j]); acc[2 * j + 1] += hi16(v[j]); }
+      }
+    }
+  u32x4_t o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack16(acc[2 * j], acc[2 * j + 1]);
+  *reinterpret_cast<u32x4_t*>(dX + pix * C + ch * 8) = o;
+}
+
+// ------------------------------------------------------------------ temporal attention backward
+// One workgroup = one pixel x one 320-channel slab x all F frames (as the forward); thread = (40-dim slice, frame).
+constexpr int SLAB = 320, SL = 40, NSL = SLAB / SL;
+struct TABParams {
+  const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ld;
+  const uint16_t* dO; int64_t lddo;
+  uint16_t* dQ; uint16_t* dK; uint16_t* dV; int64_t ldd;
+  int frames; int64_t L; float scale, scale_log2; int64_t npix;
+};
+template <int FP, int DP>
+__global__ __launch_bounds__(NSL * FP) void temporal_attn_bwd_kernel(const TABParams p) {
+  constexpr int ROWB = SLAB + 8;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];     // [4][F][ROWB] then float Pm[NSL][F][F], dSm[NSL][F][F]
+  const int F = p.frames;
+  const int tid = threadIdx.x;
+  const int64_t pix = blockIdx.x;
+  const int c0 = blockIdx.y * SLAB;
+  const int64_t v = pix / p.L, l = pix % p.L;
+  float* const Pm = reinterpret_cast<float*>(smem + (size_t)4 * F * ROWB);
+  float* const dSm = Pm + (size_t)NSL * F * F;
+  constexpr int chunks = SLAB / 8;
+  for (int it = tid; it < 4 * F * chunks; it += NSL * FP) {
+    const int ch = it % chunks, f = (it / chunks) % F, ten = it / (chunks * F);
+    const int64_t row = (v * F + f) * p.L + l;
+    const uint16_t* src = ten == 0 ? p.Q + row * p.ld : ten == 1 ? p.K + row * p.ld : ten == 2 ? p.V + row * p.ld : p.dO + row * p.lddo;
+    *reinterpret_cast<u32x4_t*>(smem + ((size_t)ten * F + f) * ROWB + ch * 8) = *reinterpret_cast<const u32x4_t*>(src + c0 + ch * 8);
+  }
+  __syncthreads();
+  const int sl = tid % NSL, i = tid / NSL;
+  const bool act = i < F;
+  const int fi = act ? i : F - 1;
+  auto slab = [&](int ten, int f) { return smem + ((size_t)ten * F + f) * ROWB + sl * SL; };
+  float q[SL], go[SL];
+#pragma unroll
+  for (int d = 0; d < SL; ++d) { q[d] = h2f(slab(0, fi)[d]); go[d] = h2f(slab(3, fi)[d]); }
+  float s[FP], dp[FP];
+#pragma unroll
+  for (int j = 0; j < FP; ++j) {
+    float a = 0.f, b = 0.f;
+    if (j < F) {
+      const uint16_t* kr = slab(1, j); const uint16_t* vr = slab(2, j);
+#pragma unroll
+      for (int d = 0; d < SL; ++d) { a = fmaf(q[d], h2f(kr[d]), a); b = fmaf(go[d], h2f(vr[d]), b); }
+    }
+    s[j] = a; dp[j] = b;
+  }
+  if constexpr (DP >= 2) {
+#pragma unroll
+    for (int j = 0; j < FP; ++j) { s[j] += __shfl_xor(s[j], 1); dp[j] += __shfl_xor(dp[j], 1); }
+  }
+  if constexpr (DP >= 4) {
+#pragma unroll
+    for (int j = 0; j < FP; ++j) { s[j] += __shfl_xor(s[j], 2); dp[j] += __shfl_xor(dp[j], 2); }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < FP; ++j) if (j < F) mx = fmaxf(mx, s[j]);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < FP; ++j) { s[j] = (j < F) ? __builtin_amdgcn_exp2f((s[j] - mx) * p.scale_log2) : 0.f; sum += s[j]; }
+  const float inv = 1.f / sum;
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < FP; ++j) { s[j] *= inv; delta = fmaf(s[j], dp[j], delta); }
+  float dq[SL];
+#pragma unroll
+  for (int d = 0; d < SL; ++d) dq[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < FP; ++j) {
+    if (j < F) {
+      const float ds = s[j] * (dp[j] - delta) * p.scale;
+      if (act) { Pm[((size_t)sl * F + i) * F + j] = s[j]; dSm[((size_t)sl * F + i) * F + j] = ds; }
+      const uint16_t* kr = slab(1, j);
+#pragma unroll
+      for (int d = 0; d < SL; ++d) dq[d] = fmaf(ds, h2f(kr[d]), dq[d]);
+    }
+  }
+  const int64_t row = (v * F + fi) * p.L + l;
+  if (act) {
+    uint16_t* dst = p.dQ + row * p.ldd + c0 + sl * SL;
+#pragma unroll
+    for (int c = 0; c < SL / 8; ++c) {
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack16(dq[8 * c + 2 * e], dq[8 * c + 2 * e + 1]);
+      *reinterpret_cast<u32x4_t*>(dst + c * 8) = o;
+    }
+  }
+  __syncthreads();
+  // thread (slice, key frame j = i): dK_j = sum_i dS_ij Q_i, dV_j = sum_i P_ij dO_i
+  float dk[SL], dv[SL];
+#pragma unroll
+  for (int d = 0; d < SL; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  if (act) {
+    for (int qi = 0; qi < F; ++qi) {
+      const float ds = dSm[((size_t)sl * F + qi) * F + i], pp = Pm[((size_t)sl * F + qi) * F + i];
+      const uint16_t* qr = slab(0, qi); const uint16_t* gr = slab(3, qi);
+#pragma unroll
+      for (int d = 0; d < SL; ++d) { dk[d] = fmaf(ds, h2f(qr[d]), dk[d]); dv[d] = fmaf(pp, h2f(gr[d]), dv[d]); }
+    }
+    uint16_t* dkd = p.dK + row * p.ldd + c0 + sl * SL;
+    uint16_t* dvd = p.dV + row * p.ldd + c0 + sl * SL;
+#pragma unroll
+    for (int c = 0; c < SL / 8; ++c) {
+      u32x4_t a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = pack16(dk[8 * c + 2 * e], dk[8 * c + 2 * e + 1]); b[e] = pack16(dv[8 * c + 2 * e], dv[8 * c + 2 * e + 1]); }
+      *reinterpret_cast<u32x4_t*>(dkd + c * 8) = a;
+      *reinterpret_cast<u32x4_t*>(dvd + c * 8) = b;
+    }
+  }
+}
+
+template <int FP, int DP>
+int launch_tab(hipStream_t s, const TABParams& p, int C) {
+  if (p.npix > 0x7fffffffLL) return A3D_EINVAL;
+  const size_t lds = (size_t)4 * p.frames * (SLAB + 8) * sizeof(uint16_t) + (size_t)2 * NSL * p.frames * p.frames * sizeof(float);
+  static uint64_t attr_done = 0;
+  if (int rc = a3d_once_per_device(attr_done, [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_bwd_kernel<FP, DP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        4 * FP * (SLAB + 8) * 2 + 2 * NSL * FP * FP * 4); })) return rc;
+  temporal_attn_bwd_kernel<FP, DP><<<dim3((unsigned)p.npix, (unsigned)(C / SLAB)), dim3(NSL * FP), lds, s>>>(p);
+  return a3d_launch_status();
+}
+template <int DP>
+int launch_tab_dp(hipStream_t s, const TABParams& p, int C) {
+  return p.frames <= 16 ? launch_tab<16, DP>(s, p, C) : launch_tab<32, DP>(s, p, C);
+}
+
+#ifndef A3D_STORAGE_F16
+// ------------------------------------------------------------------ optimiser (fp32 master parameters in one flat buffer)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float v = g[i]; s = fmaf(v, v, s); }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+// ctrl[0] = factor applied to every gradient (1 / loss_scale, times the clip coefficient), ctrl[1] = 1 when the step must be skipped
+// (non-finite gradients: GradScaler semantics of train.py:583-590), ctrl[2] = gradient norm after unscaling
+__global__ void clip_ctrl_kernel(const float* __restrict__ sq, float max_norm, float inv_loss_scale, float* __restrict__ ctrl) {
+  const float norm = sqrtf(sq[0]) * inv_loss_scale;
+  const bool finite = isfinite(norm);
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(1.f, max_norm / (norm + 1e-6f));        // torch.nn.utils.clip_grad_norm_
+  ctrl[0] = finite ? inv_loss_scale * coef : 0.f;
+  ctrl[1] = finite ? 0.f : 1.f;
+  ctrl[2] = norm;
+}
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                     int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                     const float* __restrict__ ctrl) {
+  const float gs = ctrl ? ctrl[0] : 1.f;
+  if (ctrl && ctrl[1] != 0.f) return;                                       // skipped step: parameters and moments untouched
+  const float step = lr / bc1, rs = rsqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);                                      // decoupled weight decay (torch.optim.AdamW)
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    pi -= step * mi / (sqrtf(vi) * rs + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+#endif
+
+}  // namespace
+
+extern "C" int A3D_FN(a3d_transpose)(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int64_t cols, int64_t rows_pad) {
+  if (!X || !Y || rows <= 0 || cols <= 0 || rows_pad < rows || ldx < cols || ldy < rows_pad) return A3D_EINVAL;
+  const int64_t bx = (rows_pad + 63) / 64, by = (cols + 63) / 64;
+  if (bx > 0x7fffffffLL || by > 65535) return A3D_EINVAL;
+  transpose_kernel<<<dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)X, ldx, (uint16_t*)Y, ldy, rows, cols, rows_pad);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_colsum)(a3d_stream_t stream, const void* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha, int accumulate) {
+  if (!X || !out || rows <= 0 || cols <= 0 || ldx < cols) return A3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) { if (hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s); e != hipSuccess) return (int)e; }
+  const int64_t bx = (cols + 63) / 64;
+  int64_t by = (rows + 255) / 256; if (by > 512) by = 512;
+  const int64_t rpb = (rows + by - 1) / by;
+  colsum_kernel<<<dim3((unsigned)bx, (unsigned)by), dim3(256), 0, s>>>((const uint16_t*)X, ldx, rows, cols, rpb, out, alpha);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_geglu_bwd)(a3d_stream_t stream, const void* P, int64_t ldp, const void* dY, int64_t lddy, void* dP, int64_t lddp, int64_t M, int64_t N) {
+  if (!P || !dY || !dP || M <= 0 || N <= 0 || N % 32 != 0 || ldp % 8 || lddy % 8 || lddp % 8) return A3D_EINVAL;
+  const int64_t n = M * (N / 8);
+  geglu_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)P, ldp, (const uint16_t*)dY, lddy, (uint16_t*)dP, lddp, M, N);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_axpby)(a3d_stream_t stream, const void* X, void* Y, int64_t n, float a, float b) {
+  if (!X || !Y || n <= 0 || n % 8 != 0) return A3D_EINVAL;
+  axpby_kernel<<<dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)X, (uint16_t*)Y, n / 8, a, b);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_layer_norm_bwd)(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, void* dX,
+                                           float* dgamma, float* dbeta, int64_t M, int C, float eps, int accumulate) {
+  if (!X || !dY || !gamma || !dX || M <= 0 || C <= 0 || C > 2048 || (dgamma == nullptr) != (dbeta == nullptr)) return A3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dgamma && !accumulate) {
+    if (hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s); e != hipSuccess) return (int)e;
+    if (hipError_t e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s); e != hipSuccess) return (int)e;
+  }
+  LNBParams p{(const uint16_t*)X, (const uint16_t*)dY, gamma, (uint16_t*)dX, dgamma, dbeta, M, C, eps};
+  int64_t blocks = (M + 3) / 4; if (blocks > 2048) blocks = 2048;
+  const int cpl = (C + 63) / 64;
+  if (cpl <= 5) layer_norm_bwd_kernel<5><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  else if (cpl <= 10) layer_norm_bwd_kernel<10><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  else if (cpl <= 20) layer_norm_bwd_kernel<20><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  else layer_norm_bwd_kernel<32><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_group_norm_bwd)(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, const float* beta,
+                                           const float* stats, void* dX, float* ws, float* dgamma, float* dbeta,
+                                           int B, int64_t rows, int C, int groups, int silu) {
+  if (!X || !dY || !gamma || !beta || !stats || !dX || !ws || B <= 0 || rows <= 0 || C <= 0 || groups <= 0 || groups > 64 || C % groups != 0 || C % 8 != 0)
+    return A3D_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return A3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * C * 2 * sizeof(float), s); e != hipSuccess) return (int)e;
+  GNBParams p{(const uint16_t*)X, (const uint16_t*)dY, gamma, beta, stats, (uint16_t*)dX, ws, dgamma, dbeta, B, rows, C, groups, C / groups, silu, 0};
+  int64_t by = (rows + 63) / 64; if (by > 256) by = 256;
+  p.rows_per_block = (rows + by - 1) / by;
+  if (B > 65535) return A3D_EINVAL;
+  gn_bwd_sums_kernel<<<dim3((unsigned)((C + 255) / 256), (unsigned)by, (unsigned)B), dim3(256), 0, s>>>(p);
+  int64_t bx = (rows * (C / 8) + 255) / 256; if (bx > 4096) bx = 4096;
+  gn_bwd_apply_kernel<<<dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s>>>(p);
+  if (dgamma) gn_bwd_param_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s>>>(p);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_zero_insert2x)(a3d_stream_t stream, const void* dY, void* Z, int B, int H, int W, int C) {
+  if (!dY || !Z || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0) return A3D_EINVAL;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  zero_insert_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)dY, (uint16_t*)Z, B, H, W, Ho, Wo, C);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_upsample2x_bwd)(a3d_stream_t stream, const void* dU, void* dX, int B, int H, int W, int He, int We, int C) {
+  if (!dU || !dX || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0) return A3D_EINVAL;
+  if ((He != 2 * H && He != 2 * H - 1) || (We != 2 * W && We != 2 * W - 1)) return A3D_EINVAL;
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  upsample_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)dU, (uint16_t*)dX, B, H, W, He, We, C);
+  return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_temporal_attn_bwd)(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+                                              const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t ldd,
+                                              int videos, int frames, int64_t L, int heads, int head_dim, float scale) {
+  if (!Q || !K || !V || !dO || !dQ || !dK || !dV || videos <= 0 || frames <= 0 || frames > 32 || L <= 0 || heads <= 0) return A3D_EINVAL;
+  const int C = heads * head_dim;
+  if (C % SLAB != 0 || ldqkv % 8 || lddo % 8 || ldd % 8 || ldqkv < C || lddo < C || ldd < C) return A3D_EINVAL;
+  TABParams p{(const uint16_t*)Q, (const uint16_t*)K, (const uint16_t*)V, ldqkv, (const uint16_t*)dO, lddo,
+              (uint16_t*)dQ, (uint16_t*)dK, (uint16_t*)dV, ldd, frames, L, scale, scale * 1.4426950408889634f, (int64_t)videos * L};
+  hipStream_t s = (hipStream_t)stream;
+  switch (head_dim) {
+    case 40: return launch_tab_dp<1>(s, p, C);
+    case 80: return launch_tab_dp<2>(s, p, C);
+    case 160: return launch_tab_dp<4>(s, p, C);
+    default: return A3D_EUNSUPPORTED;
+  }
+}
+
+#ifndef A3D_STORAGE_F16
+extern "C" int a3d_sqnorm_f32(a3d_stream_t stream, const float* g, int64_t n, float* out, int accumulate) {
+  if (!g || !out || n <= 0) return A3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) { if (hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s); e != hipSuccess) return (int)e; }
+  int64_t blocks = (n + 2047) / 2048; if (blocks > 2048) blocks = 2048;
+  sqnorm_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g, n, out);
+  return a3d_launch_status();
+}
+
+extern "C" int a3d_clip_ctrl_f32(a3d_stream_t stream, const float* sqnorm, float max_norm, float inv_loss_scale, float* ctrl) {
+  if (!sqnorm || !ctrl) return A3D_EINVAL;
+  clip_ctrl_kernel<<<dim3(1), dim3(1), 0, (hipStream_t)stream>>>(sqnorm, max_norm, inv_loss_scale, ctrl);
+  return a3d_launch_status();
+}
+
+extern "C" int a3d_adamw_f32(a3d_stream_t stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* ctrl) {
+  if (!p || !g || !m || !v || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return A3D_EINVAL;
+  int64_t blocks = (n + 1023) / 1024; if (blocks > 4096) blocks = 4096;
+  adamw_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ctrl);
+  return a3d_launch_status();
+}
+#endif

@@ -67,6 +67,22 @@ _SIGNATURES = {
     "a3d_softmax_rows_f32_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "a3d_channel_mix_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_i64, c_f32]),
     "a3d_cfg_ddim_step_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_f32, c_f32, c_f32]),
+    # training path (include/animate3d_hip.h, "Training path" section)
+    "a3d_flash_attn_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
+                                        ctypes.POINTER(_RowMapC), c_int, c_int, c_int, c_i64, c_i64, c_int, c_f32, c_f32, c_int]),
+    "a3d_temporal_attn_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
+    "a3d_layer_norm_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_int]),
+    "a3d_group_norm_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int]),
+    "a3d_geglu_bwd_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
+    "a3d_transpose_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "a3d_colsum_bf16": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_f32, c_int]),
+    "a3d_axpby_bf16": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32]),
+    "a3d_zero_insert2x_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int]),
+    "a3d_upsample2x_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_sqnorm_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_int]),
+    "a3d_clip_ctrl_f32": (c_int, [c_vp, c_vp, c_f32, c_f32, c_vp]),
+    "a3d_adamw_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
 }
 # fp16-storage twins (include/animate3d_hip.h, last section): same signatures
 for _name in list(_SIGNATURES):
@@ -397,6 +413,137 @@ class HipOps:
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
         _check(self.lib.a3d_channel_mix_f32(self._stream(), _p(x), _p(w), _p(b), _p(y), B, Cin, Cout, H * W, scale), "a3d_channel_mix_f32")
         return y
+
+    # ---- training path: backward kernels (reference: torch autograd behind train.py:576-590) and the optimiser step
+    def flash_attn_bwd(self, q, k, v, do, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
+                       q_per_kv: int = 1, do_scale: float = 1.0, need_dq: bool = True, need_dkv: bool = True):
+        """Gradients of ``flash_attn`` (same maps): ``do`` = gradient of the output buffer (rows as q), scaled by ``do_scale`` (= the
+        forward's out_scale).  Returns (dq [q rows, C] | None, dk, dv [k rows, C] | None); rows of dk / dv that the K/V map never
+        reads (e.g. frames > 0 in the first-frame branch) are zero."""
+        q, k, v, do = self._act(q, "attn_bwd.q"), self._act(k, "attn_bwd.k"), self._act(v, "attn_bwd.v"), self._act(do, "attn_bwd.do")
+        C = q.shape[1]
+        D = C // heads
+        assert k.stride(0) == v.stride(0) and do.shape == q.shape
+        dq = self.empty(q.shape[0], C) if need_dq else None
+        dk = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
+        dv = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
+        stats = torch.empty((2, groups * heads * q_len), dtype=torch.float32, device=self.device)
+        qm, km, dom = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(do.stride(0))
+        dqm, dkm = qmap.c(C), kmap.c(C)
+        rc = self.lib.a3d_flash_attn_bwd_bf16(self._stream(), _p(q), _p(k), _p(v), _p(do), _p(dq), _p(dk), _p(dv), _p(stats[0]), _p(stats[1]),
+                                              ctypes.byref(qm), ctypes.byref(km), ctypes.byref(dom), ctypes.byref(dqm), ctypes.byref(dkm),
+                                              groups, heads, D, q_len, kv_len, q_per_kv, float(D) ** -0.5, do_scale, 0)
+        _check(rc, f"a3d_flash_attn_bwd_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len} q_per_kv={q_per_kv}")
+        return dq, dk, dv
+
+    def temporal_attn_bwd(self, q, k, v, do, videos: int, frames: int, L: int, heads: int):
+        """Returns one [rows, 3C] buffer = [dq | dk | dv]."""
+        q, k, v, do = self._act(q, "tattn_bwd.q"), self._act(k, "tattn_bwd.k"), self._act(v, "tattn_bwd.v"), self._act(do, "tattn_bwd.do")
+        C = q.shape[1]
+        assert q.stride(0) == k.stride(0) == v.stride(0)
+        d = self.empty(q.shape[0], 3 * C)
+        rc = self.lib.a3d_temporal_attn_bwd_bf16(self._stream(), _p(q), _p(k), _p(v), q.stride(0), _p(do), do.stride(0),
+                                                 _p(d), d.data_ptr() + 2 * C, d.data_ptr() + 4 * C, 3 * C,
+                                                 videos, frames, L, heads, C // heads, float(C // heads) ** -0.5)
+        _check(rc, f"a3d_temporal_attn_bwd_bf16 videos={videos} frames={frames} L={L} C={C}")
+        return d
+
+    def layer_norm_bwd(self, x, dy, gamma, eps: float, need_param: bool = True):
+        x, dy = self._act(x, "ln_bwd.x"), self._act(dy, "ln_bwd.dy")
+        assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape
+        M, C = x.shape
+        dx = self.empty(M, C)
+        dg = torch.empty(C, dtype=torch.float32, device=self.device) if need_param else None
+        db = torch.empty(C, dtype=torch.float32, device=self.device) if need_param else None
+        _check(self.lib.a3d_layer_norm_bwd_bf16(self._stream(), _p(x), _p(dy), _p(gamma), _p(dx), _p(dg), _p(db), M, C, eps, 0),
+               f"a3d_layer_norm_bwd_bf16 M={M} C={C}")
+        return dx, dg, db
+
+    def group_norm_stats(self, x, B: int, rows: int, groups: int, eps: float) -> torch.Tensor:
+        """fp32 [B, groups, 2] = (mean, rstd) from the fp64 sums kernel (the finalisation is a [B, groups] host-side expression)."""
+        sums = self.group_norm_sums(x, B, rows, groups)
+        cnt = float(rows * (x.shape[1] // groups))
+        mean = sums[..., 0] / cnt
+        var = (sums[..., 1] / cnt - mean * mean).clamp_min(0.0)
+        return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).to(torch.float32).contiguous()
+
+    def group_norm_bwd(self, x, dy, B: int, rows: int, gamma, beta, groups: int, stats, silu: bool, need_param: bool = False):
+        x, dy = self._act(x, "gn_bwd.x"), self._act(dy, "gn_bwd.dy")
+        assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.shape[0] == B * rows
+        C = x.shape[1]
+        dx = self.empty(x.shape[0], C)
+        ws = torch.empty(B * C * 2, dtype=torch.float32, device=self.device)
+        dg = torch.zeros(C, dtype=torch.float32, device=self.device) if need_param else None
+        db = torch.zeros(C, dtype=torch.float32, device=self.device) if need_param else None
+        _check(self.lib.a3d_group_norm_bwd_bf16(self._stream(), _p(x), _p(dy), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), _p(dg), _p(db),
+                                                B, rows, C, groups, 1 if silu else 0), f"a3d_group_norm_bwd_bf16 B={B} rows={rows} C={C}")
+        return dx, dg, db
+
+    def geglu_bwd(self, proj_il, dy):
+        proj_il, dy = self._act(proj_il, "geglu_bwd.p"), self._act(dy, "geglu_bwd.dy")
+        M, N2 = proj_il.shape
+        dp = self.empty(M, N2)
+        _check(self.lib.a3d_geglu_bwd_bf16(self._stream(), _p(proj_il), proj_il.stride(0), _p(dy), dy.stride(0), _p(dp), N2, M, N2 // 2),
+               f"a3d_geglu_bwd_bf16 M={M} N={N2 // 2}")
+        return dp
+
+    def transpose(self, x, pad: int = 64):
+        """[rows, cols] -> [cols, rows rounded up to ``pad``] (zero filled): an operand of the weight-gradient GEMM."""
+        x = self._act(x, "transpose.x")
+        rows, cols = x.shape
+        rp = (rows + pad - 1) // pad * pad
+        y = self.empty(cols, rp)
+        _check(self.lib.a3d_transpose_bf16(self._stream(), _p(x), x.stride(0), _p(y), rp, rows, cols, rp), f"a3d_transpose_bf16 {rows}x{cols}")
+        return y
+
+    def colsum(self, x, alpha: float = 1.0):
+        x = self._act(x, "colsum.x")
+        out = torch.empty(x.shape[1], dtype=torch.float32, device=self.device)
+        _check(self.lib.a3d_colsum_bf16(self._stream(), _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), alpha, 0), "a3d_colsum_bf16")
+        return out
+
+    def axpby_(self, x, y, a: float = 1.0, b: float = 1.0):
+        """y <- a x + b y (in place on ``y``)."""
+        x, y = self._act(x, "axpby.x"), self._act(y, "axpby.y")
+        assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+        _check(self.lib.a3d_axpby_bf16(self._stream(), _p(x), _p(y), x.numel(), a, b), "a3d_axpby_bf16")
+        return y
+
+    def scaled(self, x, a: float):
+        return self.axpby_(x, torch.empty_like(x), a, 0.0)
+
+    def zero_insert2x(self, dy, B: int, H: int, W: int):
+        dy = self._act(dy, "zero_insert.dy")
+        assert dy.is_contiguous() and dy.shape[0] == B * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1)
+        z = self.empty(B * H * W, dy.shape[1])
+        _check(self.lib.a3d_zero_insert2x_bf16(self._stream(), _p(dy), _p(z), B, H, W, dy.shape[1]), "a3d_zero_insert2x_bf16")
+        return z
+
+    def upsample2x_bwd(self, du, B: int, H: int, W: int, He: int, We: int):
+        du = self._act(du, "upsample_bwd.du")
+        assert du.is_contiguous() and du.shape[0] == B * He * We
+        dx = self.empty(B * H * W, du.shape[1])
+        _check(self.lib.a3d_upsample2x_bwd_bf16(self._stream(), _p(du), _p(dx), B, H, W, He, We, du.shape[1]), "a3d_upsample2x_bwd_bf16")
+        return dx
+
+    def sqnorm(self, g: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+        assert g.dtype == torch.float32 and g.is_contiguous()
+        out = out if out is not None else torch.empty(1, dtype=torch.float32, device=self.device)
+        _check(self.raw_lib.a3d_sqnorm_f32(self._stream(), _p(g), g.numel(), _p(out), 1 if accumulate else 0), "a3d_sqnorm_f32")
+        return out
+
+    def clip_ctrl(self, sq: torch.Tensor, max_norm: float, inv_loss_scale: float = 1.0):
+        ctrl = torch.empty(3, dtype=torch.float32, device=self.device)
+        _check(self.raw_lib.a3d_clip_ctrl_f32(self._stream(), _p(sq), max_norm, inv_loss_scale, _p(ctrl)), "a3d_clip_ctrl_f32")
+        return ctrl
+
+    def adamw_(self, p, g, m, v, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, step: int = 1, ctrl=None):
+        for t in (p, g, m, v):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+        b1, b2 = betas
+        _check(self.raw_lib.a3d_adamw_f32(self._stream(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, weight_decay,
+                                          1.0 - b1 ** step, 1.0 - b2 ** step, _p(ctrl)), "a3d_adamw_f32")
+        return p
 
     def cfg_ddim_step(self, eps_pair, x, first_frame, guidance: float, alpha_t: float, alpha_prev: float):
         """Fused pipeline epilogue (pipeline.py:1023-1031); fp32 [n, C, F, H, W] tensors."""

@@ -159,6 +159,18 @@ class SpatioTemporalI2VAttnProcessor(Holder):
         a = float(torch.sigmoid(m)[0])
         return 1.0 - a, (a if sp else 0.0), (a if im else 0.0)
 
+    def blend_coefficients_t(self):
+        """Same weights with autograd history (training path): 0-dim tensors where ``mix_factor`` is involved."""
+        sp, im = self.use_spatial_attn, self.use_image_attn
+        if not self.use_alpha_blender or not (sp or im):
+            return self.blend_coefficients()
+        m = self.alpha_blender.mix_factor.float()
+        if sp and im:
+            a = torch.softmax(m, dim=0)
+            return a[1], a[0], a[2]
+        a = torch.sigmoid(m)[0]
+        return 1.0 - a, (a if sp else 0.0), (a if im else 0.0)
+
 
 # ---------------- diffusers-named containers
 class Attention(Holder):

@@ -59,6 +59,10 @@ class MVUNetMotionModel(nn.Module):
         self._ops = ops
         self._ops_auto = False
         self._packed = None
+        self._packed_frozen = None          # training: persistent pack of the frozen sub-modules (enable_training)
+        self._pack_grad = False             # True while _pack_train re-packs trainable sub-modules under autograd
+        self._train_ops = None              # AutogradOps over the op set once enable_training() was called
+        self._active_ops = None
         self._pe_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.parallel = None                # set by animate3d_amd.parallel.shard_unet
         self._frames = (0, 0)               # (frames of the call, first frame of this rank): set by forward
@@ -191,15 +195,15 @@ class MVUNetMotionModel(nn.Module):
                 if not hasattr(p, "kind"):
                     raise TypeError(f"{type(p).__name__} is not an animate3d_amd processor (see animate3d_amd.modules)")
                 mod.set_processor(p)
-        self._packed = None
+        self._invalidate()
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         res = super().load_state_dict(state_dict, strict=strict, assign=assign)
-        self._packed = None
+        self._invalidate()
         return res
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self._invalidate()
         self._pe_cache = {}
         if getattr(self, "_ops_auto", False):       # .half() / .to(bfloat16) / .to(device): the op set follows the model
             self._ops, self._ops_auto = None, False
@@ -232,7 +236,7 @@ class MVUNetMotionModel(nn.Module):
                             key = f"{name}.attentions.{j}.transformer_blocks.0.attn1.processor.to_q_i2v.weight"
                             if getattr(tb.attn1.processor, "kind", None) == "mvdream_i2v" and key not in sd:
                                 tb.attn1.processor.to_q_i2v.weight.copy_(tb.attn1.to_q.weight)
-            model._packed = None
+            model._invalidate()
         return model
 
     def _load_ip_adapter_weights(self, state_dict):
@@ -255,7 +259,7 @@ class MVUNetMotionModel(nn.Module):
                 proc.to_k_ip[0].weight.copy_(state_dict["ip_adapter"][f"{key_id}.to_k_ip.weight"])
                 proc.to_v_ip[0].weight.copy_(state_dict["ip_adapter"][f"{key_id}.to_v_ip.weight"])
                 key_id += 2
-        self._packed = None
+        self._invalidate()
 
     def init_synthetic(self, seed: int = 0):
         """Seeded on-device synthetic weights of realistic scale (no checkpoints exist offline):
@@ -277,12 +281,24 @@ class MVUNetMotionModel(nn.Module):
             for name, p in self.named_parameters():
                 if name.endswith("to_out_i2v.weight") or name.endswith("to_out_sp.weight"):
                     p.copy_(torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * 0.02)
-        self._packed = None
+        self._invalidate()
         return self
 
     # ------------------------------------------------------------------ op set / packed weights
+    def _invalidate(self):
+        """Weights / processors / dtype changed: every packed copy (and what the autograd op set derived from them) is stale."""
+        self._packed = None
+        self._packed_frozen = None
+        if self._train_ops is not None:
+            self._train_ops._persistent.clear()
+
     @property
     def ops(self):
+        if self._active_ops is not None:       # a grad-enabled forward runs on the autograd view of the op set
+            return self._active_ops
+        return self._base_ops()
+
+    def _base_ops(self):
         if self._ops is None:
             from .hip_ops import HipOps      # raises without an MI355X or without the built library
             # storage type of the kernels = the model's: fp16 for a .half() model (animatemv_guidance.py:339-346), bf16 otherwise
@@ -290,14 +306,19 @@ class MVUNetMotionModel(nn.Module):
             self._ops_auto = True
         return self._ops
 
+    def _d(self, t: torch.Tensor) -> torch.Tensor:
+        """Inference packs are detached copies; while ``_pack_train`` runs, a trainable parameter keeps its autograd history so
+        that the gradient of the packed (cast / concatenated / interleaved) kernel operand flows back to it."""
+        return t if (self._pack_grad and t.requires_grad) else t.detach()
+
     def _w(self, t: torch.Tensor) -> torch.Tensor:        # kernel weight: act dtype, contiguous
-        return t.detach().to(self.ops.act_dtype).contiguous()
+        return self._d(t).to(self.ops.act_dtype).contiguous()
 
     def _f(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:   # bias / affine: fp32
-        return None if t is None else t.detach().float().contiguous()
+        return None if t is None else self._d(t).float().contiguous()
 
     def _conv_w(self, conv: nn.Conv2d) -> torch.Tensor:   # [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
-        w = conv.weight.detach()
+        w = self._d(conv.weight)
         return self._w(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
 
     def _pack_resnet(self, r: M.ResnetBlock2D):
@@ -312,8 +333,8 @@ class MVUNetMotionModel(nn.Module):
     def _pack_ff(self, tb):
         return SimpleNamespace(n3=(self._f(tb.norm3.weight), self._f(tb.norm3.bias)),
                                # GEGLU projection rows interleaved (h | gate in blocks of 32) for the fused GEMM epilogue
-                               ff1=(self._w(self.ops.interleave_geglu(tb.ff.net[0].proj.weight.detach())),
-                                    self._f(self.ops.interleave_geglu(tb.ff.net[0].proj.bias.detach()))),
+                               ff1=(self._w(self.ops.interleave_geglu(self._d(tb.ff.net[0].proj.weight))),
+                                    self._f(self.ops.interleave_geglu(self._d(tb.ff.net[0].proj.bias)))),
                                ff2=(self._w(tb.ff.net[2].weight), self._f(tb.ff.net[2].bias)))
 
     def _pack_t2d(self, t: M.Transformer2DModel):
@@ -333,13 +354,13 @@ class MVUNetMotionModel(nn.Module):
             norm=(self._f(t.norm.weight), self._f(t.norm.bias)),
             pin=(self._conv_w(t.proj_in), self._f(t.proj_in.bias)),
             n1=(self._f(tb.norm1.weight), self._f(tb.norm1.bias)),
-            qkv=self._w(torch.cat([w.detach() for w in qkv], 0)),
+            qkv=self._w(torch.cat([self._d(w) for w in qkv], 0)),
             oi2v=(self._w(p1.to_out_i2v.weight), self._f(p1.to_out_i2v.bias)) if i2v else None,
             o1=(self._w(a1.to_out[0].weight), self._f(a1.to_out[0].bias)),
             n2=(self._f(tb.norm2.weight), self._f(tb.norm2.bias)),
             q2=self._w(a2.to_q.weight),
-            kv_text=self._w(torch.cat([a2.to_k.weight.detach(), a2.to_v.weight.detach()], 0)),
-            kv_ip=[self._w(torch.cat([k.weight.detach(), v.weight.detach()], 0)) for k, v in zip(p2.to_k_ip, p2.to_v_ip)],
+            kv_text=self._w(torch.cat([self._d(a2.to_k.weight), self._d(a2.to_v.weight)], 0)),
+            kv_ip=[self._w(torch.cat([self._d(k.weight), self._d(v.weight)], 0)) for k, v in zip(p2.to_k_ip, p2.to_v_ip)],
             ip_scale=list(p2.scale), ip_tokens=list(p2.num_tokens),
             o2=(self._w(a2.to_out[0].weight), self._f(a2.to_out[0].bias)),
             pout=(self._conv_w(t.proj_out), self._f(t.proj_out.bias)))
@@ -359,22 +380,24 @@ class MVUNetMotionModel(nn.Module):
             else:   # diffusers BasicTransformerBlock.pos_embed (sinusoidal) when the processor holds none
                 pe = sinusoidal_pos_1d(C, self.config.motion_max_seq_length)[0].to(a.to_q.weight.device)
             proc_pe = hasattr(pr, "time_pos_embed")          # the processor restores the temporal encoding itself (:583-584)
-            ct, cs, ci = pr.blend_coefficients()
+            # merge weights: python floats for inference; under _pack_train the trainable mix_factor stays a tensor (its
+            # gradient comes out of the to_out GEMMs' backward)
+            ct, cs, ci = pr.blend_coefficients_t() if self._pack_grad else pr.blend_coefficients()
             ns = SimpleNamespace(
                 heads=a.heads, spatial=pr.use_spatial_attn, image=pr.use_image_attn,
                 spatial_pe=pr.use_spatial_attn and pr.use_spatial_encoding, camera_pe=pr.use_spatial_attn and pr.use_camera_encoding,
                 n=(self._f(ln.weight), self._f(ln.bias)),
-                qkv=self._w(torch.cat([a.to_q.weight.detach(), a.to_k.weight.detach(), a.to_v.weight.detach()], 0)),
+                qkv=self._w(torch.cat([self._d(a.to_q.weight), self._d(a.to_k.weight), self._d(a.to_v.weight)], 0)),
                 o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)),
                 pe_t=self._w(pe), coef=(ct, cs, ci), proc=pr,
                 # diffusers' BasicTransformerBlock.pos_embed stays on unless the spatial branch carries an encoding
                 # (inference.py:176-178): the temporal PE then sits on the LayerNorm output that EVERY branch reads
                 block_pe=not proc_pe)
             if pr.use_spatial_attn:
-                ns.qkv_sp = self._w(torch.cat([pr.to_k_sp.weight.detach(), pr.to_v_sp.weight.detach(), pr.to_q_sp.weight.detach()], 0))   # [K; V; Q]
+                ns.qkv_sp = self._w(torch.cat([self._d(pr.to_k_sp.weight), self._d(pr.to_v_sp.weight), self._d(pr.to_q_sp.weight)], 0))   # [K; V; Q]
                 ns.osp = (self._w(pr.to_out_sp.weight), self._f(pr.to_out_sp.bias))
             if pr.use_image_attn:
-                ns.qkv_img = self._w(torch.cat([pr.to_k_i2v.weight.detach(), pr.to_v_i2v.weight.detach(), pr.to_q_i2v.weight.detach()], 0))
+                ns.qkv_img = self._w(torch.cat([self._d(pr.to_k_i2v.weight), self._d(pr.to_v_i2v.weight), self._d(pr.to_q_i2v.weight)], 0))
                 ns.oimg = (self._w(pr.to_out_i2v.weight), self._f(pr.to_out_i2v.bias))
             attns.append(ns)
         out = SimpleNamespace(norm=(self._f(m.norm.weight), self._f(m.norm.bias)),
@@ -693,8 +716,70 @@ class MVUNetMotionModel(nn.Module):
             return out
         return step
 
+    # ------------------------------------------------------------------ training
+    def enable_training(self, compute_dtype: Optional[torch.dtype] = None):
+        """Make grad-enabled forwards differentiable (train.py:576-590: ``unet(...)`` then ``loss.backward()``): they run on
+        ``animate3d_amd.autograd_ops.AutogradOps`` — the same kernels forward, the backward kernels of the C-ABI's training section
+        behind ``torch.autograd.Function`` — and read the trainable parameters (``requires_grad``; the reference trains
+        ``motion_modules.`` and ``i2v.``, configs/training/train.yaml) through per-step packed copies that keep their autograd
+        history, so ``.grad`` lands on the fp32 ``nn.Parameter`` exactly as under the reference's autocast.  ``compute_dtype``
+        (bf16 default, or fp16 = the reference's autocast type; then use a loss scaler) is the kernels' storage type for a model
+        kept in fp32.  ``torch.no_grad()`` forwards are unchanged.  Returns ``self``."""
+        from .autograd_ops import AutogradOps
+        if compute_dtype is not None and self._base_ops().act_dtype != compute_dtype:
+            if not getattr(self, "_ops_auto", False):
+                raise ValueError("enable_training(compute_dtype=...) cannot replace an op set that was passed in")
+            from .hip_ops import HipOps
+            self._ops = HipOps(self.device, compute_dtype)
+            self._invalidate()
+        self._train_ops = AutogradOps(self._base_ops())
+        return self
+
+    def _mark_persistent(self, node):
+        if torch.is_tensor(node):
+            node._a3d_persistent = True
+        elif isinstance(node, SimpleNamespace):
+            for v in vars(node).values():
+                self._mark_persistent(v)
+        elif isinstance(node, (list, tuple)):
+            for v in node:
+                self._mark_persistent(v)
+
+    def _pack_train(self):
+        """Pack for one differentiable forward: sub-modules without a trainable parameter come from a persistent detached pack
+        (so that the autograd op set can cache their transposed / flipped dgrad operands), the others are packed again with
+        ``_pack_grad`` on — a cast / cat / interleave per step, the price of fp32 master weights behind 16-bit kernels."""
+        if self._packed_frozen is None:
+            self._packed_frozen = self._pack()
+            self._packed = None                    # the inference pack goes stale as soon as an optimiser step runs
+            self._mark_persistent(self._packed_frozen)
+        Pf = self._packed_frozen
+        trainable = lambda m: m is not None and any(p.requires_grad for p in m.parameters())
+        for name, mod in (("time_embedding", self.time_embedding), ("camera_embedding", getattr(self, "camera_embedding", None)),
+                          ("encoder_hid_proj", self.encoder_hid_proj), ("conv_in", self.conv_in), ("conv_norm_out", self.conv_norm_out),
+                          ("conv_out", self.conv_out)):
+            if trainable(mod):
+                raise NotImplementedError(f"{name} is not trainable on this path (the reference trains 'motion_modules.' and 'i2v.' only)")
+        self._pack_grad = True
+        try:
+            def block(blk, pf):
+                out = SimpleNamespace(**vars(pf))
+                out.resnets = [self._pack_resnet(r) if trainable(r) else q for r, q in zip(blk.resnets, pf.resnets)]
+                if pf.t2d is not None:
+                    out.t2d = [self._pack_t2d(t) if trainable(t) else q for t, q in zip(blk.attentions, pf.t2d)]
+                out.motion = [self._pack_motion(m) if trainable(m) else q for m, q in zip(blk.motion_modules, pf.motion)]
+                if (blk.downsamplers is not None and trainable(blk.downsamplers[0])) or (blk.upsamplers is not None and trainable(blk.upsamplers[0])):
+                    raise NotImplementedError("trainable down / up-sampler convolutions are not supported")
+                return out
+            P = SimpleNamespace(**vars(Pf))
+            P.down = [block(b, q) for b, q in zip(self.down_blocks, Pf.down)]
+            P.mid = block(self.mid_block, Pf.mid)
+            P.up = [block(b, q) for b, q in zip(self.up_blocks, Pf.up)]
+        finally:
+            self._pack_grad = False
+        return P
+
     # ------------------------------------------------------------------ forward
-    @torch.no_grad()
     @on_model_device
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], encoder_hidden_states: torch.Tensor,
                 timestep_cond: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
@@ -703,7 +788,26 @@ class MVUNetMotionModel(nn.Module):
                 camera: Optional[torch.Tensor] = None, num_views: int = 4, i2v_cond_time_zero: bool = False):
         """Same contract as the reference forward (unet_motion_mv_model.py:633-867): ``sample``
         [V, C, F, h, w] with V = b*cfg*views in (b n) order, returns ``.sample`` of the same shape.
-        Inference only (the reference's callers wrap it in no_grad: pipeline.py:758, guidance :422)."""
+        Inference (the reference's callers wrap it in no_grad: pipeline.py:758, guidance :422) runs without autograd; after
+        ``enable_training()`` a grad-enabled call is differentiable (train.py:576-590)."""
+        kw = dict(timestep_cond=timestep_cond, attention_mask=attention_mask, cross_attention_kwargs=cross_attention_kwargs,
+                  added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=down_block_additional_residuals,
+                  mid_block_additional_residual=mid_block_additional_residual, return_dict=return_dict, camera=camera,
+                  num_views=num_views, i2v_cond_time_zero=i2v_cond_time_zero)
+        if self._train_ops is not None and torch.is_grad_enabled():
+            if self.parallel is not None and self.parallel.world > 1:
+                raise NotImplementedError("a sharded (shard_unet) model is inference-only; training shards the batch (train.py: DDP)")
+            self._active_ops = self._train_ops
+            try:
+                return self._forward_impl(sample, timestep, encoder_hidden_states, packed=self._pack_train(), **kw)
+            finally:
+                self._active_ops = None
+        with torch.no_grad():
+            return self._forward_impl(sample, timestep, encoder_hidden_states, packed=None, **kw)
+
+    def _forward_impl(self, sample, timestep, encoder_hidden_states, *, packed, timestep_cond, attention_mask, cross_attention_kwargs,
+                      added_cond_kwargs, down_block_additional_residuals, mid_block_additional_residual, return_dict, camera, num_views,
+                      i2v_cond_time_zero):
         assert sample.shape[0] % num_views == 0, "[UNet] input batch size must be dividable by num_views!"
         if attention_mask is not None or timestep_cond is not None or down_block_additional_residuals is not None \
                 or mid_block_additional_residual is not None:
@@ -720,7 +824,7 @@ class MVUNetMotionModel(nn.Module):
             raise ValueError(f"latent size {(H, W)} is smaller than the {1 << (nlev - 1)}x total down-sampling")
         if F > cfg.motion_max_seq_length:
             raise ValueError(f"num_frames {F} exceeds motion_max_seq_length {cfg.motion_max_seq_length}")
-        P = self._packed if self._packed is not None else self._pack()
+        P = packed if packed is not None else (self._packed if self._packed is not None else self._pack())
         dev, adt = sample.device, ops.act_dtype
         img_embeds = None if added_cond_kwargs is None else added_cond_kwargs.get("image_embeds")
         if torch.is_tensor(timestep) and timestep.numel() not in (1, V):

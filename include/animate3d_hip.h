@@ -203,6 +203,78 @@ int a3d_cfg_ddim_step_f32(a3d_stream_t stream, const float* eps_pair, const floa
 
 
 /* ---------------------------------------------------------------------------------------------------------------------
+ * Training path: the backward kernels behind `loss.backward()` of train.py:576-590 and the fused
+ * optimiser step of train.py:583-596.  The matrix products of the backward pass (dgrad = dY W, wgrad = dY^T X) reuse
+ * a3d_gemm / a3d_conv3x3 on transposed operands; what is declared here is everything else.
+ * --------------------------------------------------------------------------------------------------------------------- */
+
+/* Flash attention backward (the xformers memory_efficient_attention backward of attention_processor.py:103-105, 233-235, 405-418,
+ * 656-658, 691-693).  Same row maps as a3d_flash_attn; dO rows through `domap`, dQ through `dqmap`, dK / dV through `dkmap`
+ * (group index of the K/V maps: the first of the `q_per_kv` consecutive query groups that read that K/V, e.g. the F frames of a
+ * video in the first-frame branch; groups % q_per_kv == 0).  dO is the gradient of the attention output scaled by `do_scale`
+ * (the forward's out_scale).  lse2 / delta: fp32 scratch [groups * heads * q_len] each (log2-sum-exp and sum_k P dP per query
+ * row, recomputed here: the forward keeps nothing).  dQ may be NULL (no query gradient wanted) or dK == dV == NULL (keys / values
+ * of frozen text / image tokens); accumulate != 0 adds into dQ / dK / dV.  head_dim 40 / 64 / 80 / 160. */
+int a3d_flash_attn_bwd_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* dO,
+                            void* dQ, void* dK, void* dV, float* lse2, float* delta,
+                            const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* domap,
+                            const a3d_rowmap* dqmap, const a3d_rowmap* dkmap,
+                            int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int q_per_kv,
+                            float scale, float do_scale, int accumulate);
+
+/* Temporal attention backward (attention_processor.py:630-636 under autograd): rows ((v*F + f)*L + l); Q / K / V share the row
+ * stride ldqkv, dQ / dK / dV share ldd (e.g. the three column ranges of one [rows, 3C] gradient buffer).  frames <= 32. */
+int a3d_temporal_attn_bwd_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+                               const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t ldd,
+                               int videos, int frames, int64_t L, int heads, int head_dim, float scale);
+
+/* LayerNorm backward (diffusers BasicTransformerBlock.norm1/2/3): dX [M, C]; dgamma / dbeta fp32 [C] (both or neither;
+ * accumulate == 0 zeroes them first).  C <= 2048. */
+int a3d_layer_norm_bwd_bf16(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, void* dX,
+                            float* dgamma, float* dbeta, int64_t M, int C, float eps, int accumulate);
+
+/* GroupNorm (+ fused SiLU) backward on channel-last [B][rows][C] (ResnetBlock2D.norm1/2, Transformer2DModel.norm, the 3-D norm of
+ * TransformerTemporalModel): stats fp32 [B][groups][2] = (mean, rstd) as a3d_group_norm_apply takes them; ws fp32 [B*C*2] scratch;
+ * dgamma / dbeta fp32 [C], ADDED to (both or neither). */
+int a3d_group_norm_bwd_bf16(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, const float* beta,
+                            const float* stats, void* dX, float* ws, float* dgamma, float* dbeta,
+                            int B, int64_t rows, int C, int groups, int silu);
+
+/* GEGLU backward on the interleaved projection P [M, 2N] of a3d_gemm_geglu (column blocks [32 h | 32 gate]):
+ * dP = [dY * gelu(gate) | dY * h * gelu'(gate)] in the same layout.  N % 32 == 0. */
+int a3d_geglu_bwd_bf16(a3d_stream_t stream, const void* P, int64_t ldp, const void* dY, int64_t lddy, void* dP, int64_t lddp,
+                       int64_t M, int64_t N);
+
+/* Y[c][r] = X[r][c] (r < rows, c < cols), Y[c][rows .. rows_pad) = 0: operands of the weight-gradient GEMM dW = dY^T X, whose
+ * contraction (the token rows) must be a multiple of 64. */
+int a3d_transpose_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int64_t cols,
+                       int64_t rows_pad);
+
+/* out[c] (+)= alpha * sum_r X[r][c]  (bias gradients), fp32 out. */
+int a3d_colsum_bf16(a3d_stream_t stream, const void* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha, int accumulate);
+
+/* Y = a X + b Y over n elements (n % 8 == 0): sum of the gradients of two branches. */
+int a3d_axpby_bf16(a3d_stream_t stream, const void* X, void* Y, int64_t n, float a, float b);
+
+/* dgrad helper of the stride-2 down-sampling conv: Z [B, H, W, C] = dY [B, Ho, Wo, C] at the even positions, zero elsewhere
+ * (Ho = (H-1)/2 + 1); the input gradient then is a stride-1 a3d_conv3x3 of Z with the flipped, transposed weight. */
+int a3d_zero_insert2x_bf16(a3d_stream_t stream, const void* dY, void* Z, int B, int H, int W, int C);
+
+/* Backward of the nearest up-sampling in front of the up-sampler conv: dX [B, H, W, C] = sum of the <= 4 positions of
+ * dU [B, He, We, C] each input pixel was copied to (He = 2H or 2H-1, likewise We: the forced sizes of unet_motion_mv_model.py:831-837). */
+int a3d_upsample2x_bwd_bf16(a3d_stream_t stream, const void* dU, void* dX, int B, int H, int W, int He, int We, int C);
+
+/* Optimiser over ONE flat fp32 buffer holding every trainable parameter (and flat gradient / moment buffers of the same length):
+ *   a3d_sqnorm_f32     out[0] (+)= sum g^2
+ *   a3d_clip_ctrl_f32  ctrl[0] = inv_loss_scale * min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_, train.py:586,593),
+ *                      ctrl[1] = 1 if the norm is not finite (GradScaler: skip the step), ctrl[2] = the unscaled norm
+ *   a3d_adamw_f32      torch.optim.AdamW step (decoupled weight decay) on g * ctrl[0], skipped when ctrl[1] != 0; ctrl may be NULL. */
+int a3d_sqnorm_f32(a3d_stream_t stream, const float* g, int64_t n, float* out, int accumulate);
+int a3d_clip_ctrl_f32(a3d_stream_t stream, const float* sqnorm, float max_norm, float inv_loss_scale, float* ctrl);
+int a3d_adamw_f32(a3d_stream_t stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* ctrl);
+
+/* ---------------------------------------------------------------------------------------------------------------------
  * fp16-storage twins.  Every entry point above that reads or writes 16-bit activations / weights exists a second time with
  * IEEE fp16 as the storage type (same signature, same semantics, same fp32 accumulation / statistics / softmax; the MFMA is
  * v_mfma_f32_32x32x16_f16): the dtype the reference's 4D-SDS caller runs the UNet in (animatemv_guidance.py:339-346 casts
@@ -248,6 +320,28 @@ int a3d_timestep_embed_f16(a3d_stream_t stream, const float* t, void* Y, int V, 
 int a3d_im2col_in_f16(a3d_stream_t stream, const void* sample, int dtype, void* Y, int V, int C, int F, int H, int W);
 int a3d_unpack_out_f16(a3d_stream_t stream, const void* X, void* Y, int dtype, int V, int C, int F, int H, int W);
 int a3d_softmax_rows_f32_f16(a3d_stream_t stream, const float* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N);
+int a3d_flash_attn_bwd_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* dO,
+                            void* dQ, void* dK, void* dV, float* lse2, float* delta,
+                            const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* domap,
+                            const a3d_rowmap* dqmap, const a3d_rowmap* dkmap,
+                            int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int q_per_kv,
+                            float scale, float do_scale, int accumulate);
+int a3d_temporal_attn_bwd_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
+                               const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t ldd,
+                               int videos, int frames, int64_t L, int heads, int head_dim, float scale);
+int a3d_layer_norm_bwd_f16(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, void* dX,
+                            float* dgamma, float* dbeta, int64_t M, int C, float eps, int accumulate);
+int a3d_group_norm_bwd_f16(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, const float* beta,
+                            const float* stats, void* dX, float* ws, float* dgamma, float* dbeta,
+                            int B, int64_t rows, int C, int groups, int silu);
+int a3d_geglu_bwd_f16(a3d_stream_t stream, const void* P, int64_t ldp, const void* dY, int64_t lddy, void* dP, int64_t lddp,
+                       int64_t M, int64_t N);
+int a3d_transpose_f16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int64_t cols,
+                       int64_t rows_pad);
+int a3d_colsum_f16(a3d_stream_t stream, const void* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha, int accumulate);
+int a3d_axpby_f16(a3d_stream_t stream, const void* X, void* Y, int64_t n, float a, float b);
+int a3d_zero_insert2x_f16(a3d_stream_t stream, const void* dY, void* Z, int B, int H, int W, int C);
+int a3d_upsample2x_bwd_f16(a3d_stream_t stream, const void* dU, void* dX, int B, int H, int W, int He, int We, int C);
 
 #ifdef __cplusplus
 }

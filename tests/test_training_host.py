@@ -1,0 +1,266 @@
+"""CPU tests of the training path's HOST logic: the product UNet runs a grad-enabled forward on
+``AutogradOps`` over the plain-torch op set of tests/torch_ops.py, and the gradients that ``loss.backward()`` leaves on its
+parameters must equal those torch autograd leaves on the oracle's restatement of the reference forward for the loss of
+train.py:540-577 (first frame clean, noise prediction on the rest).  This pins every backward composition of
+animate3d_amd/autograd_ops.py (dgrad / wgrad through transposed operands, flipped conv weights, zero-stuffed stride-2 dgrad,
+up-sampler backward, recomputed GEGLU projection, first-frame K/V sharing, accumulated IP-adapter attention, merge-weight
+gradient) and the per-step differentiable weight packing of unet.py; the kernels themselves are -m gpu."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from animate3d_amd.config import UNetConfig
+from animate3d_amd.unet import MVUNetMotionModel
+from oracle import unet_ref as O
+from tests.torch_ops import TorchRefOps
+
+SMALL = dict(block_out_channels=(32, 64, 64, 64))
+TRAINABLE = ("i2v.", "motion_modules.")          # configs/training/train.yaml: trainable_modules
+
+
+def _pair(n, Fr, hw, **cfgkw):
+    ocfg = O.UNetConfig(**SMALL, **cfgkw)
+    ref = O.MVUNetMotionModelRef(ocfg, n, Fr, hw)
+    O.init_synthetic_weights(ref, seed=0, dense=True)
+    model = MVUNetMotionModel(UNetConfig(**SMALL, **cfgkw), ops=TorchRefOps(), num_views=n)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    for m in (ref, model):                        # train.py:343-349
+        m.requires_grad_(False)
+        for name, p in m.named_parameters():
+            if any(t in name for t in TRAINABLE):
+                p.requires_grad = True
+    return ocfg, ref, model
+
+
+def _loss(unet, inp, target):
+    # the oracle's forward is wrapped in no_grad (it restates the inference call sites); its body is plain differentiable torch
+    fwd = type(unet).forward.__wrapped__.__get__(unet) if isinstance(unet, O.MVUNetMotionModelRef) else unet
+    pred = fwd(**inp).sample                      # train.py:570-577
+    return F.mse_loss(pred[:, :, 1:].float(), target.float(), reduction="mean")
+
+
+@pytest.mark.parametrize("n,Fr,hw,kw", [
+    (2, 3, (8, 8), {}),
+    (2, 2, (12, 20), {}),                                                   # forced up-sample sizes in the backward
+    (2, 2, (8, 8), dict(motion_use_alpha_blender=False)),
+    (2, 2, (8, 8), dict(mvdream_image_attn=False, motion_spatial_attn=False)),
+])
+def test_parameter_gradients_match_autograd_of_the_oracle(n, Fr, hw, kw):
+    ocfg, ref, model = _pair(n, Fr, hw, **kw)
+    inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=3, cfg_doubled=False)
+    g = torch.Generator().manual_seed(1)
+    target = torch.randn(n, 4, Fr - 1, hw[0], hw[1], generator=g)
+    model.enable_training()
+    # Yardstick = the oracle in float64.  Its own fp32 autograd is the noise floor: the gradients of the merge weights and of the
+    # deepest layers are long, heavily cancelling sums (fp32 autograd of the oracle is off by up to ~5 % on a mix_factor), so the
+    # bar per tensor is "within 5x the oracle's fp32-vs-fp64 difference" (or 1e-3 of the tensor's largest gradient).
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else ({k: w.double() for k, w in v.items()} if isinstance(v, dict) else v)
+    l_ref = _loss(ref64, {k: dbl(v) for k, v in inp.items()}, target.double())
+    l_ref.backward()
+    _loss(ref, inp, target).backward()
+    l = _loss(model, inp, target)
+    assert l.requires_grad
+    l.backward()
+    assert abs(l.item() - l_ref.item()) < 1e-4 * abs(l_ref.item())
+    g64 = {k: p.grad for k, p in ref64.named_parameters() if p.requires_grad}
+    g32 = {k: p.grad for k, p in ref.named_parameters() if p.requires_grad}
+    got = {k: p.grad for k, p in model.named_parameters() if p.requires_grad}
+    assert set(g64) == set(got) and len(got) > 100
+    top = max(float(g.abs().max()) for g in g64.values() if g is not None)
+    worst = 0.0
+    for k, gr in g64.items():
+        assert got[k] is not None, f"no gradient reached {k}"
+        if gr is None:
+            continue
+        scale = float(gr.abs().max())
+        err = float((got[k].double() - gr).abs().max())
+        floor = float((g32[k].double() - gr).abs().max())
+        rel = 2e-2 if k.endswith("mix_factor") else 1e-3      # merge weight: sum over W * dW (weight space) instead of dY * T (token space)
+        assert err <= max(5.0 * floor, rel * scale, 1e-6 * top), (k, err, floor, scale)
+        if scale > 1e-4 * top:
+            worst = max(worst, err / scale)
+    print(f"[parity] {len(got)} trainable tensors, worst max-abs gradient error / max |grad| (tensors above 1e-4 of the largest) = {worst:.2e}")
+    # frozen parameters stay without gradient, and a no_grad forward is the inference path
+    assert all(p.grad is None for k, p in model.named_parameters() if not p.requires_grad)
+    with torch.no_grad():
+        y = model(**inp).sample
+    assert not y.requires_grad
+
+
+def test_training_rejects_what_it_cannot_differentiate():
+    ocfg, ref, model = _pair(2, 2, (8, 8))
+    inp = O.synthetic_inputs(ocfg, 2, 2, 2, (8, 8), seed=3, cfg_doubled=False)
+    model.enable_training()
+    model.conv_in.weight.requires_grad = True
+    with pytest.raises(NotImplementedError):
+        model(**inp)
+    model.conv_in.weight.requires_grad = False
+    model.down_blocks[0].resnets[0].conv1.weight.requires_grad = True        # a 3x3 conv weight: no wgrad kernel
+    with pytest.raises(NotImplementedError):
+        model(**inp).sample.sum().backward()
+
+
+# ------------------------------------------------------------------ the optimisation step (animate3d_amd/train.py)
+def _batch(ocfg, b, n, Fr, hw, seed):
+    g = torch.Generator().manual_seed(seed)
+    return dict(latents=torch.randn(b, n, 4, Fr, hw[0], hw[1], generator=g) * 0.5,
+                text=torch.randn(b, 77, ocfg.cross_attention_dim, generator=g),
+                cameras=torch.randn(b * n, 16, generator=g),
+                image_embeds=torch.randn(b * n, ocfg.ip_image_embed_dim, generator=g),
+                noise=torch.randn(b, n, 4, Fr - 1, hw[0], hw[1], generator=g),
+                timesteps=torch.randint(0, 1000, (b,), generator=g))
+
+
+def _reference_steps(ref, batches, n, steps_lr=1e-3):
+    """train.py:351-357, 540-596 with stock torch on the oracle: AdamW + clip_grad_norm_(1.0), no autocast (fp32)."""
+    from animate3d_amd.denoise import ddim_schedule
+    from animate3d_amd.train import add_noise
+    ac = ddim_schedule(25)[1]
+    fwd = type(ref).forward.__wrapped__.__get__(ref)
+    params = [p for p in ref.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=steps_lr, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    losses = []
+    for bt in batches:
+        lat = bt["latents"]
+        b, nn_, c, f, h, w = lat.shape
+        noisy = torch.cat([lat[:, :, :, :1], add_noise(lat[:, :, :, 1:], bt["noise"], bt["timesteps"], ac)], dim=3).reshape(b * nn_, c, f, h, w)
+        ehs = bt["text"][:, None].expand(b, nn_, 77, -1).reshape(b * nn_, 77, -1)
+        t = bt["timesteps"][:, None].expand(b, nn_).reshape(-1)
+        added = None if bt["image_embeds"] is None else {"image_embeds": bt["image_embeds"]}
+        pred = fwd(noisy, t, encoder_hidden_states=ehs, camera=bt["cameras"], num_views=n, added_cond_kwargs=added).sample
+        loss = F.mse_loss(pred.reshape(b, nn_, c, f, h, w)[:, :, :, 1:].float(), bt["noise"].float())
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+    return losses
+
+
+def _product_steps(model, batches, n, lr=1e-3, group=None, **optkw):
+    from animate3d_amd.denoise import ddim_schedule
+    from animate3d_amd.train import FlatAdamW, training_step
+    ac = ddim_schedule(25)[1]
+    model.enable_training()
+    opt = FlatAdamW([p for p in model.parameters() if p.requires_grad], model.ops, lr=lr, **optkw)
+    out = []
+    for bt in batches:
+        out.append(training_step(model, opt, bt["latents"], bt["text"], bt["cameras"], bt["image_embeds"], alphas_cumprod=ac, num_views=n,
+                                 noise=bt["noise"], timesteps=bt["timesteps"], group=group))
+    return out, opt
+
+
+def test_training_steps_follow_torch_adamw_on_the_oracle():
+    n, Fr, hw = 2, 3, (8, 8)
+    ocfg, ref, model = _pair(n, Fr, hw)
+    batches = [_batch(ocfg, 1, n, Fr, hw, seed=10 + i) for i in range(3)]
+    p0 = {k: p.detach().clone() for k, p in ref.named_parameters() if p.requires_grad}
+    want = _reference_steps(ref, batches[:1], n)
+    g0 = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.requires_grad}       # clipped gradient of step 0
+    got, opt = _product_steps(model, batches[:1], n)
+    assert abs(got[0]["loss"] - want[0]) < 1e-5 * abs(want[0]) and not got[0]["skipped"]
+    # First AdamW step: every element moves by ~lr * sign(g) (plus weight decay).  Elements whose gradient is fp32 noise (e.g. a bias
+    # in front of a GroupNorm: exactly zero in exact arithmetic) get a coin-flip sign in ANY implementation, so the comparison
+    # runs over the elements that carry a gradient worth the name.
+    pm, pr = dict(model.named_parameters()), dict(ref.named_parameters())
+    tot = bad = 0
+    for k, g in g0.items():
+        sig = g.abs() > 1e-2 * g.abs().max().clamp_min(1e-30)
+        d_ref, d_got = (pr[k].detach() - p0[k])[sig], (pm[k].detach() - p0[k])[sig]
+        tot += int(sig.sum())
+        bad += int(((d_ref - d_got).abs() > 0.05 * d_ref.abs()).sum())
+    print(f"[parity] first AdamW step: {tot} parameter elements with a significant gradient, {bad} moved differently (> 5 %)")
+    assert tot > 10_000 and bad <= 1e-3 * tot
+    # two more steps from each side's own parameters: the losses stay together
+    want += _reference_steps(ref, batches[1:], n)
+    from animate3d_amd.denoise import ddim_schedule
+    from animate3d_amd.train import training_step
+    for bt in batches[1:]:
+        got.append(training_step(model, opt, bt["latents"], bt["text"], bt["cameras"], bt["image_embeds"], alphas_cumprod=ddim_schedule(25)[1],
+                                 num_views=n, noise=bt["noise"], timesteps=bt["timesteps"]))
+    for i, (g, w) in enumerate(zip(got, want)):
+        print(f"[parity] train step {i}: loss {g['loss']:.6f} (torch on the oracle {w:.6f}), grad norm {g['grad_norm']:.4f}")
+    assert abs(got[1]["loss"] - want[1]) < 2e-3 * abs(want[1])
+    assert all(p.data_ptr() >= opt.flat_p.data_ptr() for p in opt.params)
+
+
+def test_loss_scaler_skips_and_backs_off_on_overflow():
+    n, Fr, hw = 2, 2, (8, 8)
+    ocfg, ref, model = _pair(n, Fr, hw)
+    bt = _batch(ocfg, 1, n, Fr, hw, seed=3)
+    bad = dict(bt, latents=bt["latents"].clone())
+    bad["latents"][0, 0, 0, 1, 0, 0] = float("inf")
+    before = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+    got, opt = _product_steps(model, [bad, bt], n, loss_scale=1024.0)
+    assert got[0]["skipped"] and opt.loss_scale == 512.0 and not got[1]["skipped"] and opt.step_count == 1
+    changed = sum(int(not torch.equal(p, before[k])) for k, p in model.named_parameters() if p.requires_grad)
+    assert changed > 100
+
+
+# ------------------------------------------------------------------ data parallel (train.py: DDP) over gloo, world 2
+def _dp_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, Fr, hw = 2, 2, (8, 8)
+        ocfg, ref, model = _pair(n, Fr, hw)
+        from animate3d_amd.denoise import ddim_schedule
+        from animate3d_amd.train import FlatAdamW, training_step
+        bt = _batch(ocfg, 1, n, Fr, hw, seed=20 + rank)                      # this rank's shard of the global batch
+        model.enable_training()
+        opt = FlatAdamW([p for p in model.parameters() if p.requires_grad], model.ops, lr=1e-3, bucket_bytes=1 << 20)   # several buckets in flight
+        seen = {}
+        reduce = opt.all_reduce_grads
+
+        def spy(group=None):                                                 # local gradient just before the exchange
+            seen["local"] = opt.flat_g.clone()
+            return reduce(group)
+        opt.all_reduce_grads = spy
+        info = training_step(model, opt, bt["latents"], bt["text"], bt["cameras"], bt["image_embeds"], alphas_cumprod=ddim_schedule(25)[1],
+                             num_views=n, noise=bt["noise"], timesteps=bt["timesteps"])
+        locals_ = [torch.zeros_like(opt.flat_g) for _ in range(world)]
+        dist.all_gather(locals_, seen["local"])
+        total = sum(locals_)
+        err = float((opt.flat_g - total).abs().max() / total.abs().max())
+        differ = float((locals_[0] - locals_[1]).abs().max() / total.abs().max())          # the shards really are different data
+        norm = float((total / world)[:opt.numel].norm())
+        gathered = [torch.zeros_like(opt.flat_p) for _ in range(world)]
+        dist.all_gather(gathered, opt.flat_p)
+        same = all(torch.equal(gathered[0], g) for g in gathered) and differ > 1e-2
+        q.put((rank, err, same, abs(info["grad_norm"] - norm) / norm))
+    except Exception as e:
+        q.put((rank, repr(e), False, 0.0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_over_gloo():
+    """One process per GPU, batch sharded (train.py:392-399 DistributedSampler): after the bucketed all-reduce of the flat gradient
+    every rank holds the sum of the ranks' gradients, clips by the norm of their mean, takes the same AdamW step and stays
+    bit-identical to its peers.  (That the mean of per-shard gradients is the gradient of the global batch's mean loss is
+    arithmetic, not something this code decides; on these random fp32 networks it only holds to a few per cent numerically.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, same, dnorm in res:
+        assert not isinstance(err, str), err
+        print(f"[parity] rank {rank}: flat gradient after the exchange vs sum of the ranks' gradients: max err / max |g| = {err:.2e}, "
+              f"clip norm vs |mean gradient| {dnorm:.2e}")
+        assert err < 1e-6 and same and dnorm < 1e-3          # fp32 sums over 2M elements in two orders

@@ -211,3 +211,113 @@ class TorchRefOps:
         y = math.sqrt(alpha_prev) * x0 + math.sqrt(1 - alpha_prev) * e
         y[:, :, 0] = first_frame.reshape(n, x.shape[1], x.shape[3], x.shape[4])
         return y
+
+    # ------------------------------------------------------------------ training path (include/animate3d_hip.h "Training path")
+    # References of the backward kernels: torch autograd through the forward references above, in fp32.
+    def flash_attn_bwd(self, q, k, v, do, qmap, kmap, groups, heads, q_len, kv_len, *, q_per_kv=1, do_scale=1.0, need_dq=True, need_dkv=True):
+        with torch.enable_grad():
+            qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
+            o = TorchRefOps(torch.float32, q.device).flash_attn(qf, kf, vf, qmap, kmap, groups, heads, q_len, kv_len, out_scale=do_scale)
+            o.backward(do.float())
+        z = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
+        return (self._o(z(qf)) if need_dq else None, self._o(z(kf)) if need_dkv else None, self._o(z(vf)) if need_dkv else None)
+
+    def temporal_attn_bwd(self, q, k, v, do, videos, frames, L, heads):
+        with torch.enable_grad():
+            qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
+            TorchRefOps(torch.float32, q.device).temporal_attn(qf, kf, vf, videos, frames, L, heads).backward(do.float())
+        return self._o(torch.cat([qf.grad, kf.grad, vf.grad], dim=1))
+
+    def layer_norm_bwd(self, x, dy, gamma, eps, need_param=True):
+        with torch.enable_grad():
+            xf = x.detach().float().clone().requires_grad_(True)
+            g = gamma.detach().float().clone().requires_grad_(True)
+            b = torch.zeros_like(g).requires_grad_(True)
+            F.layer_norm(xf, (x.shape[1],), g, b, eps).backward(dy.float())
+        return self._o(xf.grad), (g.grad if need_param else None), (b.grad if need_param else None)
+
+    def group_norm_stats(self, x, B, rows, groups, eps):
+        t = x.float().reshape(B, rows, groups, x.shape[1] // groups)
+        mean = t.mean(dim=(1, 3))
+        var = t.var(dim=(1, 3), unbiased=False)
+        return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).float().contiguous()
+
+    def group_norm_bwd(self, x, dy, B, rows, gamma, beta, groups, stats, silu, need_param=False):
+        C = x.shape[1]
+        with torch.enable_grad():
+            xf = x.detach().float().clone().requires_grad_(True)
+            g = gamma.detach().float().clone().requires_grad_(True)
+            b = beta.detach().float().clone().requires_grad_(True)
+            t = xf.reshape(B, rows, groups, C // groups)
+            mean = t.mean(dim=(1, 3), keepdim=True)
+            var = t.var(dim=(1, 3), unbiased=False, keepdim=True)
+            eps = (1.0 / stats[:, None, :, None, 1] ** 2 - var).detach()          # the eps the statistics were taken with
+            y = ((t - mean) / torch.sqrt(var + eps)).reshape(B * rows, C) * g + b
+            if silu:
+                y = F.silu(y)
+            y.backward(dy.float())
+        return self._o(xf.grad), (g.grad if need_param else None), (b.grad if need_param else None)
+
+    def geglu_bwd(self, proj_il, dy):
+        N = proj_il.shape[1] // 2
+        with torch.enable_grad():
+            p = proj_il.detach().float().clone().requires_grad_(True)
+            blk = p.reshape(p.shape[0], N // 32, 2, 32)
+            (blk[:, :, 0].reshape(-1, N) * F.gelu(blk[:, :, 1].reshape(-1, N))).backward(dy.float())
+        return self._o(p.grad)
+
+    def transpose(self, x, pad=64):
+        rows, cols = x.shape
+        rp = (rows + pad - 1) // pad * pad
+        y = torch.zeros((cols, rp), dtype=x.dtype, device=x.device)
+        y[:, :rows] = x.t()
+        return y
+
+    def colsum(self, x, alpha=1.0):
+        return alpha * x.float().sum(dim=0)
+
+    def axpby_(self, x, y, a=1.0, b=1.0):
+        y.copy_(self._o(a * x.float() + (b * y.float() if b != 0.0 else 0.0)))
+        return y
+
+    def scaled(self, x, a):
+        return self._o(a * x.float())
+
+    def zero_insert2x(self, dy, B, H, W):
+        C = dy.shape[1]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        z = torch.zeros((B, H, W, C), dtype=dy.dtype, device=dy.device)
+        z[:, ::2, ::2] = dy.reshape(B, Ho, Wo, C)
+        return z.reshape(B * H * W, C)
+
+    def upsample2x_bwd(self, du, B, H, W, He, We):
+        C = du.shape[1]
+        with torch.enable_grad():
+            x = torch.zeros((B, C, H, W), dtype=torch.float32, device=du.device, requires_grad=True)
+            F.interpolate(x, size=(He, We), mode="nearest").backward(du.float().reshape(B, He, We, C).permute(0, 3, 1, 2))
+        return self._o(x.grad.permute(0, 2, 3, 1).reshape(B * H * W, C))
+
+    def sqnorm(self, g, out=None, accumulate=False):
+        s = (g.float() ** 2).sum().reshape(1)
+        if out is not None:
+            out.copy_(out + s if accumulate else s)
+            return out
+        return s
+
+    def clip_ctrl(self, sq, max_norm, inv_loss_scale=1.0):
+        norm = torch.sqrt(sq[0]) * inv_loss_scale
+        finite = bool(torch.isfinite(norm))
+        coef = min(1.0, max_norm / (float(norm) + 1e-6)) if (max_norm > 0 and finite) else 1.0
+        return torch.tensor([inv_loss_scale * coef if finite else 0.0, 0.0 if finite else 1.0, float(norm)], dtype=torch.float32, device=sq.device)
+
+    def adamw_(self, p, g, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, step=1, ctrl=None):
+        if ctrl is not None and float(ctrl[1]) != 0.0:
+            return p
+        gs = g * (float(ctrl[0]) if ctrl is not None else 1.0)
+        b1, b2 = betas
+        p.mul_(1.0 - lr * weight_decay)
+        m.mul_(b1).add_(gs, alpha=1.0 - b1)
+        v.mul_(b2).addcmul_(gs, gs, value=1.0 - b2)
+        denom = v.sqrt() / math.sqrt(1.0 - b2 ** step) + eps
+        p.addcdiv_(m, denom, value=-lr / (1.0 - b1 ** step))
+        return p
