@@ -52,21 +52,24 @@ class FlatAdamW:
             raise ValueError("FlatAdamW keeps fp32 master parameters on one device (the reference trains an fp32 model under autocast)")
         self.ops = ops
         self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
-        n = sum(p.numel() for p in self.params)
-        pad = (-n) % 8
+        # every parameter starts on a 256-byte boundary of the flat buffers (the kernels read affine vectors with 16-byte loads; a
+        # 1-element mix_factor would otherwise misalign everything behind it); the padding stays zero in all four buffers
+        ALIGN = 64
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = n
-        self.flat_p = torch.zeros(n + pad, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(n + pad, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n + pad, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n + pad, dtype=torch.float32, device=dev)
-        off = 0
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self.offsets):
                 k = p.numel()
                 self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + k].view(p.shape)
                 p.grad = self.flat_g[off:off + k].view(p.shape)       # autograd accumulates into this view in place
-                off += k
         self.step_count = 0
         self.loss_scale = loss_scale              # None: no scaling (bf16 kernels)
         self.growth_interval, self._good_steps = growth_interval, 0
@@ -80,10 +83,8 @@ class FlatAdamW:
                 p.grad = self.flat_g[off:off + k].view(p.shape)
 
     def _spans(self):
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             yield off, p.numel()
-            off += p.numel()
 
     def scale(self, loss: torch.Tensor) -> torch.Tensor:
         return loss if self.loss_scale is None else loss * self.loss_scale

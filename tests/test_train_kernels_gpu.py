@@ -244,7 +244,7 @@ def test_autograd_ops_attention_and_norm_compositions(ops, ref):
         k, v, q, qi = kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C], kvq[:, 3 * C:]
         y = o.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L)
         y2 = o.flash_attn(qi, k, v, qm, k0, b * F, heads, n * L, n * L)
-        t = o.temporal_attn(kvq[:, :3 * C][:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C], V, F, L, heads)
+        t = o.temporal_attn(kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C], V, F, L, heads)
         return torch.cat([y, y2, t], dim=1)
 
     kvq = rnd(rows, 4 * C, seed=1, dtype=dt)
