@@ -6,7 +6,7 @@ The reference trains the motion modules and the ``*_i2v`` projections with plain
 ``torch.autograd.Function`` whose forward is the inference kernel and whose backward is built from the backward kernels of
 ``include/animate3d_hip.h`` ("Training path") plus the forward GEMM / conv kernels on transposed operands:
 
-    gemm            dX = dY W            (a3d_gemm on W^T),  dW = dY^T X (a3d_transpose x2 + a3d_gemm),  db = a3d_colsum
+    gemm            dX = dY W            (a3d_gemm on W^T),  dW = dY^T X (a3d_wgrad: split over the token axis),  db = a3d_colsum
     conv3x3         dX = conv(dY, flipped W^T) (+ a3d_zero_insert2x for stride 2, a3d_upsample2x_bwd behind the up-sampler)
     gemm_geglu      projection recomputed, a3d_geglu_bwd, then as gemm
     flash_attn      a3d_flash_attn_bwd     temporal_attn  a3d_temporal_attn_bwd
@@ -52,9 +52,9 @@ class _Gemm(torch.autograd.Function):
         if need[1]:
             dx = base.gemm(dy, aops.transposed_weight(w), alpha=ctx.alpha)
         if need[6]:
-            # d alpha = sum dY * (X W^T + bias) = sum W * (dY^T X) + bias . colsum(dY): the wgrad product in fp32 (a3d_gemm_f32out), then a
-            # weight-sized reduction — heavy cancellation, so the 16-bit rounding of dW must not come first
-            dw_u = base.gemm_f32out(base.transpose(dy), base.transpose(x))          # dY^T X  [N, K] fp32
+            # d alpha = sum dY * (X W^T + bias) = sum W * (dY^T X) + bias . colsum(dY): the fp32 weight gradient, then a weight-sized
+            # reduction — heavy cancellation, so the 16-bit rounding of dW must not come first
+            dw_u = base.wgrad(dy, x)                                                # dY^T X  [N, K] fp32
             db_u = base.colsum(dy) if bias is not None else None
             dalpha = (w.float() * dw_u).sum()
             if db_u is not None:
@@ -64,7 +64,7 @@ class _Gemm(torch.autograd.Function):
             if need[3]:
                 db = db_u * ctx.alpha
         elif need[2]:
-            dw = base.gemm(base.transpose(dy), base.transpose(x), alpha=ctx.alpha)  # dY^T X  [N, K]
+            dw = base.wgrad(dy, x, ctx.alpha).to(w.dtype)
             if need[3]:
                 db = base.colsum(dy, ctx.alpha)
         elif need[3]:
@@ -89,7 +89,7 @@ class _GemmGeglu(torch.autograd.Function):
         proj = base.gemm(x, w_il, b_il)                     # recomputed: the forward keeps only its input
         dp = base.geglu_bwd(proj, _c(dy))
         dx = base.gemm(dp, aops.transposed_weight(w_il)) if need[1] else None
-        dw = base.gemm(base.transpose(dp), base.transpose(x)) if need[2] else None
+        dw = base.wgrad(dp, x).to(w_il.dtype) if need[2] else None
         db = base.colsum(dp) if need[3] else None
         return None, dx, dw, db
 

@@ -16,7 +16,8 @@
 // forward's row permutation (kperm), so that the 16 results of a lane are two runs of 8 consecutive rows and P / dS, packed to
 // 16 bits, ARE the B operand of the gradient products (contraction over rows) without any cross-lane movement; their A operand
 // is a transposed image [d][row] of the row-side tensor, written while staging (4 rows x 8 dims per thread, v_perm_b32).
-// First version of the training path: single-buffered LDS, div/mod row addressing on every tile — correct first, tuned later.
+// The loads of the next row tile are issued into registers before the current tile's MFMAs and written to LDS after them; a wave owns
+// one or two 32-column sub-tiles (CT) that share every row-side LDS fragment.
 #include "common.h"
 
 namespace {
@@ -35,6 +36,20 @@ struct BwdParams {
 A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
   return (g / m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (s / m.seg_len) * m.seg_stride + (s % m.seg_len);
 }
+// the same map with the group part hoisted: the staging loops evaluate it for every row of every tile, and a 64-bit
+// div / mod pair per row cost more than the tile's MFMAs in the first version (profiles/README.md, training section)
+struct GroupRows { int64_t base; int64_t seg_stride; uint32_t seg_len; };
+A3D_DEV GroupRows group_rows(const a3d_rowmap& m, int64_t g) {
+  GroupRows r;
+  r.base = (g / m.gdiv) * m.ga + (g % m.gdiv) * m.gb;
+  r.seg_stride = m.seg_stride;
+  r.seg_len = m.seg_len > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)m.seg_len;     // sequence positions are < 2^31
+  return r;
+}
+A3D_DEV int64_t row_of(const GroupRows& a, int s) {
+  const uint32_t seg = (uint32_t)s / a.seg_len;
+  return a.base + (int64_t)seg * a.seg_stride + (int64_t)((uint32_t)s - seg * a.seg_len);
+}
 
 // row (within a 32-row sub-tile) that feeds MFMA A-row i: result register r of a lane in half g then is row 16*(r>>3) + 8*g + (r&7)
 A3D_DEV int kperm(int i) {
@@ -42,8 +57,8 @@ A3D_DEV int kperm(int i) {
   return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
 }
 
-template <int D, int MODE, int NU>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
+template <int D, int MODE, int NU, int CT, bool ALIGNED, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   constexpr int BR = 32 * NU;              // rows per LDS tile
   constexpr int DK = (D + 15) / 16 * 16;   // contraction length of the score products, zero padded
   constexpr int KS = DK / 16;
@@ -53,6 +68,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
   constexpr int DCH = D / 8;               // 16-byte chunks per row
   constexpr int N_ELEMS = BR * NROW, T_ELEMS = MT * 32 * TROW;
   constexpr int NT = (MODE == MODE_STATS) ? 0 : (MODE == MODE_DQ ? 1 : 2);
+  constexpr int NCH = BR * DCH, NPT = (NCH + 255) / 256;            // natural staging: 16-byte chunks, per thread
+  constexpr int TIT = (BR / 4) * DCH, TPT = (TIT + 255) / 256;      // transposed staging: 4-row x 8-dim items, per thread
+  constexpr int WCOLS = 32 * CT;           // columns per wave
   static_assert((NROW / 8) % 2 == 1 && (TROW / 8) % 2 == 1, "LDS row strides must be an odd number of 16-B slots");
 
   __shared__ __attribute__((aligned(16))) uint16_t smem[2 * N_ELEMS + (NT > 0 ? NT : 1) * T_ELEMS];
@@ -65,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
   const int head = blockIdx.x % p.heads;
-  const int ct = blockIdx.x / p.heads;
+  const int ctile = blockIdx.x / p.heads;
   const int64_t hoff = (int64_t)head * D;
   const int64_t grp_c = (MODE == MODE_DKV) ? (int64_t)blockIdx.y * p.q_per_kv : (int64_t)blockIdx.y;   // group the column maps see
   const int clen = (MODE == MODE_DKV) ? p.kv_len : p.q_len;
@@ -79,12 +97,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
     }
   }
 
-  // ---- column operands (B fragments): lane (column l31, half g) holds X[col][16*ks + 8*g .. +7]
-  const int col = ct * 128 + wid * 32 + l31;
-  const bool col_ok = col < clen;
-  const int colc = col_ok ? col : clen - 1;
-  u32x4_t cA[KS], cB[KS];
-  {
+  // ---- column operands (B fragments): lane (column l31 of sub-tile c, half g) holds X[col][16*ks + 8*g .. +7]
+  int col[CT]; bool col_ok[CT];
+  u32x4_t cA[CT][KS], cB[CT][KS];
+  float lse_c[CT], dl_c[CT];                                  // MODE_DQ: statistics of this lane's queries
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    col[c] = ctile * (4 * WCOLS) + wid * WCOLS + 32 * c + l31;
+    col_ok[c] = col[c] < clen;
+    const int colc = col_ok[c] ? col[c] : clen - 1;
     const uint16_t* a_src; const uint16_t* b_src;
     if constexpr (MODE == MODE_DKV) {
       const int64_t row = map_row(p.km, grp_c, colc);
@@ -97,36 +118,96 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
     for (int ks = 0; ks < KS; ++ks) {
       const int d0 = 16 * ks + 8 * g;
       if (d0 < D) {
-        cA[ks] = *reinterpret_cast<const u32x4_t*>(a_src + d0);
-        cB[ks] = *reinterpret_cast<const u32x4_t*>(b_src + d0);
+        cA[c][ks] = *reinterpret_cast<const u32x4_t*>(a_src + d0);
+        cB[c][ks] = *reinterpret_cast<const u32x4_t*>(b_src + d0);
       } else {
-        cA[ks] = u32x4_t{0u, 0u, 0u, 0u};
-        cB[ks] = u32x4_t{0u, 0u, 0u, 0u};
+        cA[c][ks] = u32x4_t{0u, 0u, 0u, 0u};
+        cB[c][ks] = u32x4_t{0u, 0u, 0u, 0u};
       }
+    }
+    lse_c[c] = 0.f; dl_c[c] = 0.f;
+    if constexpr (MODE == MODE_DQ) {
+      const int64_t si = ((int64_t)blockIdx.y * p.heads + head) * p.q_len + colc;
+      lse_c[c] = p.lse2[si]; dl_c[c] = p.delta[si];
     }
   }
 
-  f32x16_t acc1[MT], acc2[MODE == MODE_DKV ? MT : 1];
+  f32x16_t acc1[CT][MT], acc2[MODE == MODE_DKV ? CT : 1][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.f;
-  if constexpr (MODE == MODE_DKV) {
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
-  }
-  float m_run = -INFINITY, l_run = 0.f, t_run = 0.f;     // MODE_STATS
-  float lse_c = 0.f, dl_c = 0.f;                          // MODE_DQ: statistics of this lane's query
-  if constexpr (MODE == MODE_DQ) {
-    const int64_t si = ((int64_t)blockIdx.y * p.heads + head) * p.q_len + colc;
-    lse_c = p.lse2[si]; dl_c = p.delta[si];
-  }
+      for (int r = 0; r < 16; ++r) {
+        acc1[c][mt][r] = 0.f;
+        if constexpr (MODE == MODE_DKV) acc2[c][mt][r] = 0.f;
+      }
+  float m_run[CT], l_run[CT], t_run[CT];                     // MODE_STATS
+#pragma unroll
+  for (int c = 0; c < CT; ++c) { m_run[c] = -INFINITY; l_run[c] = 0.f; t_run[c] = 0.f; }
 
   const int nrow_off = kperm(l31) * NROW + 8 * g;
   const int trow_off = l31 * TROW + 8 * g;
 
+  // ---- row-tile staging through registers: the loads of tile t+1 are issued before tile t's MFMAs, the LDS writes after them
+  const uint16_t* const src_a = ((MODE == MODE_DKV) ? p.Q : p.K) + hoff;      // row-side tensors: (Q, dO) in DKV, (K, V) otherwise
+  const uint16_t* const src_b = ((MODE == MODE_DKV) ? p.dO : p.V) + hoff;
+  const int64_t ld_a = (MODE == MODE_DKV) ? p.qm.ld : p.km.ld;
+  const int64_t ld_b = (MODE == MODE_DKV) ? p.dom.ld : p.km.ld;
+  const int ntiles = (rlen + BR - 1) / BR;
+  const int total_tiles = ntiles * ((MODE == MODE_DKV) ? p.q_per_kv : 1);
+  u32x4_t n1[NPT], n2[NPT], t1r[TPT][4], t2r[MODE == MODE_DKV ? TPT : 1][4];
+  float stat_r = 0.f;
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const int64_t grp_r = (MODE == MODE_DKV) ? grp_c + t / ntiles : grp_c;      // group the row maps see
+    const int r0 = (t % ntiles) * BR;
+    const GroupRows ra = (MODE == MODE_DKV) ? group_rows(p.qm, grp_r) : group_rows(p.km, grp_r);
+    const GroupRows rb = (MODE == MODE_DKV) ? group_rows(p.dom, grp_r) : ra;
+    // ALIGNED: a tile never straddles a map segment (seg_len % BR == 0), so its rows are consecutive: one division per tile
+    const int64_t tile_a = ALIGNED ? row_of(ra, r0) : 0, tile_b = ALIGNED ? ((MODE == MODE_DKV) ? row_of(rb, r0) : tile_a) : 0;
+    auto rows_of = [&](int s, int64_t& row_a, int64_t& row_b) __attribute__((always_inline)) {
+      if (s >= rlen) s = rlen - 1;
+      if constexpr (ALIGNED) {
+        row_a = tile_a + (s - r0); row_b = tile_b + (s - r0);
+      } else {
+        row_a = row_of(ra, s); row_b = (MODE == MODE_DKV) ? row_of(rb, s) : row_a;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int c = tid + 256 * i;
+      if (NCH % 256 == 0 || c < NCH) {
+        const int r = c / DCH, ch = c % DCH;
+        int64_t row_a, row_b;
+        rows_of(r0 + r, row_a, row_b);
+        n1[i] = *reinterpret_cast<const u32x4_t*>(src_a + row_a * ld_a + ch * 8);
+        n2[i] = *reinterpret_cast<const u32x4_t*>(src_b + row_b * ld_b + ch * 8);
+      }
+    }
+    if constexpr (MODE != MODE_STATS) {
+#pragma unroll
+      for (int i = 0; i < TPT; ++i) {
+        const int it = tid + 256 * i;
+        if (TIT % 256 == 0 || it < TIT) {
+          const int rq = it / DCH, ch = it % DCH;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int64_t row_a, row_b;
+            rows_of(r0 + 4 * rq + j, row_a, row_b);
+            t1r[i][j] = *reinterpret_cast<const u32x4_t*>(src_a + row_a * ld_a + ch * 8);
+            if constexpr (MODE == MODE_DKV) t2r[i][j] = *reinterpret_cast<const u32x4_t*>(src_b + row_b * ld_b + ch * 8);
+          }
+        }
+      }
+    }
+    if constexpr (MODE == MODE_DKV) {
+      if (tid < 2 * BR) {
+        int s = r0 + (tid % BR); if (s >= rlen) s = rlen - 1;
+        const int64_t si = (grp_r * p.heads + head) * (int64_t)p.q_len + s;
+        stat_r = (tid < BR) ? p.lse2[si] : p.delta[si];
+      }
+    }
+  };
   // transposed staging of 4 rows x 8 dims: word j of a row holds dims 2j (lo) and 2j+1 (hi)
   auto store_t = [&](uint16_t* T, int ch, int rq, const u32x4_t (&w)[4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -140,193 +221,203 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdParams p) {
       *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j + 1) * TROW + rq * 4) = odd;
     }
   };
-
-  const int ngrp_r = (MODE == MODE_DKV) ? p.q_per_kv : 1;
-  for (int gi = 0; gi < ngrp_r; ++gi) {
-    const int64_t grp_r = (MODE == MODE_DKV) ? grp_c + gi : grp_c;      // group the row maps see
-    for (int r0 = 0; r0 < rlen; r0 += BR) {
-      // ---- stage the row tile: natural images of both row-side tensors, transposed image(s) for the gradient products
-      for (int c = tid; c < BR * DCH; c += 256) {
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int c = tid + 256 * i;
+      if (NCH % 256 == 0 || c < NCH) {
         const int r = c / DCH, ch = c % DCH;
-        int s = r0 + r; if (s >= rlen) s = rlen - 1;
-        const uint16_t *s1, *s2;
-        if constexpr (MODE == MODE_DKV) {
-          s1 = p.Q + map_row(p.qm, grp_r, s) * p.qm.ld; s2 = p.dO + map_row(p.dom, grp_r, s) * p.dom.ld;
-        } else {
-          const int64_t row = map_row(p.km, grp_r, s);
-          s1 = p.K + row * p.km.ld; s2 = p.V + row * p.km.ld;
-        }
-        *reinterpret_cast<u32x4_t*>(N1 + r * NROW + ch * 8) = *reinterpret_cast<const u32x4_t*>(s1 + hoff + ch * 8);
-        *reinterpret_cast<u32x4_t*>(N2 + r * NROW + ch * 8) = *reinterpret_cast<const u32x4_t*>(s2 + hoff + ch * 8);
+        *reinterpret_cast<u32x4_t*>(N1 + r * NROW + ch * 8) = n1[i];
+        *reinterpret_cast<u32x4_t*>(N2 + r * NROW + ch * 8) = n2[i];
       }
-      if constexpr (MODE != MODE_STATS) {
-        for (int it = tid; it < (BR / 4) * DCH; it += 256) {
-          const int rq = it / DCH, ch = it % DCH;
-          u32x4_t w1[4], w2[4];
+    }
+    if constexpr (MODE != MODE_STATS) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            int s = r0 + 4 * rq + j; if (s >= rlen) s = rlen - 1;
-            if constexpr (MODE == MODE_DKV) {
-              w1[j] = *reinterpret_cast<const u32x4_t*>(p.Q + map_row(p.qm, grp_r, s) * p.qm.ld + hoff + ch * 8);
-              w2[j] = *reinterpret_cast<const u32x4_t*>(p.dO + map_row(p.dom, grp_r, s) * p.dom.ld + hoff + ch * 8);
-            } else {
-              w1[j] = *reinterpret_cast<const u32x4_t*>(p.K + map_row(p.km, grp_r, s) * p.km.ld + hoff + ch * 8);
-            }
-          }
-          store_t(T1, ch, rq, w1);
-          if constexpr (MODE == MODE_DKV) store_t(T2, ch, rq, w2);
+      for (int i = 0; i < TPT; ++i) {
+        const int it = tid + 256 * i;
+        if (TIT % 256 == 0 || it < TIT) {
+          store_t(T1, it % DCH, it / DCH, t1r[i]);
+          if constexpr (MODE == MODE_DKV) store_t(T2, it % DCH, it / DCH, t2r[i]);
         }
       }
-      if constexpr (MODE == MODE_DKV) {
-        if (tid < 2 * BR) {
-          int s = r0 + (tid % BR); if (s >= rlen) s = rlen - 1;
-          const int64_t si = (grp_r * p.heads + head) * (int64_t)p.q_len + s;
-          rstat[tid / BR][tid % BR] = (tid < BR) ? p.lse2[si] : p.delta[si];
-        }
-      }
-      __syncthreads();
+    }
+    if constexpr (MODE == MODE_DKV) {
+      if (tid < 2 * BR) rstat[tid / BR][tid % BR] = stat_r;
+    }
+  };
 
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int t = 0; t < total_tiles; ++t) {
+    const int r0 = (t % ntiles) * BR;
+    if (t + 1 < total_tiles) load_tile(t + 1);
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        // ---- the two score-shaped products of this 32-row sub-tile
-        f32x16_t s, dp;
+    for (int u = 0; u < NU; ++u) {
+      // ---- the two score-shaped products of this 32-row sub-tile, for the wave's CT column sub-tiles (A fragments shared)
+      f32x16_t s[CT], dp[CT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(N1 + 32 * u * NROW + nrow_off + 16 * ks);
-          const u32x4_t a2 = *reinterpret_cast<const u32x4_t*>(N2 + 32 * u * NROW + nrow_off + 16 * ks);
-          s = mfma32(a1, cA[ks], s);
-          dp = mfma32(a2, cB[ks], dp);
+        for (int r = 0; r < 16; ++r) { s[c][r] = 0.f; dp[c][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(N1 + 32 * u * NROW + nrow_off + 16 * ks);
+        const u32x4_t a2 = *reinterpret_cast<const u32x4_t*>(N2 + 32 * u * NROW + nrow_off + 16 * ks);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          s[c] = mfma32(a1, cA[c][ks], s[c]);
+          dp[c] = mfma32(a2, cB[c][ks], dp[c]);
         }
-        const int rbase = r0 + 32 * u + 8 * g;          // row of register r: rbase + 16*(r>>3) + (r&7)
-        if constexpr (MODE == MODE_STATS) {
+      }
+      const int rbase = r0 + 32 * u + 8 * g;          // row of register r: rbase + 16*(r>>3) + (r&7)
+      if constexpr (MODE == MODE_STATS) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
           float sv[16];
           float mx = -INFINITY;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            sv[r] = (rbase + 16 * (r >> 3) + (r & 7) < rlen) ? s[r] * p.scale_log2 : -INFINITY;
+            sv[r] = (rbase + 16 * (r >> 3) + (r & 7) < rlen) ? s[c][r] * p.scale_log2 : -INFINITY;
             mx = fmaxf(mx, sv[r]);
           }
           mx = fmaxf(mx, __shfl_xor(mx, 32));
-          const float m_new = fmaxf(m_run, mx);            // finite: sub-tile 0 of every tile holds a valid row
-          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-          l_run *= alpha; t_run *= alpha;
+          const float m_new = fmaxf(m_run[c], mx);            // finite: sub-tile 0 of every tile holds a valid row
+          const float alpha = __builtin_amdgcn_exp2f(m_run[c] - m_new);
+          l_run[c] *= alpha; t_run[c] *= alpha;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float e = __builtin_amdgcn_exp2f(sv[r] - m_new);
-            l_run += e;
-            t_run = fmaf(e, dp[r], t_run);
+            l_run[c] += e;
+            t_run[c] = fmaf(e, dp[c][r], t_run[c]);
           }
-          m_run = m_new;
-        } else {
+          m_run[c] = m_new;
+        }
+      } else {
+        float ls[16], dl[16];                         // MODE_DKV: statistics of the 16 rows this lane holds
+        if constexpr (MODE == MODE_DKV) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 la = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g]);
+            const float4 lb = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g + 4]);
+            const float4 da = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g]);
+            const float4 db = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g + 4]);
+            ls[8 * h] = la.x; ls[8 * h + 1] = la.y; ls[8 * h + 2] = la.z; ls[8 * h + 3] = la.w;
+            ls[8 * h + 4] = lb.x; ls[8 * h + 5] = lb.y; ls[8 * h + 6] = lb.z; ls[8 * h + 7] = lb.w;
+            dl[8 * h] = da.x; dl[8 * h + 1] = da.y; dl[8 * h + 2] = da.z; dl[8 * h + 3] = da.w;
+            dl[8 * h + 4] = db.x; dl[8 * h + 5] = db.y; dl[8 * h + 6] = db.z; dl[8 * h + 7] = db.w;
+          }
+        }
+        u32x4_t dsf[CT][2], pf[CT][2];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
           float pv[16], ds[16];
-          if constexpr (MODE == MODE_DQ) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool ok = rbase + 16 * (r >> 3) + (r & 7) < rlen;
-              pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -lse_c)) : 0.f;
-              ds[r] = pv[r] * fmaf(dp[r], p.do_scale, -dl_c);
-            }
-          } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float4 la = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g]);
-              const float4 lb = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g + 4]);
-              const float4 da = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g]);
-              const float4 db = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g + 4]);
-              const float ls[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
-              const float dl[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const int r = 8 * h + e;
-                const bool ok = rbase + 16 * h + e < rlen;
-                pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -ls[e])) : 0.f;
-                ds[r] = pv[r] * fmaf(dp[r], p.do_scale, -dl[e]);
-              }
-            }
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = rbase + 16 * (r >> 3) + (r & 7) < rlen;
+            const float lse = (MODE == MODE_DQ) ? lse_c[c] : ls[r];
+            const float del = (MODE == MODE_DQ) ? dl_c[c] : dl[r];
+            pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[c][r], p.scale_log2, -lse)) : 0.f;
+            ds[r] = pv[r] * fmaf(dp[c][r], p.do_scale, -del);
           }
-          u32x4_t dsf[2], pf[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              dsf[h][j] = pack16(ds[8 * h + 2 * j], ds[8 * h + 2 * j + 1]);
-              pf[h][j] = pack16(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
-            }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const u32x4_t t1 = *reinterpret_cast<const u32x4_t*>(T1 + 32 * mt * TROW + trow_off + 32 * u + 16 * h);
-              acc1[mt] = mfma32(t1, dsf[h], acc1[mt]);                      // dQ^T += K^T dS^T   /   dK^T += Q^T dS
-              if constexpr (MODE == MODE_DKV) {
-                const u32x4_t t2 = *reinterpret_cast<const u32x4_t*>(T2 + 32 * mt * TROW + trow_off + 32 * u + 16 * h);
-                acc2[mt] = mfma32(t2, pf[h], acc2[mt]);                     // dV^T += dO^T P
-              }
+              dsf[c][h][j] = pack16(ds[8 * h + 2 * j], ds[8 * h + 2 * j + 1]);
+              pf[c][h][j] = pack16(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x4_t f1 = *reinterpret_cast<const u32x4_t*>(T1 + 32 * mt * TROW + trow_off + 32 * u + 16 * h);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc1[c][mt] = mfma32(f1, dsf[c][h], acc1[c][mt]);        // dQ^T += K^T dS^T   /   dK^T += Q^T dS
+            if constexpr (MODE == MODE_DKV) {
+              const u32x4_t f2 = *reinterpret_cast<const u32x4_t*>(T2 + 32 * mt * TROW + trow_off + 32 * u + 16 * h);
+#pragma unroll
+              for (int c = 0; c < CT; ++c) acc2[c][mt] = mfma32(f2, pf[c][h], acc2[c][mt]);       // dV^T += dO^T P
+            }
+          }
       }
+    }
+    __syncthreads();                     // every wave is done reading this tile's images
+    if (t + 1 < total_tiles) {
+      store_tile();
       __syncthreads();
     }
   }
 
-  // ---- results: lane holds column l31; register r = 4*qd + j of tile mt is dim d = 32*mt + 8*qd + 4*g + j
-  if constexpr (MODE == MODE_STATS) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float t_tot = t_run + __shfl_xor(t_run, 32);
-    if (g == 0 && col_ok) {
-      const int64_t si = ((int64_t)blockIdx.y * p.heads + head) * p.q_len + col;
-      p.lse2[si] = m_run + __builtin_amdgcn_logf(l_tot);       // v_log_f32 = log2
-      p.delta[si] = p.do_scale * t_tot / l_tot;
-    }
-  } else {
-    if (!col_ok) return;
-    auto write = [&](uint16_t* base, const a3d_rowmap& m, const f32x16_t (&acc)[MT], float mul) __attribute__((always_inline)) {
-      uint16_t* dst = base + map_row(m, grp_c, col) * m.ld + hoff;
+  // ---- results: lane holds column l31 of each sub-tile; register r = 4*qd + j of tile mt is dim d = 32*mt + 8*qd + 4*g + j
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int d0 = 32 * mt + 8 * qd + 4 * g;
-          if (d0 < D) {
-            float v0 = acc[mt][4 * qd] * mul, v1 = acc[mt][4 * qd + 1] * mul, v2 = acc[mt][4 * qd + 2] * mul, v3 = acc[mt][4 * qd + 3] * mul;
-            u32x2_t* o = reinterpret_cast<u32x2_t*>(dst + d0);
-            if (p.accumulate) {
-              const u32x2_t old = *o;
-              v0 += lo16(old[0]); v1 += hi16(old[0]); v2 += lo16(old[1]); v3 += hi16(old[1]);
-            }
-            u32x2_t w;
-            w[0] = pack16(v0, v1); w[1] = pack16(v2, v3);
-            *o = w;
-          }
-        }
-    };
-    if constexpr (MODE == MODE_DQ) {
-      write(p.dQ, p.dqm, acc1, p.scale);
+  for (int c = 0; c < CT; ++c) {
+    if constexpr (MODE == MODE_STATS) {
+      const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32);
+      const float t_tot = t_run[c] + __shfl_xor(t_run[c], 32);
+      if (g == 0 && col_ok[c]) {
+        const int64_t si = ((int64_t)blockIdx.y * p.heads + head) * p.q_len + col[c];
+        p.lse2[si] = m_run[c] + __builtin_amdgcn_logf(l_tot);       // v_log_f32 = log2
+        p.delta[si] = p.do_scale * t_tot / l_tot;
+      }
     } else {
-      write(p.dK, p.dkm, acc1, p.scale);
-      write(p.dV, p.dkm, acc2, p.do_scale);
+      if (!col_ok[c]) continue;
+      auto write = [&](uint16_t* base, const a3d_rowmap& m, const f32x16_t (&acc)[MT], float mul) __attribute__((always_inline)) {
+        uint16_t* dst = base + map_row(m, grp_c, col[c]) * m.ld + hoff;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int d0 = 32 * mt + 8 * qd + 4 * g;
+            if (d0 < D) {
+              float v0 = acc[mt][4 * qd] * mul, v1 = acc[mt][4 * qd + 1] * mul, v2 = acc[mt][4 * qd + 2] * mul, v3 = acc[mt][4 * qd + 3] * mul;
+              u32x2_t* o = reinterpret_cast<u32x2_t*>(dst + d0);
+              if (p.accumulate) {
+                const u32x2_t old = *o;
+                v0 += lo16(old[0]); v1 += hi16(old[0]); v2 += lo16(old[1]); v3 += hi16(old[1]);
+              }
+              u32x2_t w;
+              w[0] = pack16(v0, v1); w[1] = pack16(v2, v3);
+              *o = w;
+            }
+          }
+      };
+      if constexpr (MODE == MODE_DQ) {
+        write(p.dQ, p.dqm, acc1[c], p.scale);
+      } else {
+        write(p.dK, p.dkm, acc1[c], p.scale);
+        write(p.dV, p.dkm, acc2[c], p.do_scale);
+      }
     }
   }
 }
 
-template <int D, int MODE, int NU>
+template <int D, int MODE, int NU, int CT>
 int launch(hipStream_t s, const BwdParams& p, int groups_y) {
   const int clen = (MODE == MODE_DKV) ? p.kv_len : p.q_len;
-  const int64_t ctiles = (clen + 127) / 128;
+  const int64_t ctiles = (clen + 128 * CT - 1) / (128 * CT);
   if (ctiles * p.heads > 0x7fffffffLL || groups_y > 65535) return A3D_EINVAL;
-  attn_bwd_kernel<D, MODE, NU><<<dim3((unsigned)(ctiles * p.heads), (unsigned)groups_y), dim3(256), 0, s>>>(p);
+  const dim3 grid((unsigned)(ctiles * p.heads), (unsigned)groups_y);
+  // row side: (Q, dO) maps in DKV, the K/V map otherwise
+  constexpr int BR = 32 * NU;
+  const bool aligned = (MODE == MODE_DKV) ? (p.qm.seg_len % BR == 0 && p.dom.seg_len % BR == 0) : (p.km.seg_len % BR == 0);
+  // workgroups per CU the register budget is set for: two wherever the kernel fits 256 registers without spilling
+  constexpr int OCC = (CT == 1 && (D <= 64 || (D == 80 && MODE != MODE_DKV))) ? 2 : 1;
+  if (aligned) attn_bwd_kernel<D, MODE, NU, CT, true, OCC><<<grid, dim3(256), 0, s>>>(p);
+  else attn_bwd_kernel<D, MODE, NU, CT, false, OCC><<<grid, dim3(256), 0, s>>>(p);
   return a3d_launch_status();
 }
 
+// One 32-column sub-tile per wave and two workgroups per CU: measured faster than two sub-tiles at one workgroup per CU (whose single
+// wave per SIMD has nothing to overlap its LDS / exp / staging latencies with); the CT = 2 instantiation stays available for tuning.
 template <int MODE>
 int dispatch(hipStream_t s, const BwdParams& p, int head_dim, int groups_y) {
   switch (head_dim) {
-    case 40: return launch<40, MODE, 2>(s, p, groups_y);
-    case 64: return launch<64, MODE, 2>(s, p, groups_y);
-    case 80: return launch<80, MODE, 2>(s, p, groups_y);
-    case 160: return launch<160, MODE, 1>(s, p, groups_y);
+    case 40: return launch<40, MODE, 2, 1>(s, p, groups_y);
+    case 64: return launch<64, MODE, 2, 1>(s, p, groups_y);
+    case 80: return launch<80, MODE, 2, 1>(s, p, groups_y);
+    case 160: return launch<160, MODE, 1, 1>(s, p, groups_y);
     default: return A3D_EUNSUPPORTED;
   }
 }

@@ -1,0 +1,181 @@
+// Weight gradient dW[N, K] = alpha * dY^T X of every trainable Linear (training path; reference: autograd of the
+// nn.Linear layers inside `motion_modules.` / `i2v.`, train.py:576-590).
+//
+// Shape of the problem on this model: the OUTPUT is small (320^2 .. 1280 x 5120) and the CONTRACTION is the token axis
+// (M = 4 096 .. 65 536 rows).  A GEMM kernel that tiles the output gets 9 .. 400 workgroups with a contraction loop thousands of
+// steps long — the first version of the training path ran it that way (on transposed copies of dY and X) and spent 25 % of the step
+// on <= 9 of 256 CUs.  Here the token axis is split over the grid instead (split-K): a workgroup owns a 128 x 128 output tile and
+// a slice of M, reads dY and X in their natural row-major layout (no transposed copies) and writes its partial tile to a workspace
+// [splits][N][K]; a second, bandwidth-trivial kernel sums the splits.  (Adding the partial tiles into the result with global atomics
+// was measured first: the splits of one tile finish together and ~60 of them serialise on the same L2 lines — the epilogue took
+// 20 x longer than the products, profiles/README.md.)
+//
+// Both MFMA operands need the token index as the contraction, i.e. transposed images dY^T [n][m], X^T [k][m]: they are built while
+// staging (4 rows x 8 columns per thread, v_perm_b32 + 8-byte LDS writes — the forward attention's V^T path), double-buffered in
+// LDS with register prefetch of the next 32 rows; one barrier per step.  4 waves = 2 x 2, each 64 x 64 of the tile.
+#include "common.h"
+
+namespace {
+
+struct WgParams {
+  const uint16_t* dY; int64_t lddy; const uint16_t* X; int64_t ldx;
+  float* ws;
+  int64_t M; int N, K; int tiles_k; int tiles; int splits; int64_t rows_per_split; float alpha;
+};
+
+constexpr int WG_BR = 32;               // token rows per step
+constexpr int WG_TROW = WG_BR + 8;      // transposed image row stride (elements): 5 x 16 B, odd
+constexpr int WG_T = 128 * WG_TROW;     // elements per image
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgParams p) {
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * WG_T];      // [buffer][A | B]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, g = lane >> 5;
+  const int wn = wid >> 1, wk = wid & 1;
+  // grid.x = output tile, grid.y = token slice.  (Measured alternative: an XCD-aware order that keeps all tiles of one slice on one
+  // XCD's L2 — 2 x SLOWER; the kernel is bound by the latency of its one-step-ahead staging loads, not by HBM re-reads, and the plain
+  // order spreads each slice's lines over all eight L2s.  profiles/README.md, training section.)
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int n0 = (tile / p.tiles_k) * 128, k0 = (tile % p.tiles_k) * 128;
+  const int64_t m_beg = (int64_t)split * p.rows_per_split;
+  const int64_t m_end = min(p.M, m_beg + p.rows_per_split);
+  // staging role: threads 0..127 transpose dY (operand A), 128..255 transpose X (operand B); item = 4 rows x 8 columns
+  const bool is_a = tid < 128;
+  const int it = tid & 127;
+  const int rq = it >> 4, ch = it & 15;
+  const uint16_t* const src = is_a ? p.dY : p.X;
+  const int64_t ld = is_a ? p.lddy : p.ldx;
+  const int c_first = (is_a ? n0 : k0) + ch * 8;
+  const bool col_ok = c_first < (is_a ? p.N : p.K);
+  u32x4_t stg[4];
+  auto load = [&](int64_t m0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = m0 + 4 * rq + j;
+      stg[j] = (col_ok && m < m_end) ? *reinterpret_cast<const u32x4_t*>(src + m * ld + c_first) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+    uint16_t* const T = smem + (2 * buf + (is_a ? 0 : 1)) * WG_T;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // word j of a row holds columns 2j (lo) and 2j+1 (hi)
+      u32x2_t even, odd;
+      even[0] = __builtin_amdgcn_perm(stg[1][j], stg[0][j], 0x05040100u);
+      even[1] = __builtin_amdgcn_perm(stg[3][j], stg[2][j], 0x05040100u);
+      odd[0] = __builtin_amdgcn_perm(stg[1][j], stg[0][j], 0x07060302u);
+      odd[1] = __builtin_amdgcn_perm(stg[3][j], stg[2][j], 0x07060302u);
+      *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j) * WG_TROW + rq * 4) = even;
+      *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j + 1) * WG_TROW + rq * 4) = odd;
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int a_off = (wn * 64 + l31) * WG_TROW + 8 * g;
+  const int b_off = (wk * 64 + l31) * WG_TROW + 8 * g;
+  const int64_t nsteps = (m_end - m_beg + WG_BR - 1) / WG_BR;
+  load(m_beg);
+  store(0);
+  __syncthreads();
+  for (int64_t t = 0; t < nsteps; ++t) {
+    const int buf = (int)(t & 1);
+    if (t + 1 < nsteps) load(m_beg + (t + 1) * WG_BR);
+    const uint16_t* const TA = smem + (2 * buf) * WG_T + a_off;
+    const uint16_t* const TB = smem + (2 * buf + 1) * WG_T + b_off;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const u32x4_t*>(TA + 32 * i * WG_TROW + 16 * ks);
+        bf[i] = *reinterpret_cast<const u32x4_t*>(TB + 32 * i * WG_TROW + 16 * ks);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(af[a], bf[b], acc[a][b]);
+    }
+    if (t + 1 < nsteps) store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> workspace [split][n][k]: register r of a lane is row n = 8*(r>>2) + 4*g + (r&3), column k = l31 of its 32 x 32 block
+  float* const out = p.ws + (int64_t)split * p.N * p.K;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kcol = k0 + wk * 64 + b * 32 + l31;
+      if (kcol < p.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nrow = n0 + wn * 64 + a * 32 + mfma_row(r, g);
+          if (nrow < p.N) out[(int64_t)nrow * p.K + kcol] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+// dW (+)= alpha * sum over splits
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int64_t lddw, int N, int K,
+                                                            int splits, float alpha, int accumulate) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;             // one float4 of the [N, K] result
+  const int64_t total4 = (int64_t)N * K / 4;
+  if (i4 >= total4) return;
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4 v = reinterpret_cast<const float4*>(ws + (int64_t)sp * N * K)[i4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int64_t e = i4 * 4;
+  float* o = dW + (e / K) * lddw + (e % K);
+  if (accumulate) { o[0] += alpha * s.x; o[1] += alpha * s.y; o[2] += alpha * s.z; o[3] += alpha * s.w; }
+  else { o[0] = alpha * s.x; o[1] = alpha * s.y; o[2] = alpha * s.z; o[3] = alpha * s.w; }
+}
+
+}  // namespace
+
+// splits of the token axis for a given problem (also the workspace size): ~768 workgroups (3 per CU), >= 1 024 token rows each
+static void wgrad_plan(int64_t M, int64_t N, int64_t K, int64_t* splits, int64_t* rows_per_split) {
+  const int64_t tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int64_t sp = (768 + tiles - 1) / tiles;
+  const int64_t max_splits = (M + 1023) / 1024;
+  if (sp > max_splits) sp = max_splits;
+  if (sp < 1) sp = 1;
+  int64_t rps = (M + sp - 1) / sp;
+  rps = (rps + WG_BR - 1) / WG_BR * WG_BR;
+  *splits = (M + rps - 1) / rps;
+  *rows_per_split = rps;
+}
+
+#ifndef A3D_STORAGE_F16
+extern "C" int64_t a3d_wgrad_ws_floats(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int64_t sp, rps;
+  wgrad_plan(M, N, K, &sp, &rps);
+  return sp * N * K;
+}
+#endif
+
+extern "C" int A3D_FN(a3d_wgrad)(a3d_stream_t stream, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                                  float* ws, int64_t M, int64_t N, int64_t K, float alpha, int accumulate) {
+  if (!dY || !X || !dW || !ws || M <= 0 || N <= 0 || K <= 0 || N % 8 != 0 || K % 8 != 0 || lddy % 8 != 0 || ldx % 8 != 0) return A3D_EINVAL;
+  if (lddy < N || ldx < K || lddw < K || N > 0x7fffffffLL || K > 0x7fffffffLL) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dY) & 15u) || (reinterpret_cast<uintptr_t>(X) & 15u) || (reinterpret_cast<uintptr_t>(ws) & 15u)) return A3D_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t tiles_k = (K + 127) / 128, tiles = ((N + 127) / 128) * tiles_k;
+  int64_t splits, rps;
+  wgrad_plan(M, N, K, &splits, &rps);
+  if (tiles > 0x7fffffffLL || splits > 65535) return A3D_EINVAL;
+  WgParams p{(const uint16_t*)dY, lddy, (const uint16_t*)X, ldx, ws, M, (int)N, (int)K, (int)tiles_k, (int)tiles, (int)splits, rps, alpha};
+  wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s>>>(p);
+  const int64_t total4 = N * K / 4;
+  wgrad_reduce_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s>>>(ws, dW, lddw, (int)N, (int)K, (int)splits, alpha, accumulate);
+  return a3d_launch_status();
+}

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "a3d_group_norm_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int]),
     "a3d_geglu_bwd_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64]),
     "a3d_transpose_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64]),
+    "a3d_wgrad_ws_floats": (c_i64, [c_i64, c_i64, c_i64]),
+    "a3d_wgrad_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_f32, c_int]),
     "a3d_colsum_bf16": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_f32, c_int]),
     "a3d_axpby_bf16": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32]),
     "a3d_zero_insert2x_bf16": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int]),
@@ -495,6 +497,17 @@ class HipOps:
         y = self.empty(cols, rp)
         _check(self.lib.a3d_transpose_bf16(self._stream(), _p(x), x.stride(0), _p(y), rp, rows, cols, rp), f"a3d_transpose_bf16 {rows}x{cols}")
         return y
+
+    def wgrad(self, dy, x, alpha: float = 1.0):
+        """fp32 [N, K] = alpha * dy^T x: the weight gradient of y = x W^T (split over the token axis, fp32 atomics)."""
+        dy, x = self._act(dy, "wgrad.dy"), self._act(x, "wgrad.x")
+        assert dy.shape[0] == x.shape[0]
+        M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+        dw = torch.empty((N, K), dtype=torch.float32, device=self.device)
+        ws = torch.empty(int(self.raw_lib.a3d_wgrad_ws_floats(M, N, K)), dtype=torch.float32, device=self.device)
+        _check(self.lib.a3d_wgrad_bf16(self._stream(), _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), K, _p(ws), M, N, K, alpha, 0),
+               f"a3d_wgrad_bf16 M={M} N={N} K={K}")
+        return dw
 
     def colsum(self, x, alpha: float = 1.0):
         x = self._act(x, "colsum.x")

@@ -250,6 +250,14 @@ int a3d_geglu_bwd_bf16(a3d_stream_t stream, const void* P, int64_t ldp, const vo
 int a3d_transpose_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int64_t cols,
                        int64_t rows_pad);
 
+/* Weight gradient of a Linear: dW[N, K] (fp32, row stride lddw floats) (+)= alpha * dY[M, N]^T X[M, K], both operands in their natural
+ * row-major layout.  The token axis M is split over the grid (the output is small, the contraction long): partial tiles go to the
+ * fp32 workspace `ws` (a3d_wgrad_ws_floats(M, N, K) floats, 16-byte aligned) and a second kernel sums them.  accumulate != 0 adds
+ * to dW.  N % 8 == 0, K % 8 == 0, 16-byte aligned rows. */
+int64_t a3d_wgrad_ws_floats(int64_t M, int64_t N, int64_t K);
+int a3d_wgrad_bf16(a3d_stream_t stream, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                   float* ws, int64_t M, int64_t N, int64_t K, float alpha, int accumulate);
+
 /* out[c] (+)= alpha * sum_r X[r][c]  (bias gradients), fp32 out. */
 int a3d_colsum_bf16(a3d_stream_t stream, const void* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha, int accumulate);
 
@@ -342,6 +350,8 @@ int a3d_colsum_f16(a3d_stream_t stream, const void* X, int64_t ldx, int64_t rows
 int a3d_axpby_f16(a3d_stream_t stream, const void* X, void* Y, int64_t n, float a, float b);
 int a3d_zero_insert2x_f16(a3d_stream_t stream, const void* dY, void* Z, int B, int H, int W, int C);
 int a3d_upsample2x_bwd_f16(a3d_stream_t stream, const void* dU, void* dX, int B, int H, int W, int He, int We, int C);
+int a3d_wgrad_f16(a3d_stream_t stream, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                   float* ws, int64_t M, int64_t N, int64_t K, float alpha, int accumulate);
 
 #ifdef __cplusplus
 }

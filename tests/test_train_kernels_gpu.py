@@ -48,7 +48,7 @@ def check(name, got, want, tol):
 
 
 # ------------------------------------------------------------------ attention
-@pytest.mark.parametrize("C,n,F,L", [(320, 2, 2, 96), (640, 2, 3, 40), (1280, 3, 2, 16)])
+@pytest.mark.parametrize("C,n,F,L", [(320, 2, 2, 96), (640, 2, 3, 40), (1280, 3, 2, 16), (320, 2, 2, 328), (640, 2, 2, 272), (320, 2, 2, 128), (1280, 2, 2, 64)])   # ragged tails; last two: tiles aligned to the map segments (no per-row division)
 def test_flash_attn_bwd_multiview_and_first_frame(ops, ref, C, n, F, L):
     """attention_processor.py:340, 389-418: "(b n f) l -> (b f) (n l)" queries; the first-frame branch reads frame 0's keys for all
     F frames of a video, so dK / dV are sums over F query groups and vanish on the other frames."""
@@ -68,10 +68,10 @@ def test_flash_attn_bwd_multiview_and_first_frame(ops, ref, C, n, F, L):
     assert float(got[1][fr != 0].abs().max()) == 0.0 and float(got[2][fr != 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("C,T", [(320, 77), (640, 16), (1280, 77)])
-def test_flash_attn_bwd_cross_attention_query_only(ops, ref, C, T):
+@pytest.mark.parametrize("C,T,L", [(320, 77, 50), (640, 16, 50), (1280, 77, 50), (320, 77, 600)])
+def test_flash_attn_bwd_cross_attention_query_only(ops, ref, C, T, L):
     """attention_processor.py:233-270: text / IP tokens are frozen inputs, only dQ is wanted; the IP branch's out_scale scales dO."""
-    dt, heads, V, F, L = ops.act_dtype, 8, 2, 3, 50
+    dt, heads, V, F = ops.act_dtype, 8, 2, 3
     B2 = V * F
     q, do = rnd(B2 * L, C, seed=1, dtype=dt), rnd(B2 * L, C, seed=2, dtype=dt)
     kv = rnd(V * T, 2 * C, seed=3, dtype=dt)
@@ -147,6 +147,17 @@ def test_geglu_bwd_and_layout_helpers(ops, ref):
     for He, We in ((6, 10), (5, 9), (6, 9)):
         du = rnd(2 * He * We, 64, seed=7, dtype=dt)
         check(f"upsample2x_bwd {(He, We)}", ops.upsample2x_bwd(du, 2, 3, 5, He, We), ref.upsample2x_bwd(du, 2, 3, 5, He, We), ELEM_TOL[dt])
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 320, 320), (300, 2560, 320), (65536, 320, 1280), (77, 8, 72), (4096, 1280, 5120)])
+def test_wgrad_split_over_tokens(ops, ref, M, N, K):
+    """dW = dY^T X of the trainable Linear layers: natural layouts in (strided column views allowed), fp32 out, token axis split."""
+    dt = ops.act_dtype
+    dyb, xb = rnd(M, N + 8, seed=1, dtype=dt), rnd(M, K + 16, seed=2, dtype=dt)
+    dy, x = dyb[:, 8:], xb[:, :K]
+    got, want = ops.wgrad(dy, x, 0.5), ref.wgrad(dy, x, 0.5)
+    assert got.dtype == torch.float32
+    check(f"wgrad {M}x{N}x{K}", got, want, 2e-5)
 
 
 def test_optimizer_kernels_match_torch_adamw(ops):

@@ -273,6 +273,9 @@ class TorchRefOps:
         y[:, :rows] = x.t()
         return y
 
+    def wgrad(self, dy, x, alpha=1.0):
+        return alpha * (dy.float().t() @ x.float())
+
     def colsum(self, x, alpha=1.0):
         return alpha * x.float().sum(dim=0)
 
