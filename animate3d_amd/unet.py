@@ -725,15 +725,38 @@ class MVUNetMotionModel(nn.Module):
         history, so ``.grad`` lands on the fp32 ``nn.Parameter`` exactly as under the reference's autocast.  ``compute_dtype``
         (bf16 default, or fp16 = the reference's autocast type; then use a loss scaler) is the kernels' storage type for a model
         kept in fp32.  ``torch.no_grad()`` forwards are unchanged.  Returns ``self``."""
-        from .autograd_ops import AutogradOps
         if compute_dtype is not None and self._base_ops().act_dtype != compute_dtype:
             if not getattr(self, "_ops_auto", False):
                 raise ValueError("enable_training(compute_dtype=...) cannot replace an op set that was passed in")
             from .hip_ops import HipOps
             self._ops = HipOps(self.device, compute_dtype)
             self._invalidate()
-        self._train_ops = AutogradOps(self._base_ops())
+        self._train_dtype = compute_dtype
+        self._training_enabled = True
+        self._autograd_ops()
         return self
+
+    def _autograd_ops(self):
+        """The autograd view of the CURRENT op set (``unet.to(device)`` after ``enable_training()`` — train.py:456 — replaces it)."""
+        from .autograd_ops import AutogradOps
+        base = self._base_ops()
+        want = getattr(self, "_train_dtype", None)
+        if want is not None and base.act_dtype != want and getattr(self, "_ops_auto", False):
+            from .hip_ops import HipOps
+            self._ops = base = HipOps(self.device, want)
+            self._invalidate()
+        if self._train_ops is None or self._train_ops.base is not base:
+            self._train_ops = AutogradOps(base)
+            self._packed_frozen = None
+        return self._train_ops
+
+    def enable_gradient_checkpointing(self):
+        """train.py:381-382.  Accepted for call compatibility and a no-op: the backward keeps its activations (38 GB at the train.yaml
+        shape, of 288 GB per MI355X) — recomputation would only cost time here."""
+        self._gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self._gradient_checkpointing = False
 
     def _mark_persistent(self, node):
         if torch.is_tensor(node):
@@ -751,7 +774,7 @@ class MVUNetMotionModel(nn.Module):
         ``_pack_grad`` on — a cast / cat / interleave per step, the price of fp32 master weights behind 16-bit kernels."""
         if self._packed_frozen is None:
             self._packed_frozen = self._pack()
-            self._packed = None                    # the inference pack goes stale as soon as an optimiser step runs
+            self._packed = None                    # (_pack stored it as the inference pack; that one is rebuilt on demand)
             self._mark_persistent(self._packed_frozen)
         Pf = self._packed_frozen
         trainable = lambda m: m is not None and any(p.requires_grad for p in m.parameters())
@@ -794,10 +817,11 @@ class MVUNetMotionModel(nn.Module):
                   added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=down_block_additional_residuals,
                   mid_block_additional_residual=mid_block_additional_residual, return_dict=return_dict, camera=camera,
                   num_views=num_views, i2v_cond_time_zero=i2v_cond_time_zero)
-        if self._train_ops is not None and torch.is_grad_enabled():
+        if getattr(self, "_training_enabled", False) and torch.is_grad_enabled():
             if self.parallel is not None and self.parallel.world > 1:
                 raise NotImplementedError("a sharded (shard_unet) model is inference-only; training shards the batch (train.py: DDP)")
-            self._active_ops = self._train_ops
+            self._active_ops = self._autograd_ops()
+            self._packed = None        # the parameters are about to change: the next no_grad call (validation) packs them afresh
             try:
                 return self._forward_impl(sample, timestep, encoder_hidden_states, packed=self._pack_train(), **kw)
             finally:

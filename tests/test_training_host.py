@@ -264,3 +264,56 @@ def test_data_parallel_gradients_over_gloo():
         print(f"[parity] rank {rank}: flat gradient after the exchange vs sum of the ranks' gradients: max err / max |g| = {err:.2e}, "
               f"clip norm vs |mean gradient| {dnorm:.2e}")
         assert err < 1e-6 and same and dnorm < 1e-3          # fp32 sums over 2M elements in two orders
+
+
+def test_validation_forward_after_each_optimiser_step_sees_the_updated_weights():
+    """train.py:644-700 samples with the SAME unet between optimisation steps: the no_grad path must not reuse kernel-layout copies of
+    parameters an optimiser step has changed since (and the next training step must not reuse the validation pack either)."""
+    n, Fr, hw = 2, 2, (8, 8)
+    ocfg, ref, model = _pair(n, Fr, hw)
+    inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=3, cfg_doubled=False)
+    batches = [_batch(ocfg, 1, n, Fr, hw, seed=30 + i) for i in range(2)]
+    model.enable_gradient_checkpointing()                                  # train.py:381-382: accepted, keeps activations
+    from animate3d_amd.denoise import ddim_schedule
+    from animate3d_amd.train import FlatAdamW, training_step
+    model.enable_training()
+    opt = FlatAdamW([p for p in model.parameters() if p.requires_grad], model.ops, lr=1e-2)      # large steps: stale weights would show
+    with torch.no_grad():
+        y0 = model(**inp).sample
+    for bt in batches:
+        training_step(model, opt, bt["latents"], bt["text"], bt["cameras"], bt["image_embeds"], alphas_cumprod=ddim_schedule(25)[1],
+                      num_views=n, noise=bt["noise"], timesteps=bt["timesteps"])
+        with torch.no_grad():
+            y = model(**inp).sample
+        ref.load_state_dict(model.state_dict())                              # the oracle with the CURRENT weights
+        want = ref(**inp).sample
+        assert float((y - want).abs().max()) < 2e-3 * float(want.abs().max())
+        assert float((y - y0).abs().max()) > 1e-2 * float(want.abs().max())    # and the step did change the function
+        y0 = y
+
+
+def test_flat_adamw_checkpoint_round_trip_and_grad_relinking():
+    from animate3d_amd.train import FlatAdamW
+    ops = TorchRefOps()
+    g = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((7, 5), (1,), (130,))]
+    before = [p.detach().clone() for p in ps]
+    opt = FlatAdamW(ps, ops, lr=1e-2, max_grad_norm=0.0)
+    assert all(torch.equal(p.detach(), b) for p, b in zip(ps, before))      # re-homing keeps the values ...
+    assert all(o % 64 == 0 for o in opt.offsets)                             # ... in 256-byte aligned slots of one buffer
+    for p in ps:
+        p.grad = None                                                        # optimizer.zero_grad(set_to_none=True) of a caller
+    opt.zero_grad()
+    loss = sum((p ** 2).sum() for p in ps)
+    loss.backward()
+    assert all(p.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * o for p, o in zip(ps, opt.offsets))
+    opt.step()
+    sd = opt.state_dict()
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = FlatAdamW(ps2, ops, lr=1e-2, max_grad_norm=0.0)
+    opt2.load_state_dict(sd)
+    for o, pp in ((opt, ps), (opt2, ps2)):
+        o.zero_grad()
+        sum((p ** 2).sum() for p in pp).backward()
+        o.step()
+    assert opt2.step_count == 2 and all(torch.equal(a, b) for a, b in zip(ps, ps2))
