@@ -426,7 +426,8 @@ class HipOps:
         C = q.shape[1]
         D = C // heads
         assert k.stride(0) == v.stride(0) and do.shape == q.shape
-        dq = self.empty(q.shape[0], C) if need_dq else None
+        # rows the query map never reaches (none in the model's calls) must still come back defined
+        dq = (self.empty(q.shape[0], C) if q.shape[0] == groups * q_len else torch.zeros((q.shape[0], C), dtype=self.act_dtype, device=self.device)) if need_dq else None
         dk = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
         dv = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
         stats = torch.empty((2, groups * heads * q_len), dtype=torch.float32, device=self.device)
