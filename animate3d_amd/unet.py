@@ -833,11 +833,22 @@ class MVUNetMotionModel(nn.Module):
                       added_cond_kwargs, down_block_additional_residuals, mid_block_additional_residual, return_dict, camera, num_views,
                       i2v_cond_time_zero):
         assert sample.shape[0] % num_views == 0, "[UNet] input batch size must be dividable by num_views!"
-        if attention_mask is not None or timestep_cond is not None or down_block_additional_residuals is not None \
-                or mid_block_additional_residual is not None:
-            raise NotImplementedError("attention_mask / timestep_cond / ControlNet residuals are never passed by the reference callers")
+        if timestep_cond is not None:
+            # the reference adds time_embedding.cond_proj(timestep_cond) (:726-730); the SD1.5 UNet has no cond_proj (time_cond_proj_dim = None)
+            raise ValueError("timestep_cond needs a time_embedding.cond_proj, which this UNet (time_cond_proj_dim = None) does not have")
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask (:700-703: an additive key bias inside every attention) is not supported; no caller "
+                                      "of the reference passes one")
         if cross_attention_kwargs:
-            raise NotImplementedError("cross_attention_kwargs (LoRA scale) is not supported")
+            # diffusers hands `scale` to the processors as the LoRA scale; without LoRA layers (this model has none) it changes nothing
+            extra = set(cross_attention_kwargs) - {"scale"}
+            if extra:
+                raise NotImplementedError(f"cross_attention_kwargs {sorted(extra)} are not supported (only the LoRA `scale`, a no-op here)")
+        residuals = down_block_additional_residuals is not None or mid_block_additional_residual is not None
+        if residuals and (torch.is_grad_enabled() and getattr(self, "_training_enabled", False)):
+            raise NotImplementedError("ControlNet residuals are an inference input (:787-796, 816-817); the training path does not differentiate them")
+        if residuals and self.parallel is not None and self.parallel.world > 1:
+            raise NotImplementedError("ControlNet residuals with a sharded (shard_unet) model are not supported")
         cfg, ops = self.config, self.ops
         V, _, F, H, W = sample.shape
         n = self.num_views or num_views
@@ -928,11 +939,29 @@ class MVUNetMotionModel(nn.Module):
                 x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.down[0], pk.down[1], stride=2)
                 skips.append(x)
                 sizes.append((h_, w_))
+        def plus(x_rows, res, hh, ww):
+            """rows + a ControlNet residual given as the reference gives it, [(V F), C, hh, ww] (:787-796, 816-817)."""
+            C = x_rows.shape[1]
+            if tuple(res.shape) != (B2, C, hh, ww):
+                raise ValueError(f"additional residual of shape {tuple(res.shape)}, expected {(B2, C, hh, ww)}")
+            r = ops.empty(B2 * hh * ww, C)                                  # a fresh buffer: the sum is formed in it (never in the caller's tensor)
+            r.copy_(res.to(device=dev).permute(0, 2, 3, 1).reshape(B2 * hh * ww, C))      # layout change to token rows
+            return ops.axpby_(x_rows, r, 1.0, 1.0)
+
+        if down_block_additional_residuals is not None:
+            if len(down_block_additional_residuals) != len(skips):
+                raise ValueError(f"{len(down_block_additional_residuals)} down-block residuals for {len(skips)} skip connections")
+            geo = [sizes[0]]
+            for bi, pkd in enumerate(P.down):
+                geo += [sizes[bi]] * len(pkd.resnets) + ([sizes[bi + 1]] if pkd.down is not None else [])
+            skips = [plus(s_, r_, *g_) for s_, r_, g_ in zip(skips, down_block_additional_residuals, geo)]
         pk = P.mid
         x = self._resnet(x, B2, h_, w_, pk.resnets[0], semb, rb_rows)
         x = self._t2d(x, V, n, F, h_, w_, pk.t2d[0], text_rows, ip_rows, T)
         x = self._motion(x, V, n, F, h_, w_, pk.motion[0])
         x = self._resnet(x, B2, h_, w_, pk.resnets[1], semb, rb_rows)
+        if mid_block_additional_residual is not None:
+            x = plus(x, mid_block_additional_residual, h_, w_)
         lvl = len(sizes) - 1
         for blk, pk in zip(self.up_blocks, P.up):
             for j, rp in enumerate(pk.resnets):

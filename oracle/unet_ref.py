@@ -798,7 +798,8 @@ class MVUNetMotionModelRef(nn.Module):
 
     @torch.no_grad()
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, camera=None,
-                num_views: int = 4, i2v_cond_time_zero: bool = False, return_dict: bool = True, **unused):
+                num_views: int = 4, i2v_cond_time_zero: bool = False, return_dict: bool = True,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, **unused):
         assert sample.shape[0] % num_views == 0, "[UNet] input batch size must be dividable by num_views!"   # :684
         V, _, num_frames, h, w = sample.shape
         timesteps = timestep
@@ -835,7 +836,11 @@ class MVUNetMotionModelRef(nn.Module):
         for blk in self.down_blocks:                                         # :771-785
             x, outs = blk(x, emb, ehs, num_frames)
             skips += outs
-        x = self.mid_block(x, emb, ehs, num_frames)                          # :799-817
+        if down_block_additional_residuals is not None:                      # :787-796 (ControlNet)
+            skips = tuple(s_ + r_ for s_, r_ in zip(skips, down_block_additional_residuals))
+        x = self.mid_block(x, emb, ehs, num_frames)                          # :799-815
+        if mid_block_additional_residual is not None:                        # :816-817
+            x = x + mid_block_additional_residual
         forward_upsample_size = any(s % (2 ** self.num_upsamplers) != 0 for s in (h, w))   # :690-698
         for i, blk in enumerate(self.up_blocks):                             # :823-852
             k = len(blk.resnets)

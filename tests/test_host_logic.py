@@ -325,3 +325,46 @@ def test_structural_config_variants_match_oracle():
         np.testing.assert_allclose(model(**inp).sample.numpy(), ref(**inp).sample.numpy(), rtol=2e-3, atol=2e-4, err_msg=str(sw))
     with pytest.raises(ValueError):
         MVUNetMotionModel(UNetConfig(**dict(base, in_channels=9)), ops=TorchRefOps(), num_views=2)
+
+
+def _residual_shapes(cfg, B2, hw):
+    """Shapes of down_block_res_samples (unet_motion_mv_model.py:769-785): conv_in, then per down block its resnets' outputs and the
+    down-sampler's output; plus the mid block's output."""
+    h, w = hw
+    boc = cfg.block_out_channels
+    shapes = [(B2, boc[0], h, w)]
+    for i, c in enumerate(boc):
+        shapes += [(B2, c, h, w)] * cfg.layers_per_block
+        if i != len(boc) - 1:
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            shapes.append((B2, c, h, w))
+    return shapes, (B2, boc[-1], h, w)
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (12, 20)])
+def test_controlnet_residual_inputs(hw):
+    """unet_motion_mv_model.py:787-796, 816-817: additional residuals on the skip connections and on the mid block's output
+    (given as the reference gives them: [(V F), C, h, w]); and the LoRA `scale` of cross_attention_kwargs, a no-op without LoRA layers."""
+    n, Fr = 2, 2
+    ocfg, ref, model = _pair(n, Fr, hw)
+    inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=9)
+    down_shapes, mid_shape = _residual_shapes(ocfg, n * Fr, hw)
+    g = torch.Generator().manual_seed(4)
+    down = tuple(0.3 * torch.randn(s, generator=g) for s in down_shapes)
+    mid = 0.3 * torch.randn(mid_shape, generator=g)
+    keep = [t.clone() for t in down] + [mid.clone()]
+    y = model(**inp, down_block_additional_residuals=down, mid_block_additional_residual=mid, cross_attention_kwargs={"scale": 0.8}).sample
+    assert all(torch.equal(a, b) for a, b in zip(list(down) + [mid], keep)), "the call must not write into the caller's residual tensors"
+    y_ref = ref(**inp, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=2e-3, atol=2e-4)
+    assert not np.allclose(y.numpy(), model(**inp).sample.numpy(), atol=1e-3)
+    np.testing.assert_allclose(model(**inp, mid_block_additional_residual=mid).sample.numpy(),
+                               ref(**inp, mid_block_additional_residual=mid).sample.numpy(), rtol=2e-3, atol=2e-4)
+    with pytest.raises(ValueError):
+        model(**inp, down_block_additional_residuals=down[:-1])
+    with pytest.raises(ValueError):
+        model(**inp, timestep_cond=torch.zeros(n, 4))
+    with pytest.raises(NotImplementedError):
+        model(**inp, attention_mask=torch.ones(n, 77))
+    with pytest.raises(NotImplementedError):
+        model(**inp, cross_attention_kwargs={"gligen": {}})

@@ -279,3 +279,27 @@ def test_forward_is_hip_graph_capturable(models):
         torch.cuda.synchronize()
         y_eager = hip(**src).sample
         assert torch.equal(y_static, y_eager), "graph replay differs from the eager forward"
+
+
+def test_controlnet_residual_inputs_on_the_gpu():
+    """unet_motion_mv_model.py:787-796, 816-817 on the HIP path (a3d_axpby): a two-level real-width model (head dims 40 / 80) with
+    additional residuals on every skip connection and on the mid block's output, against the oracle."""
+    kw = dict(block_out_channels=(320, 640), down_has_attn=(True, False), layers_per_block=1)
+    n, Fr, hw = 2, 2, (16, 16)
+    ocfg = O.UNetConfig(**kw)
+    ref = O.build_fast(ocfg, n, Fr, hw, seed=0)
+    hip = MVUNetMotionModel(UNetConfig(**kw), num_views=n, device="cuda")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.half().eval()
+    inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=4)
+    B2 = n * Fr
+    shapes = [(B2, 320, 16, 16), (B2, 320, 16, 16), (B2, 320, 8, 8), (B2, 640, 8, 8)]
+    g = torch.Generator().manual_seed(2)
+    down = [0.5 * torch.randn(s, generator=g) for s in shapes]
+    mid = 0.5 * torch.randn((B2, 640, 8, 8), generator=g)
+    y_ref = ref(**inp, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    y_plain = ref(**inp).sample
+    y = hip(**_cuda(inp), down_block_additional_residuals=[t.cuda() for t in down], mid_block_additional_residual=mid.cuda()).sample
+    e, mx, sc = _rel(y, y_ref)
+    print(f"[parity] ControlNet residual inputs, fp16 storage vs oracle: rel_l2={e:.3e} (residuals move the output by {_rel(y_plain, y_ref)[0]:.3e})")
+    assert e < 6e-3 and _rel(y_plain, y_ref)[0] > 10 * e
