@@ -34,12 +34,14 @@ def select_trainable(unet, trainable_modules: Sequence[str] = TRAINABLE_MODULES)
     return out
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (train.py:351-357) over one flat buffer, with clip_grad_norm_ (train.py:586, 593) and the
     GradScaler's dynamic loss scale (train.py:583-590; only needed for fp16 kernels) folded into the step.
 
     ``params`` keep being ordinary ``nn.Parameter`` objects (state_dict, checkpointing and the model code see no difference);
-    their storage and their ``.grad`` are views of ``self.flat_p`` / ``self.flat_g``."""
+    their storage and their ``.grad`` are views of ``self.flat_p`` / ``self.flat_g``.  A ``torch.optim.Optimizer`` with one
+    parameter group, so the learning-rate schedulers of train.py:431-440 (``diffusers.optimization.get_scheduler`` -> ``LambdaLR``)
+    drive it through ``param_groups[0]["lr"]``; its ``state_dict`` holds the flat moment buffers."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], ops, lr: float = 1e-4, betas=(0.9, 0.999), weight_decay: float = 1e-2,
                  eps: float = 1e-8, max_grad_norm: float = 1.0, loss_scale: Optional[float] = None, growth_interval: int = 2000,
@@ -50,8 +52,9 @@ class FlatAdamW:
         dev = self.params[0].device
         if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
             raise ValueError("FlatAdamW keeps fp32 master parameters on one device (the reference trains an fp32 model under autocast)")
+        super().__init__(self.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.ops = ops
-        self.lr, self.betas, self.weight_decay, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
+        self.max_grad_norm = max_grad_norm
         # every parameter starts on a 256-byte boundary of the flat buffers (the kernels read affine vectors with 16-byte loads; a
         # 1-element mix_factor would otherwise misalign everything behind it); the padding stays zero in all four buffers
         ALIGN = 64
@@ -76,7 +79,13 @@ class FlatAdamW:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.last_ctrl = None
 
-    def zero_grad(self):
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zeroes the flat gradient and keeps every ``.grad`` a view of it (``set_to_none`` is accepted and ignored: autograd must keep
+        accumulating into the flat buffer)."""
         self.flat_g.zero_()
         for p, (off, k) in zip(self.params, self._spans()):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:      # somebody replaced .grad (set_to_none)
@@ -109,8 +118,9 @@ class FlatAdamW:
         self.step_count += 1
         inv = 1.0 / (world * (self.loss_scale if self.loss_scale is not None else 1.0))
         ctrl = self.ops.clip_ctrl(self.ops.sqnorm(self.flat_g), self.max_grad_norm, inv)
-        self.ops.adamw_(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr=self.lr, betas=self.betas, eps=self.eps,
-                        weight_decay=self.weight_decay, step=self.step_count, ctrl=ctrl)
+        grp = self.param_groups[0]
+        self.ops.adamw_(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr=float(grp["lr"]), betas=tuple(grp["betas"]), eps=grp["eps"],
+                        weight_decay=grp["weight_decay"], step=self.step_count, ctrl=ctrl)
         factor, skipped, norm = (float(x) for x in ctrl.tolist())
         self.last_ctrl = ctrl
         if skipped:
@@ -126,7 +136,7 @@ class FlatAdamW:
         return {"grad_norm": norm, "skipped": bool(skipped), "grad_factor": factor}
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg[:self.numel].clone(), "exp_avg_sq": self.exp_avg_sq[:self.numel].clone(),
+        return {"step": self.step_count, "lr": self.param_groups[0]["lr"], "initial_lr": self.param_groups[0].get("initial_lr"), "exp_avg": self.exp_avg[:self.numel].clone(), "exp_avg_sq": self.exp_avg_sq[:self.numel].clone(),
                 "loss_scale": self.loss_scale, "good_steps": self._good_steps}
 
     def load_state_dict(self, sd):
@@ -134,6 +144,10 @@ class FlatAdamW:
         self.exp_avg[:self.numel].copy_(sd["exp_avg"])
         self.exp_avg_sq[:self.numel].copy_(sd["exp_avg_sq"])
         self.loss_scale, self._good_steps = sd["loss_scale"], int(sd["good_steps"])
+        if sd.get("lr") is not None:
+            self.param_groups[0]["lr"] = sd["lr"]
+        if sd.get("initial_lr") is not None:
+            self.param_groups[0]["initial_lr"] = sd["initial_lr"]
 
 
 def add_noise(x: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor, alphas_cumprod: torch.Tensor) -> torch.Tensor:

@@ -317,3 +317,24 @@ def test_flat_adamw_checkpoint_round_trip_and_grad_relinking():
         sum((p ** 2).sum() for p in pp).backward()
         o.step()
     assert opt2.step_count == 2 and all(torch.equal(a, b) for a, b in zip(ps, ps2))
+
+
+def test_flat_adamw_is_driven_by_torch_lr_schedulers():
+    """train.py:431-440, 603: get_scheduler(...) returns a LambdaLR over the optimiser; warm-up must reach the fused step."""
+    from animate3d_amd.train import FlatAdamW
+    ops = TorchRefOps()
+    p = torch.nn.Parameter(torch.ones(10))
+    q = torch.nn.Parameter(torch.ones(10))
+    opt = FlatAdamW([p], ops, lr=1e-2, weight_decay=0.0, max_grad_norm=0.0)
+    ref = torch.optim.AdamW([q], lr=1e-2, weight_decay=0.0)
+    warm = lambda step: min(1.0, (step + 1) / 4)
+    s1 = torch.optim.lr_scheduler.LambdaLR(opt, warm)
+    s2 = torch.optim.lr_scheduler.LambdaLR(ref, warm)
+    for _ in range(6):
+        for o, t in ((opt, p), (ref, q)):
+            o.zero_grad()
+            (t ** 3).sum().backward()
+            o.step()
+        s1.step(); s2.step()
+        assert abs(s1.get_last_lr()[0] - s2.get_last_lr()[0]) < 1e-12 and abs(opt.lr - s2.get_last_lr()[0]) < 1e-12
+    assert torch.allclose(p.detach(), q.detach(), rtol=0, atol=1e-6)
