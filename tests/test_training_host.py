@@ -338,3 +338,68 @@ def test_flat_adamw_is_driven_by_torch_lr_schedulers():
         s1.step(); s2.step()
         assert abs(s1.get_last_lr()[0] - s2.get_last_lr()[0]) < 1e-12 and abs(opt.lr - s2.get_last_lr()[0]) < 1e-12
     assert torch.allclose(p.detach(), q.detach(), rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the reference's own loop: torch DDP + torch.optim.AdamW around the drop-in
+def _ddp_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, Fr, hw = 2, 2, (8, 8)
+        ocfg, ref, model = _pair(n, Fr, hw)
+        model.enable_training()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(params, lr=1e-3)                             # train.py:351-357
+        ddp = DDP(model)                                                     # train.py:456-457
+        ddp.train()
+        inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=40 + rank, cfg_doubled=False)      # a different shard per rank
+        target = torch.randn(n, 4, Fr - 1, *hw, generator=torch.Generator().manual_seed(50 + rank))
+        with ddp.no_sync():                                                  # local gradient, no exchange
+            F.mse_loss(ddp(**inp).sample[:, :, 1:].float(), target).backward()
+        local = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+        opt.zero_grad()
+        loss = F.mse_loss(ddp(**inp).sample[:, :, 1:].float(), target)       # train.py:572-577
+        loss.backward()                                                      # DDP's bucketed all-reduce (mean) rides on the Function graph
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)             # :593
+        got = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+        opt.step()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        mean = sum(gathered) / world
+        mean = mean * min(1.0, 1.0 / (float(mean.norm()) + 1e-6))
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        peers = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(peers, flat)
+        q.put((rank, float((got - mean).abs().max() / mean.abs().max()), all(torch.equal(peers[0], t) for t in peers)))
+    except Exception as e:
+        q.put((rank, repr(e), False))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_training_loop_with_torch_ddp_over_gloo():
+    """The unmodified pattern of train.py:351-357, 456-457, 572-596 — DistributedDataParallel around the UNet, torch.optim.AdamW,
+    clip_grad_norm_ — works on the drop-in: DDP's gradient hooks fire on the parameters the autograd op set feeds."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, same in res:
+        assert not isinstance(err, str), err
+        print(f"[parity] rank {rank}: DDP-averaged, clipped gradient vs mean of the ranks' local gradients: {err:.2e}; parameters identical across ranks: {same}")
+        assert err < 1e-3 and same          # two fp32 evaluations of the clip norm
