@@ -25,6 +25,7 @@ What is different is everything underneath:
 from __future__ import annotations
 
 import math
+import os
 import re
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple, Union
@@ -238,6 +239,79 @@ class MVUNetMotionModel(nn.Module):
                                 tb.attn1.processor.to_q_i2v.weight.copy_(tb.attn1.to_q.weight)
             model._invalidate()
         return model
+
+    _MOTION_KEY = re.compile(r"^((down_blocks|up_blocks)\.\d+|mid_block)\.motion_modules\.")
+
+    def load_motion_modules(self, motion_adapter) -> None:
+        """unet_motion_mv_model.py:394-402: copy the motion modules of a MotionAdapter (anything with a ``state_dict()`` under the
+        adapter's key names) into this model; an adapter without a mid block leaves the mid motion module as it is."""
+        sd = {k: v for k, v in motion_adapter.state_dict().items() if self._MOTION_KEY.match(k)}
+        own = self.state_dict()
+        # the adapter carries the diffusers layers only; the processors' own parameters (to_*_sp, alpha_blender, ...) are not part of it
+        want = [k for k in own if self._MOTION_KEY.match(k) and ".processor." not in k and (k in sd or not k.startswith("mid_block."))]
+        missing = [k for k in want if k not in sd]
+        if missing:
+            raise KeyError(f"motion adapter lacks {len(missing)} keys, e.g. {missing[0]}")
+        self.load_state_dict(sd, strict=False)
+
+    def save_motion_modules(self, save_directory: str, is_main_process: bool = True, safe_serialization: bool = True, **unused) -> None:
+        """unet_motion_mv_model.py:404-438: write the motion modules as a diffusers MotionAdapter directory
+        (``config.json`` + ``diffusion_pytorch_model.safetensors`` / ``.bin``) that ``MotionAdapter.from_pretrained`` reads back."""
+        if not is_main_process:
+            return
+        import json
+        cfg = self.config
+        os.makedirs(save_directory, exist_ok=True)
+        # MotionAdapter holds the diffusers layers of the motion modules; the processors' parameters travel in the UNet checkpoint
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if self._MOTION_KEY.match(k) and ".processor." not in k}
+        meta = {"_class_name": "MotionAdapter", "block_out_channels": list(cfg.block_out_channels),
+                "motion_layers_per_block": cfg.layers_per_block, "motion_norm_num_groups": cfg.norm_num_groups,
+                "motion_num_attention_heads": cfg.motion_num_attention_heads, "motion_max_seq_length": cfg.motion_max_seq_length,
+                "use_motion_mid_block": True}
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(meta, f, indent=2)
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "diffusion_pytorch_model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "diffusion_pytorch_model.bin"))
+
+    def freeze_unet2d_params(self) -> None:
+        """unet_motion_mv_model.py:370-392: freeze everything but the motion modules (fine-tuning AnimateDiff style; train.py itself
+        selects by name, ``animate3d_amd.train.select_trainable``)."""
+        for p in self.parameters():
+            p.requires_grad = False
+        for _name, blk, _c in self._blocks():
+            for p in blk.motion_modules.parameters():
+                p.requires_grad = True
+
+    # diffusers conveniences of the reference class that change nothing on this implementation
+    def fuse_qkv_projections(self):
+        """:596-618.  The kernels always run fused projections (``_pack_t2d`` / ``_pack_motion``); nothing to do."""
+
+    def unfuse_qkv_projections(self):
+        """:620-631.  See ``fuse_qkv_projections``."""
+
+    def enable_forward_chunking(self, chunk_size: Optional[int] = None, dim: int = 0) -> None:
+        """:500-528 chunks the feed-forward to save memory; the fused GEGLU GEMM never materialises the 8C-wide projection, so
+        there is nothing to chunk.  Accepted for call compatibility."""
+        if dim not in (0, 1):
+            raise ValueError(f"Make sure to set `dim` to either 0 or 1, not {dim}")
+
+    def disable_forward_chunking(self) -> None:
+        """:530-539."""
+
+    def enable_freeu(self, s1: float, s2: float, b1: float, b2: float) -> None:
+        """:562-585 (FreeU re-weighting of the up blocks' backbone / skip features) is not implemented; no caller of the reference uses it."""
+        raise NotImplementedError("FreeU is not implemented on the MI355X path")
+
+    def disable_freeu(self) -> None:
+        """:587-594.  FreeU is never on."""
+
+    def set_default_attn_processor(self) -> None:
+        """:542-555 only works while every processor is a stock diffusers one and raises otherwise; this model always carries the
+        Animate3D processors, so it raises like the reference does in that state."""
+        raise ValueError(f"Cannot call `set_default_attn_processor` when attention processors are of type {next(iter(self.attn_processors.values()))}")
 
     def _load_ip_adapter_weights(self, state_dict):
         """Counterpart of diffusers' UNet2DConditionLoadersMixin._load_ip_adapter_weights for the

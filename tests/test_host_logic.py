@@ -368,3 +368,36 @@ def test_controlnet_residual_inputs(hw):
         model(**inp, attention_mask=torch.ones(n, 77))
     with pytest.raises(NotImplementedError):
         model(**inp, cross_attention_kwargs={"gligen": {}})
+
+
+def test_motion_module_save_load_freeze_surface(tmp_path):
+    """unet_motion_mv_model.py:370-438 and the diffusers conveniences the class inherits: freeze_unet2d_params, save_motion_modules ->
+    a MotionAdapter directory -> load_motion_modules, and the no-op / raising helpers."""
+    import json
+    from types import SimpleNamespace
+    from safetensors.torch import load_file
+    ocfg, ref, model = _pair(2, 2, (8, 8))
+    model.freeze_unet2d_params()
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert trainable and all("motion_modules." in k for k in trainable)
+    assert sum("motion_modules." in k for k, _ in model.named_parameters()) == len(trainable)
+    model.save_motion_modules(str(tmp_path / "adapter"))
+    meta = json.load(open(tmp_path / "adapter" / "config.json"))
+    assert meta["_class_name"] == "MotionAdapter" and meta["block_out_channels"] == list(ocfg.block_out_channels)
+    sd = load_file(str(tmp_path / "adapter" / "diffusion_pytorch_model.safetensors"))
+    assert sd and all("motion_modules." in k and ".processor." not in k for k in sd)
+    other = MVUNetMotionModel(UNetConfig(**SMALL), ops=TorchRefOps(), num_views=2)
+    before = other.state_dict()["down_blocks.0.resnets.0.conv1.weight"].clone()
+    other.load_motion_modules(SimpleNamespace(state_dict=lambda: sd))
+    for k, v in sd.items():
+        assert torch.equal(other.state_dict()[k], v), k
+    assert torch.equal(other.state_dict()["down_blocks.0.resnets.0.conv1.weight"], before)       # nothing else touched
+    with pytest.raises(KeyError):
+        other.load_motion_modules(SimpleNamespace(state_dict=lambda: {k: v for k, v in sd.items() if "down_blocks.1" not in k}))
+    other.fuse_qkv_projections(); other.unfuse_qkv_projections(); other.enable_forward_chunking(2, 1); other.disable_forward_chunking(); other.disable_freeu()
+    with pytest.raises(NotImplementedError):
+        other.enable_freeu(0.9, 0.2, 1.2, 1.4)
+    with pytest.raises(ValueError):
+        other.set_default_attn_processor()
+    with pytest.raises(ValueError):
+        other.enable_forward_chunking(2, 3)
