@@ -534,6 +534,13 @@ class MVUNetMotionModel(nn.Module):
         pr = a.proc
         L = h * w
         pe = None
+        if self._active_ops is not None:       # a differentiable forward: the tables below enter as constants
+            learn = ([pr.spatial_pos_embed.row_embed.weight, pr.spatial_pos_embed.col_embed.weight]
+                     if a.spatial_pe and pr.spatial_encoding_type == "learnable" else [])
+            learn += [pr.camera_embed.embedding_table.weight] if a.camera_pe and pr.camera_encoding_type == "learnable" else []
+            if any(t.requires_grad for t in learn):
+                raise NotImplementedError("learnable positional / camera-encoding tables are not trainable on this path (the reference's "
+                                          "training configuration uses the sinusoid encodings); freeze them (requires_grad_(False))")
         if a.spatial_pe:
             if pr.spatial_encoding_type == "learnable":
                 sp = pr.spatial_pos_embed

@@ -44,6 +44,10 @@ def _loss(unet, inp, target):
     (2, 2, (12, 20), {}),                                                   # forced up-sample sizes in the backward
     (2, 2, (8, 8), dict(motion_use_alpha_blender=False)),
     (2, 2, (8, 8), dict(mvdream_image_attn=False, motion_spatial_attn=False)),
+    # 16x16: with these switch sets the 1x1 deepest level of an 8x8 latent makes the fp32 gradient itself chaotic (the oracle's
+    # own fp32 autograd is then 3-7 % off its float64 run on whole blocks)
+    (2, 2, (16, 16), dict(motion_image_attn=True)),                        # first-frame image branch + 3-way SoftmaxAlphaBlender weights
+    (2, 2, (16, 16), dict(motion_use_camera_encoding=True, motion_camera_encoding_type="sinusoid")),
 ])
 def test_parameter_gradients_match_autograd_of_the_oracle(n, Fr, hw, kw):
     ocfg, ref, model = _pair(n, Fr, hw, **kw)
@@ -100,6 +104,15 @@ def test_training_rejects_what_it_cannot_differentiate():
     model.down_blocks[0].resnets[0].conv1.weight.requires_grad = True        # a 3x3 conv weight: no wgrad kernel
     with pytest.raises(NotImplementedError):
         model(**inp).sample.sum().backward()
+    # learnable positional tables would be trainable by name ('motion_modules.'): refused loudly rather than left without a gradient
+    ocfg, ref, model = _pair(2, 2, (8, 8), motion_spatial_encoding_type="learnable")
+    model.enable_training()
+    with pytest.raises(NotImplementedError):
+        model(**O.synthetic_inputs(ocfg, 2, 2, 2, (8, 8), seed=3, cfg_doubled=False))
+    for k, p in model.named_parameters():
+        if "spatial_pos_embed" in k:
+            p.requires_grad = False
+    assert model(**O.synthetic_inputs(ocfg, 2, 2, 2, (8, 8), seed=3, cfg_doubled=False)).sample.requires_grad
 
 
 # ------------------------------------------------------------------ the optimisation step (animate3d_amd/train.py)
