@@ -37,7 +37,8 @@ def sources():
 
 def _digest(path: str) -> str:
     h = hashlib.sha256()
-    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "animate3d_hip.h")]:
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for dep in [path, *headers, os.path.join(os.path.dirname(PKG), "include", "animate3d_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())

@@ -34,6 +34,7 @@
 #include <utility>
 
 #include "common.h"
+#include "flash_common.h"
 
 // tuning knobs shared by the bf16 and the fp16 build of this file (defined once, in the bf16 object)
 #ifdef A3D_STORAGE_F16
@@ -43,30 +44,6 @@ int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default dispatch, 5 = plain 
 #endif
 
 namespace {
-
-constexpr int OFS_FMA = 0, OFS_PAD = 1, OFS_ACC = 2;
-constexpr float LAZY_THR = 6.0f;     // log2 units: P may reach 2^6 before the offset moves
-
-struct AttnParams {
-  const uint16_t* Q; const uint16_t* K; const uint16_t* V; uint16_t* O;
-  a3d_rowmap qm, km, om;
-  int heads; int q_len, kv_len;
-  float scale_log2, out_scale; int accumulate;
-  int causal;      // key s may only be seen by queries >= s of the same group (CLIP text tower); generic kernel only
-};
-
-A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
-  return (g / m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (s / m.seg_len) * m.seg_stride + (s % m.seg_len);
-}
-
-// K row (within a 32-row sub-tile) that feeds MFMA A-row i: chosen so that result register r of a
-// lane in half g is key 16*(r>>3) + 8*g + (r&7).
-A3D_DEV int kperm(int i) {
-  const int j = i & 3, g = (i >> 2) & 1, b = i >> 3;
-  return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
-}
-
-A3D_DEV float round16(float x) { return lo16(pack16(x, 0.f)); }
 
 // VAR (tuning experiments, a3d_tune_flash): 1 = s_setprio(1) around MFMA groups, 2 = V fragments read before the
 // exps of their sub-tile, 4 = sched_group_barrier pattern {1 MFMA, 4 TRANS, 2 VALU} over the exp/PV section.
@@ -830,21 +807,6 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const AttnParams 
 // in the kernels above (permuted reads, padded contraction with the constant-1 column), V row-major with a 96-element
 // pitch and its constant-1 "dimension" 40, transposed on the way out of LDS by ds_read_b64_tr_b16 (conflict-free at
 // this pitch).  K is triple-, V quadruple-buffered: one barrier per 64-key tile.
-template <int N, typename F, int... I>
-A3D_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-A3D_DEV void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
-
-typedef short v4i16_t __attribute__((ext_vector_type(4)));
-A3D_DEV u32x2_t lds_tr16_b64(const uint16_t* ptr) {
-  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)ptr));
-}
-A3D_DEV float vmax3(float a, float b, float c) {      // no NaN canonicalisation of the MFMA results (fmaxf adds a v_max per input)
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
 constexpr int IL_KROW = 56, IL_VPITCH = 96, IL_NKB = 3, IL_NVB = 4;
 constexpr int IL_DUMP_OFF = IL_NKB * 64 * IL_KROW + IL_NVB * 64 * IL_VPITCH;        // element offset of the staging dump area
 constexpr int IL_SMEM_BYTES = (IL_DUMP_OFF + IL_NKB * 64 * IL_KROW + 64 * 8) * 2;  // dump: 1 KB reachable under any K buffer offset
@@ -1262,7 +1224,7 @@ extern int g_a3d_ta_pix;      // temporal_attn.hip
 #ifndef A3D_STORAGE_F16
 extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
-  if (variant == 8 || variant == 17) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
+  if (variant == 8 || variant == 17 || (variant >= 20 && variant <= 23)) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
 #ifdef A3D_ABLATIONS
   if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && (variant < 1000 || variant >= 2024)) return A3D_EINVAL;
 #else
@@ -1308,6 +1270,11 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
         break;
       }
 #endif
+      // LDS-DMA staged kernel (flash_attn_dm.hip): a3d_tune_flash(20 + flags)
+      if (g_flash_variant >= 20 && g_flash_variant <= 23 && aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512) {
+        if (int rc = A3D_FN(a3d_launch_flash_dm)(g_flash_variant - 20, groups, s, p)) return rc;
+        break;
+      }
       // interleaved kernel (default for the long aligned shapes): 8 waves x 64 queries; A/B variants 7 = 4 waves x 64, 13 = 4 x 128,
       // 15 = 8 x 32; 16 = the ping-pong kernel instead
       if (g_flash_variant != 5 && g_flash_variant != 16 && aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512) {

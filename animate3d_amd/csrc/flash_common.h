@@ -1,0 +1,59 @@
+// Shared pieces of the flash-attention translation units (flash_attn.hip: plain / ping-pong / interleaved kernels and the
+// C-ABI entry point; flash_attn_dm.hip: the LDS-DMA staged level-0 kernel).
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+struct AttnParams {
+  const uint16_t* Q; const uint16_t* K; const uint16_t* V; uint16_t* O;
+  a3d_rowmap qm, km, om;
+  int heads; int q_len, kv_len;
+  float scale_log2, out_scale; int accumulate;
+  int causal;      // key s may only be seen by queries >= s of the same group (CLIP text tower); generic kernel only
+};
+
+namespace {
+
+constexpr int OFS_FMA = 0, OFS_PAD = 1, OFS_ACC = 2;
+constexpr float LAZY_THR = 6.0f;     // log2 units: P may reach 2^6 before the offset moves
+
+
+A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
+  return (g / m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (s / m.seg_len) * m.seg_stride + (s % m.seg_len);
+}
+
+// K row (within a 32-row sub-tile) that feeds MFMA A-row i: chosen so that result register r of a
+// lane in half g is key 16*(r>>3) + 8*g + (r&7).
+A3D_DEV int kperm(int i) {
+  const int j = i & 3, g = (i >> 2) & 1, b = i >> 3;
+  return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
+}
+
+A3D_DEV float round16(float x) { return lo16(pack16(x, 0.f)); }
+
+template <int N, typename F, int... I>
+A3D_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+A3D_DEV void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+A3D_DEV u32x2_t lds_tr16_b64(const uint16_t* ptr) {
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)ptr));
+}
+A3D_DEV float vmax3(float a, float b, float c) {      // no NaN canonicalisation of the MFMA results (fmaxf adds a v_max per input)
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+
+A3D_DEV uint32_t fa_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+}  // namespace
+
+// flash_attn_dm.hip (one definition per storage type; internal to the library: hidden visibility)
+__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_flash_dm)(int flags, int groups, hipStream_t s, const AttnParams& p);

@@ -278,6 +278,54 @@ def test_flash_attn_interleaved_rescale_paths(ops, ref, spikes, L, q_len):
           ref.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L))
 
 
+@pytest.mark.parametrize("var", [20, 21, 23])
+@pytest.mark.parametrize("spikes,gain", [((), 1.0), ((3,), 3.0), ((40, 70), 3.0), ((500,), 4.0), ((31, 32, 63, 64, 95, 96), 3.0),
+                                         ((250,), 12.0), ((100, 400), 40.0), ((1023,), 60.0)])
+@pytest.mark.parametrize("L,q_len", [(512, 512), (1024, 700)])
+def test_flash_attn_dma_kernel(ops, ref, var, spikes, gain, L, q_len):
+    """flash_attn_dm_kernel (LDS-DMA staging, dense LDS images; a3d_tune_flash(20 + flags)): flags 0 = exact pass only, 1 = max-free
+    pass (bf16: offset fixed after the first 32 keys) with the exact re-run on overflow, 3 = + static wave priority.  Moderate spikes stay
+    inside the max-free pass (probabilities up to ~2^70), gains >= 40 overflow bf16 and must take the re-run; a spike in the very last
+    key, a ragged query count (masked rows) and spikes in the first sub-tile are covered."""
+    heads, D = 8, 40
+    C = heads * D
+    q, k, v = rnd(q_len, C, seed=1), rnd(L, C, seed=2), rnd(L, C, seed=3)
+    for t, row in enumerate(spikes):
+        k[row] = q[7 + 3 * t] * (gain + 0.5 * t)
+    qm, km = RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0)
+    want = ref.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
+    try:
+        assert ops.lib.a3d_tune_flash(var) == 0
+        got = ops.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
+    finally:
+        ops.lib.a3d_tune_flash(0)
+    check(f"dm attn var{var} spikes {spikes} x{gain} L{L} q{q_len}", got, want)
+
+
+@pytest.mark.parametrize("var", [20, 21])
+def test_flash_attn_dma_kernel_multiview_maps(ops, ref, var):
+    """The same kernel through the multi-view and first-frame row maps (segments of L rows, 64-key tiles wrap at segment ends),
+    with accumulate / out_scale, against the fp32 reference and against the interleaved kernel."""
+    heads, D, b, n, F, L = 8, 40, 2, 4, 2, 256
+    C = heads * D
+    qkv = rnd(b * n * F * L, 3 * C, seed=21)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    qm, k0 = _mv_maps(n, F, L)
+    S = n * L
+    try:
+        for km, nm in ((qm, "mv"), (k0, "i2v")):
+            want = ref.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
+            assert ops.lib.a3d_tune_flash(var) == 0
+            check(f"dm var{var} {nm} attn", ops.flash_attn(q, k, v, qm, km, b * F, heads, S, S), want)
+        base = rnd(b * n * F * L, C, seed=22)
+        o = base.clone()
+        ops.flash_attn(q, k, v, qm, k0, b * F, heads, S, S, out=o, out_scale=0.6, accumulate=True)
+        o_r = ref.flash_attn(q, k, v, qm, k0, b * F, heads, S, S, out=base.clone(), out_scale=0.6, accumulate=True)
+        check(f"dm var{var} accumulate", o, o_r, tol=6e-3)
+    finally:
+        ops.lib.a3d_tune_flash(0)
+
+
 def test_flash_attn_d80_kernel_variants(ops, ref):
     """Head dim 80: the two-sub-tile kernel (long sequences, default from 2048 tokens) and the one-sub-tile kernel, forced both
     ways on a long and a ragged short shape, each against the fp32 reference; the forced spike exercises the two-sub-tile

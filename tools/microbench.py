@@ -56,6 +56,30 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         ops.lib.a3d_tune_flash(0)
 
 
+def bench_flashdm(ops, variants=(0, 21, 23, 20, 0, 21, 23), scales=(1.0, 0.0, 3.0)):
+    """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel
+    (a3d_tune_flash(20 + flags)) against the interleaved kernel (0), interleaved rounds in one process; err vs the interleaved
+    kernel's output.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
+    D, n, F, L, b = 40, 4, 16, 4096, 2
+    heads, C = 8, 8 * D
+    qm = RowMap(F, n * F * L, L, L, F * L)
+    S, G = n * L, b * F
+    flops = 4.0 * G * S * S * C
+    for sc in scales:
+        qkv = rnd(b * n * F * L, 3 * C, scale=sc)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        ops.lib.a3d_tune_flash(0)
+        ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+        for var in variants:
+            if ops.lib.a3d_tune_flash(var) != 0:
+                continue
+            out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+            err = ((out - ref).norm() / (ref.norm() + 1e-30)).item()
+            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5)
+            print(f"level-0 D=40 scale={sc} var={var:2d}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err vs var 0 = {err:.2e}", flush=True)
+        ops.lib.a3d_tune_flash(0)
+
+
 def bench_il_abl(ops):
     """Timing ablations of the interleaved D = 40 attention kernel (-DA3D_ABLATIONS build; results wrong by construction)."""
     D, n, F, L, b = 40, 4, 16, 4096, 2
@@ -326,7 +350,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl,
+         "il_abl": bench_il_abl, "flashdm": bench_flashdm,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
