@@ -66,6 +66,16 @@ A3D_DEV f32x16_t mfma32(const u32x4_t& a, const u32x4_t& b, const f32x16_t& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
 #endif
 }
+// MFMA 16x16x32 (bf16 or fp16 inputs, fp32 accumulate).  Lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] and B[k = 8*(l>>4) .. +7][j = l&15];
+// result register r of lane l is D[i = 4*(l>>4) + r][j = l&15].
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+A3D_DEV f32x4_t mfma16(const u32x4_t& a, const u32x4_t& b, const f32x4_t& c) {
+#ifdef A3D_STORAGE_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#endif
+}
 // row index inside a 32x32 MFMA result for register r of a lane in half g = lane>>5
 A3D_DEV int mfma_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 

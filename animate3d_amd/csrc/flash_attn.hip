@@ -47,7 +47,11 @@ namespace {
 
 // VAR (tuning experiments, a3d_tune_flash): 1 = s_setprio(1) around MFMA groups, 2 = V fragments read before the
 // exps of their sub-tile, 4 = sched_group_barrier pattern {1 MFMA, 4 TRANS, 2 VALU} over the exp/PV section.
-template <int D, int BKV, int QT, int OFS, bool ALIGNED, int VAR>
+// NM = 1 (bf16 storage, OFS_PAD / OFS_ACC, aligned launches without a tail, >= 3 tiles): first a max-free pass — the offset is the exact
+// maximum of the first tile + 40 and never moves (bf16 P has fp32's exponent range; fp32 accumulation), so the per-score VALU work is
+// one v_exp and half a v_cvt_pk; the row sums out of the matrix pipe are checked once at the end and a workgroup whose sums
+// left [0, 2^100) re-runs with the exact lazy running maximum (flash_attn_dm.hip has the long form of the argument).
+template <int D, int BKV, int QT, int OFS, bool ALIGNED, int VAR, int NM = 0>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
   constexpr int NU = BKV / 32;             // 32-key sub-tiles per KV tile
   constexpr int VROW = BKV + 8;            // V^T image row stride (elements): odd number of 16-B slots
@@ -115,6 +119,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     }
   }
 
+#ifdef A3D_STORAGE_F16
+  constexpr bool TRY_NOMAX = false;
+#else
+  constexpr bool TRY_NOMAX = NM != 0;
+#endif
+  static_assert(NM == 0 || (OFS != OFS_FMA && ALIGNED && ONES), "the max-free pass needs the offset inside the matrix pipe and MFMA row sums");
+  // One complete pass over the keys; returns false when the max-free result must be discarded.
+  auto pass = [&](auto nm_c) __attribute__((always_inline)) -> bool {
+  constexpr bool NOMAX = decltype(nm_c)::value;
+  if constexpr (OFS == OFS_PAD) {
+#pragma unroll
+    for (int qs = 0; qs < QT; ++qs)
+      if (g == G_PAD) qf[qs][KS_PAD][0] = 0u;
+  }
   // ---- K/V staging: per-thread source pointers, advanced tile by tile
   const int64_t ld = p.km.ld;
   const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
@@ -229,8 +247,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   const int krow_off = kperm(l31) * KROW + 8 * g;
   const int vrow_off = l31 * VROW + 8 * g;
 
-  auto compute = [&](int buf, int kv0, auto tail_c) {
+  // first_c: 2 = the wave-uniform `first` flag decides (exact pass), 1 = this is the first tile, 0 = it is not (max-free pass)
+  auto compute = [&](int buf, int kv0, auto tail_c, auto first_c) {
     constexpr bool TAIL = decltype(tail_c)::value;
+    constexpr int FM = decltype(first_c)::value;
     const uint16_t* const Ks = Ks0 + buf * KS_ELEMS + krow_off;
     const uint16_t* const Vt = Vt0 + buf * VT_ELEMS + vrow_off;
     // ---- S'^T = K · Q'^T (- offset) for the NU 32-key sub-tiles; one K fragment feeds all QT query sub-tiles
@@ -325,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         for (int r = 0; r < 16; ++r) sacc[0][u][r] = fmaf(sacc[0][u][r], p.scale_log2, mneg);
     } else {
       // ---- lazy offset update: the common path is max + compare + one wave vote per query sub-tile; the slow
-      //      path re-bases S', rescales O and moves the offset
+      //      path re-bases S', rescales O and moves the offset.  Max-free pass: only the first tile sets an offset.
+      if constexpr (FM != 0) {
+      const bool isfirst = (FM == 1) ? true : first;
 #pragma unroll
       for (int qs = 0; qs < QT; ++qs) {
         float mx = sacc[qs][0][0];
@@ -333,9 +355,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
         for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][u][r]);
-        if (__any(first || mx > LAZY_THR)) {
+        if (__any(isfirst || mx > LAZY_THR)) {
           const float mxp = fmaxf(mx, __shfl_xor(mx, 32));
-          float delta = first ? mxp : fmaxf(mxp, 0.f);
+          float delta = isfirst ? mxp + (NOMAX ? 40.f : 0.f) : fmaxf(mxp, 0.f);
           float new_off = m_off[qs] + delta;
           if constexpr (OFS == OFS_PAD) { new_off = round16(new_off); delta = new_off - m_off[qs]; }
           m_off[qs] = new_off;
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[qs][u][r] -= delta;
-          if (!first) {
+          if (!isfirst) {
             const float alpha = __builtin_amdgcn_exp2f(-delta);
             if constexpr (!ONES) l_run *= alpha;
 #pragma unroll
@@ -358,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
             for (int r = 0; r < 16; ++r) minit[qs][r] = -new_off;
           }
         }
+      }
       }
       first = false;
     }
@@ -421,25 +444,35 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   if (ntiles > 1) load_tile(1);
   __syncthreads();
   const int nfast = has_tail ? ntiles - 1 : ntiles;     // tiles the incremental-pointer path may load
+  constexpr std::integral_constant<int, NOMAX ? 0 : 2> FM_LOOP{};
   int t = 0;
   if constexpr (ALIGNED) {
+    if constexpr (NOMAX) {                               // peeled first tile (the launcher guarantees >= 3 tiles, no tail)
+      store_kv(1);
+      load_kv(std::false_type{});
+      compute(0, 0, std::false_type{}, std::integral_constant<int, 1>{});
+      __syncthreads();
+      t = 1;
+    }
     for (; t + 2 < nfast; ++t) {                         // steady state: no clamp, no mask, no div/mod
       store_kv((t + 1) & 1);                             // registers hold tile t+1 (requested one iteration ago)
       load_kv(std::false_type{});                        // tile t+2
-      compute(t & 1, t * BKV, std::false_type{});
+      compute(t & 1, t * BKV, std::false_type{}, FM_LOOP);
       __syncthreads();
     }
   }
   for (; t < ntiles - 1; ++t) {                          // generic / last iterations
     store_kv((t + 1) & 1);
     if (t + 2 < ntiles) load_tile(t + 2);
-    compute(t & 1, t * BKV, std::false_type{});
+    compute(t & 1, t * BKV, std::false_type{}, FM_LOOP);
     __syncthreads();
   }
-  if (has_tail) compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::true_type{});
-  else compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::false_type{});
+  if (has_tail) compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::true_type{}, FM_LOOP);
+  else compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::false_type{}, FM_LOOP);
 
   // ---- finalize: lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j] for each query sub-tile
+  float inv[QT];
+  bool bad = false;
 #pragma unroll
   for (int qs = 0; qs < QT; ++qs) {
     float l_tot;
@@ -450,7 +483,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     } else {
       l_tot = l_run + __shfl_xor(l_run, 32);
     }
-    const float inv = p.out_scale / l_tot;
+    bad = bad || !(l_tot < 1.2676506e30f) || !(l_tot > 0.f);
+    inv[qs] = p.out_scale / l_tot;
+  }
+  if constexpr (NOMAX) {
+    if (__syncthreads_or(bad ? 1 : 0)) return false;       // (every wave is also done with the LDS images)
+  }
+#pragma unroll
+  for (int qs = 0; qs < QT; ++qs) {
     if (q_ok[qs]) {
       uint16_t* orow = p.O + map_row(p.om, grp, q_idx[qs]) * p.om.ld + hoff;
 #pragma unroll
@@ -461,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           if (d < D) {
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv;
+            for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv[qs];
             if (p.accumulate) {
               const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
               v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
@@ -473,6 +513,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           }
         }
     }
+  }
+  return true;
+  };    // pass
+
+  if constexpr (TRY_NOMAX) {
+    if (!pass(std::true_type{})) pass(std::false_type{});
+  } else {
+    pass(std::false_type{});
   }
 }
 
@@ -1209,11 +1257,11 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
 }
 
 
-template <int D, int BKV, int QT, int OFS, int VAR = 0>
+template <int D, int BKV, int QT, int OFS, int VAR = 0, int NM = 0>
 void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
   const int q_tiles = (p.q_len + 128 * QT - 1) / (128 * QT);
   const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
-  if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true, VAR><<<grid, dim3(256), 0, s>>>(p);
+  if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true, VAR, NM><<<grid, dim3(256), 0, s>>>(p);
   else flash_attn_kernel<D, BKV, QT, OFS, false, 0><<<grid, dim3(256), 0, s>>>(p);
 }
 
@@ -1224,11 +1272,11 @@ extern int g_a3d_ta_pix;      // temporal_attn.hip
 #ifndef A3D_STORAGE_F16
 extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
-  if (variant == 8 || variant == 17 || (variant >= 20 && variant <= 23)) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
+  if (variant == 8 || variant == 17 || (variant >= 20 && variant <= 41)) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
 #ifdef A3D_ABLATIONS
-  if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && (variant < 1000 || variant >= 2024)) return A3D_EINVAL;
+  if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && variant != 19 && (variant < 1000 || variant >= 2024)) return A3D_EINVAL;
 #else
-  if (variant != 0 && variant != 5 && variant != 6 && variant != 7 && variant != 13 && variant != 15 && variant != 16) return A3D_EINVAL;
+  if (variant != 0 && variant != 5 && variant != 6 && variant != 7 && variant != 13 && variant != 15 && variant != 16 && variant != 19) return A3D_EINVAL;
 #endif
   g_flash_variant = variant;
   return A3D_OK;
@@ -1270,10 +1318,19 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
         break;
       }
 #endif
-      // LDS-DMA staged kernel (flash_attn_dm.hip): a3d_tune_flash(20 + flags)
-      if (g_flash_variant >= 20 && g_flash_variant <= 23 && aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512) {
-        if (int rc = A3D_FN(a3d_launch_flash_dm)(g_flash_variant - 20, groups, s, p)) return rc;
-        break;
+      // LDS-DMA staged kernel (flash_attn_dm.hip).  bf16 storage: the default for the long aligned shapes (flags 5: max-free first
+      // pass + P·V through the 16x16x32 MFMA); a3d_tune_flash(20 + flags) forces a flag set, 19 forces the interleaved kernel below.
+      // fp16 storage keeps the interleaved kernel (the max-free pass needs bf16's exponent range; forced flag sets run the exact pass).
+      {
+        const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512;
+        int dm_flags = (g_flash_variant >= 20 && g_flash_variant <= 35) ? g_flash_variant - 20 : -1;
+#ifndef A3D_STORAGE_F16
+        if (g_flash_variant == 0) dm_flags = 5;
+#endif
+        if (long_aligned && dm_flags >= 0) {
+          if (int rc = A3D_FN(a3d_launch_flash_dm)(dm_flags, groups, s, p)) return rc;
+          break;
+        }
       }
       // interleaved kernel (default for the long aligned shapes): 8 waves x 64 queries; A/B variants 7 = 4 waves x 64, 13 = 4 x 128,
       // 15 = 8 x 32; 16 = the ping-pong kernel instead
@@ -1306,6 +1363,11 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
       // long sequences (level 1 of the 512-px configurations): two query sub-tiles per wave, 32-key tiles — every K / V^T
       // fragment read feeds two MFMAs, which relieves the LDS port that bounds the one-sub-tile kernel (+4-8 %,
       // profiles/r2_microbench_flash80_ab.log); short ones keep one sub-tile per wave (more workgroups).  a3d_tune_flash(8 | 17) forces either.
+#ifndef A3D_STORAGE_F16
+      // bf16, long aligned sequences: max-free first pass with the offset in the MFMA's C operand (a3d_tune_flash(40); 41: one query sub-tile)
+      if (g_flash_variant == 40 && aligned && kv_len % 32 == 0 && kv_len >= 128) { launch<80, 32, 2, OFS_ACC, 0, 1>(true, groups, s, p); break; }
+      if (g_flash_variant == 41 && aligned && kv_len % 64 == 0 && kv_len >= 256) { launch<80, 64, 1, OFS_ACC, 0, 1>(true, groups, s, p); break; }
+#endif
       if (g_flash_variant == 8 || (g_flash_variant != 17 && q_len >= 2048 && kv_len >= 2048)) { launch<80, 32, 2, OFS_FMA>(aligned, groups, s, p); break; }
       launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p);
       break;

@@ -34,7 +34,8 @@ constexpr int DM_TILEB = 4 * DM_UNITB;             // [K keys 0..63 | V keys 0..
 constexpr int DM_VOFF = 2 * DM_UNITB;              // V image inside a tile buffer
 constexpr int DM_RING = 8;
 constexpr int DM_CK = DM_RING * DM_TILEB;          // K constant chunk (16 B): 1.0 in contraction slot 40, zeros in 41..47
-constexpr int DM_CV = DM_CK + 64;                  // V constant region: (1,0,0,0) pieces at DM_CV + {0, 80, 1280, 1360}, zero elsewhere
+constexpr int DM_CV = DM_CK + 80;                  // V constant region: (1,0,0,0) pieces at DM_CV + {0, 80, 1280, 1360}, zero elsewhere; its first
+                                                   // bank is 4 mod 8 (mod 16), where no data lane of the same read lands
 constexpr int DM_CV_BYTES = 1408;
 constexpr int DM_SMEM_BYTES = DM_CV + DM_CV_BYTES;
 constexpr float DM_L_BAD = 1.2676506e30f;          // 2^100: beyond this the max-free result is not trusted
@@ -56,6 +57,14 @@ A3D_DEV void dm_glds16_q(uint32_t voff, const void* sbase, uint32_t lds_dst) {
                "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
                : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
+// the same under a wave-uniform lane mask (0 = this wave has no share of the tile)
+A3D_DEV void dm_glds16_m(uint32_t voff, const void* sbase, uint32_t lds_dst, uint64_t mask) {
+  unsigned keep;
+  uint64_t ex;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(mask) : "memory");
+}
 A3D_DEV const uint16_t* dm_scalar(const uint16_t* ptr) {      // wave-uniform by construction; say so
   const uint64_t a = (uint64_t)(uintptr_t)ptr;
   return (const uint16_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
@@ -68,12 +77,21 @@ A3D_DEV u32x4_t dm_lds128(uint32_t off) { return *reinterpret_cast<const u32x4_t
 A3D_DEV u32x2_t dm_ldstr(uint32_t off) { return lds_tr16_b64(reinterpret_cast<const uint16_t*>(dm_smem + off)); }
 
 // FLAGS: 1 = max-free softmax with exact re-run (bf16 storage only), 2 = static s_setprio(1) for the second-dispatched half
-//        of the workgroup (MI355X_MICROARCH.md "static priority for the younger half")
-template <int FLAGS>
-__global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams p) {
-  constexpr int D = 40, QT = 2, KS = 3, MT = 2, NT = 512, BQ = 512;
+//        of the workgroup (MI355X_MICROARCH.md "static priority for the younger half"), 4 = O^T += V^T·P^T through
+//        v_mfma_f32_16x16x32: O^T has 41 useful rows (40 dims + the ones row), i.e. 48 in 16-row tiles instead of 64 in
+//        32-row tiles: 24 instead of 28 MFMA-equivalents per 64 x 64 tile.  The 32x32 score tile keeps a query in lane & 31,
+//        the 16x16x32 B operand wants it in lane & 15: one v_permlane16_swap per packed pair of P moves the odd 16-lane rows
+//        of the first key half against the even rows of the second (16 per 64 x 64 tile).
+// QT: query sub-tiles of 32 per wave.  2 = 8 waves x 64 queries (two waves per SIMD, up to 256 registers); 1 = 16 waves x 32 queries
+//     (four waves per SIMD, 128 registers: twice the LDS fragment reads per MFMA, but four instruction streams per SIMD to
+//     overlap matrix and vector work and to hide LDS latency and barrier skew).  Both stage one copy of K/V for 512 queries.
+template <int FLAGS, int QT>
+__global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const AttnParams p) {
+  constexpr int D = 40, KS = 3, MT = 2, NW = 16 / QT, NT = 64 * NW, BQ = 512;
+  constexpr int NDMA = QT;                                // LDS-DMA instructions per wave and tile (QT = 1: waves 0..9 one each)
   constexpr int KS_PAD = 2, G_PAD = 1;                    // fragment slot of contraction index 40
   constexpr int NEXP = 16 * QT, NCVT = 8 * QT;
+  constexpr bool PV16 = (FLAGS & 4) != 0;
 #ifdef A3D_STORAGE_F16
   constexpr bool TRY_NOMAX = false;
 #else
@@ -91,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
 
   // one-time LDS init: the constant region
   for (int i = tid; i < (DM_SMEM_BYTES - DM_CK) / 2; i += NT) {
-    const int vb = 2 * i - 64;      // byte offset inside the V constant region
+    const int vb = 2 * i - (DM_CV - DM_CK);      // byte offset inside the V constant region
     const bool one = (i == 0) || vb == 0 || vb == 80 || vb == 1280 || vb == 1360;
     reinterpret_cast<uint16_t*>(dm_smem + DM_CK)[i] = one ? ONE16 : (uint16_t)0;
   }
@@ -128,23 +146,40 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
     const bool isk = slot < 320;
     const int s2 = isk ? slot : slot - 320;
     const int prow = s2 / 5, c = s2 % 5;
-    const int key = isk ? prow : ((prow & ~15) | (4 * (prow & 3) + ((prow >> 2) & 3)));
+    int key = prow;
+    if (!isk) {
+      if constexpr (PV16) {     // row = 16 half + 8 b4 + 2 j + rr  holds key 16 b4 + 8 half + 4 rr + j of its 32-key sub-tile
+        const int pr = prow & 31;
+        key = (prow & ~31) | (16 * ((pr >> 3) & 1) + 8 * (pr >> 4) + 4 * (pr & 1) + ((pr >> 1) & 3));
+      } else {
+        key = (prow & ~15) | (4 * (prow & 3) + ((prow >> 2) & 3));
+      }
+    }
     return (uint32_t)(((int64_t)key * ld + c * 8) * 2);
   };
-  const uint32_t voffA = slot_src(64 * w + lane);
-  const uint32_t voffB = slot_src(512 + 16 * w + i16);
+  const uint32_t voffA = slot_src(w < 10 ? 64 * w + lane : lane);
+  const uint32_t voffB = slot_src(QT == 2 ? 512 + 16 * w + i16 : 0);
+  const uint64_t maskA = w < 10 ? ~0ull : 0ull;
 
   // ---- fragment addressing (byte offsets into dm_smem; the tile / sub-tile offset is added per step, scaled by 0 for the
   // lanes that read constants)
   const uint32_t klane = (uint32_t)(kperm(l31) * DM_ROWB + 16 * g);             // K fragments 0, 1: + 32 ks
   const uint32_t klane2 = g ? (uint32_t)DM_CK : klane + 64u;                    // K fragment 2: dims 32..39 | constant chunk
-  const uint32_t kmul = g ? 0u : 1u;
+  uint32_t kmul = g ? 0u : 1u;
+  asm volatile("" : "+v"(kmul));      // opaque: keeps  lane + mul * offset  one v_mad_u32_u24 (the compiler otherwise builds mov + cndmask + add)
   const int c4 = i16 & 3;
-  const uint32_t vrow = (uint32_t)((4 * (i16 >> 2) + 2 * (q4 >> 1)) * DM_ROWB);
-  const uint32_t vlane0 = vrow + (uint32_t)(2 * (16 * (q4 & 1) + 4 * c4));      // O^T rows 0..31: all data
-  const bool v1_data = (q4 & 1) == 0 && c4 < 2;                                 // O^T rows 32..63: dims 32..39 | ones | zeros
-  const uint32_t vlane1 = v1_data ? vrow + (uint32_t)(2 * (32 + 4 * c4)) : (((q4 & 1) == 0 && c4 == 2) ? (uint32_t)DM_CV : (uint32_t)(DM_CV + 8));
-  const uint32_t vmul = v1_data ? 1u : 0u;
+  // 32x32 PV: a 16-lane group (q4) reads keys 8 (q4 >> 1) + 4 rr + (i16 >> 2) of a 16-key half, dims 16 (q4 & 1) + 4 c4 of a 32-row tile;
+  //           rows are stored 4x4-transposed inside every 16-key group.
+  // 16x16 PV: a group reads keys [0, 16, 8, 24][q4] + 4 rr + (i16 >> 2), dims 4 c4 of a 16-row tile; row = 16 (q4 >> 1) + 8 (q4 & 1) + 2 (i16 >> 2) + rr
+  //           (the eight keys of a 32-lane half land on eight rows of one parity: 8-dword windows on all 64 banks).
+  const uint32_t vrow = PV16 ? (uint32_t)((16 * (q4 >> 1) + 8 * (q4 & 1) + 2 * (i16 >> 2)) * DM_ROWB)
+                             : (uint32_t)((4 * (i16 >> 2) + 2 * (q4 >> 1)) * DM_ROWB);
+  const uint32_t vlane0 = PV16 ? vrow + (uint32_t)(8 * c4) : vrow + (uint32_t)(2 * (16 * (q4 & 1) + 4 * c4));      // O^T rows 0..31: all data
+  const bool v1_data = PV16 ? c4 < 2 : ((q4 & 1) == 0 && c4 < 2);               // O^T rows 32..: dims 32..39 | ones | zeros
+  const bool v1_one = PV16 ? c4 == 2 : ((q4 & 1) == 0 && c4 == 2);
+  const uint32_t vlane1 = v1_data ? vrow + (uint32_t)(2 * (32 + 4 * c4)) : (v1_one ? (uint32_t)DM_CV : (uint32_t)(DM_CV + 8));
+  uint32_t vmul = v1_data ? 1u : 0u;
+  asm volatile("" : "+v"(vmul));
 
   if constexpr ((FLAGS & 2) != 0) {
     if (w >= 4) __builtin_amdgcn_s_setprio(1);
@@ -159,33 +194,74 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
     gB = dm_scalar(p.V + hoff + kgbase * ld);
     seg_off = 0;
   };
-  auto dma_a = [&](int tile) __attribute__((always_inline)) {
-    dm_glds16(voffA, gA, lds0 + (uint32_t)((tile & (DM_RING - 1)) * DM_TILEB + 1024 * w));
-  };
-  auto dma_b = [&](int tile) __attribute__((always_inline)) {      // second instruction of a tile; then the bases move on
-    dm_glds16_q(voffB, gB, lds0 + (uint32_t)((tile & (DM_RING - 1)) * DM_TILEB + 8192 + 256 * w));
+  auto dma_advance = [&]() __attribute__((always_inline)) {
     seg_off += 64;
     int64_t stp = tile_step;
     if (seg_off >= seg_len) { stp += wrap_step; seg_off = 0; }
     gA += stp; gB += stp;
   };
-  f32x16_t oacc[QT][MT];
+  auto dma_a = [&](int tile) __attribute__((always_inline)) {
+    if constexpr (QT == 2) {
+      dm_glds16(voffA, gA, lds0 + (uint32_t)((tile & (DM_RING - 1)) * DM_TILEB + 1024 * w));
+    } else {
+      dm_glds16_m(voffA, gA, lds0 + (uint32_t)((tile & (DM_RING - 1)) * DM_TILEB + 1024 * (w < 10 ? w : 0)), maskA);
+      dma_advance();
+    }
+  };
+  auto dma_b = [&](int tile) __attribute__((always_inline)) {      // second instruction of a tile (QT = 2); then the bases move on
+    if constexpr (QT == 2) {
+      dm_glds16_q(voffB, gB, lds0 + (uint32_t)((tile & (DM_RING - 1)) * DM_TILEB + 8192 + 256 * w));
+      dma_advance();
+    }
+  };
+  f32x16_t oacc[QT][MT];       // 32x32 PV: O^T tiles [query sub-tile][32 rows]
+  f32x4_t oacc16[3][2 * QT];   // 16x16 PV: O^T tiles [16 rows][16 queries]; rows 4 q4 + r, query 16 nb + i16
   u32x4_t kf[KS];
-  u32x4_t vf[MT][2];          // V^T fragments of the sub-tile whose P is multiplied next
+  u32x4_t vf[MT][2];           // V^T fragments of the sub-tile whose P is multiplied next (32x32 PV: [row tile][key half])
+  u32x4_t vf16[3];             // (16x16 PV: [row tile], 32 keys each)
   auto read_k = [&](uint32_t koff) __attribute__((always_inline)) {          // K fragments of the sub-tile at byte offset koff
-    const uint32_t a = klane + koff, a2 = klane2 + kmul * koff;
+    const uint32_t a = klane + koff, a2 = __umul24(kmul, koff) + klane2;
     kf[0] = dm_lds128(a); kf[1] = dm_lds128(a + 32); kf[2] = dm_lds128(a2);
   };
+  // V^T fragment half i of the sub-tile at a0 / a1 (a1: the row tile that holds the constants)
+  auto read_vhalf = [&](auto i_c, uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (PV16) {
+      constexpr int mb = i / 2, rr = i % 2;
+      const u32x2_t t = dm_ldstr((mb == 2 ? a1 : a0 + 32 * mb) + rr * DM_ROWB);
+      vf16[mb][2 * rr] = t[0];
+      vf16[mb][2 * rr + 1] = t[1];
+    } else {
+      constexpr int mt = i / 4, h = (i / 2) % 2, rr = i % 2;
+      const u32x2_t t = dm_ldstr((mt ? a1 : a0) + (16 * h + rr) * DM_ROWB);
+      vf[mt][h][2 * rr] = t[0];
+      vf[mt][h][2 * rr + 1] = t[1];
+    }
+  };
+  constexpr int NVH = PV16 ? 6 : 8;          // fragment halves per sub-tile
   auto read_v = [&](uint32_t voff) __attribute__((always_inline)) {
-    const uint32_t a0 = vlane0 + voff, a1 = vlane1 + vmul * voff;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const u32x2_t lo = dm_ldstr((mt ? a1 : a0) + (16 * h) * DM_ROWB);
-        const u32x2_t hi = dm_ldstr((mt ? a1 : a0) + (16 * h + 1) * DM_ROWB);
-        vf[mt][h] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
-      }
+    const uint32_t a0 = vlane0 + voff, a1 = __umul24(vmul, voff) + vlane1;
+    static_for<NVH>([&](auto i_c) __attribute__((always_inline)) { read_vhalf(i_c, a0, a1); });
+  };
+  // PV MFMA instruction i of a sub-tile (32x32: 8 instructions of 32 cycles; 16x16: 12 of 16 cycles); P as packed by finish_p
+  constexpr int NPVI = PV16 ? 6 * QT : 4 * QT;
+  auto pv_mfma = [&](auto i_c, u32x4_t (&P)[QT][2]) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (PV16) {
+      constexpr int mb = i / (2 * QT), nb = i % (2 * QT);
+      oacc16[mb][nb] = mfma16(vf16[mb], P[nb / 2][nb % 2], oacc16[mb][nb]);
+    } else {
+      constexpr int mt = i / (2 * QT), h = (i / QT) % 2, qs = i % QT;
+      oacc[qs][mt] = mfma32(vf[mt][h], P[qs][h], oacc[qs][mt]);
+    }
+  };
+  // 16x16 PV: turn the packed probabilities of query sub-tile qs, pair jj (P[qs][h][jj] = keys 16 h + 8 g + 2 jj, + 1 of query l31) into the
+  // B operands of query blocks 2 qs (in P[qs][0]) and 2 qs + 1 (in P[qs][1]): 16-lane row q4 then holds keys [0, 16, 8, 24][q4] + 2 jj, + 1
+  auto swap_p = [&](auto k_c, u32x4_t (&P)[QT][2]) __attribute__((always_inline)) {
+    constexpr int k = decltype(k_c)::value, qs = k / 4, jj = k % 4;
+    const auto r = __builtin_amdgcn_permlane16_swap(P[qs][0][jj], P[qs][1][jj], false, false);
+    P[qs][0][jj] = r[0];
+    P[qs][1][jj] = r[1];
   };
   auto clear_o = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -196,6 +272,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[qs][mt][r] = 0.f;
     }
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2 * QT; ++nb) oacc16[mb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
   const int nt = p.kv_len / 64;               // launcher guarantees kv_len % 64 == 0, nt >= 4, aligned segments
   auto prologue_dma = [&]() __attribute__((always_inline)) {      // tiles 0, 1, 2 requested; 0 and 1 complete
@@ -203,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
     dma_a(0); dma_b(0);
     dma_a(1); dma_b(1);
     dma_a(2); dma_b(2);
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
   };
   // first offset of a query: exact maximum of its first 32 scores (+ bias); leaves the re-based scores in s
   auto first_scores = [&](f32x16_t (&s)[QT], float (&m_off)[QT], float bias) __attribute__((always_inline)) {
@@ -225,32 +305,59 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
       if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);
     }
   };
-  auto store_out = [&](const float (&inv)[QT]) __attribute__((always_inline)) {
-    // lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j] for each query sub-tile
+  // row sums (O^T row 40): 32x32 layout: register 4 of the second row tile, half 0 (query l31); 16x16 layout: register 0 of row
+  // tile 2 in lanes 32..47 (query i16 of block nb).  Returns 1 / sum scaled for the store; `bad` = sum unusable (max-free pass).
+  constexpr int NINV = PV16 ? 2 * QT : QT;
+  auto row_sums = [&](float (&inv)[NINV]) __attribute__((always_inline)) -> bool {
+    bool bad = false;
 #pragma unroll
-    for (int qs = 0; qs < QT; ++qs) {
-      const int q_idx = qt * BQ + wid * 32 * QT + qs * 32 + l31;
-      if (q_idx < p.q_len) {
-        uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
+    for (int i = 0; i < NINV; ++i) {
+      float l_tot;
+      if constexpr (PV16) l_tot = __shfl(oacc16[2][i][0], 32 + i16);
+      else l_tot = __shfl(oacc[i][1][4], l31);
+      bad = bad || !(l_tot < DM_L_BAD) || !(l_tot > 0.f);
+      inv[i] = p.out_scale / l_tot;
+    }
+    return bad;
+  };
+  auto store4 = [&](uint16_t* dst, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
+    if (p.accumulate) {
+      const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(dst);
+      v0 += lo16(prev[0]); v1 += hi16(prev[0]); v2 += lo16(prev[1]); v3 += hi16(prev[1]);
+    }
+    u32x2_t o;
+    o[0] = pack16(v0, v1);
+    o[1] = pack16(v2, v3);
+    *reinterpret_cast<u32x2_t*>(dst) = o;
+  };
+  auto store_out = [&](const float (&inv)[NINV]) __attribute__((always_inline)) {
+    if constexpr (PV16) {      // lane holds O[q = 16 nb + i16][d = 16 mb + 4 q4 + r]
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int nb = 0; nb < 2 * QT; ++nb) {
+        const int q_idx = qt * BQ + wid * 32 * QT + 16 * nb + i16;
+        if (q_idx < p.q_len) {
+          uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const int d = 32 * mt + 8 * qd + 4 * g;
-            if (d < D) {
-              float v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv[qs];
-              if (p.accumulate) {
-                const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
-                v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
-              }
-              u32x2_t o;
-              o[0] = pack16(v[0], v[1]);
-              o[1] = pack16(v[2], v[3]);
-              *reinterpret_cast<u32x2_t*>(orow + d) = o;
-            }
+          for (int mb = 0; mb < 3; ++mb) {
+            const int d = 16 * mb + 4 * q4;
+            if (d < D) store4(orow + d, oacc16[mb][nb][0] * inv[nb], oacc16[mb][nb][1] * inv[nb], oacc16[mb][nb][2] * inv[nb], oacc16[mb][nb][3] * inv[nb]);
           }
+        }
+      }
+    } else {                   // lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j] for each query sub-tile
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs) {
+        const int q_idx = qt * BQ + wid * 32 * QT + qs * 32 + l31;
+        if (q_idx < p.q_len) {
+          uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const int d = 32 * mt + 8 * qd + 4 * g;
+              if (d < D) store4(orow + d, oacc[qs][mt][4 * qd] * inv[qs], oacc[qs][mt][4 * qd + 1] * inv[qs], oacc[qs][mt][4 * qd + 2] * inv[qs], oacc[qs][mt][4 * qd + 3] * inv[qs]);
+            }
+        }
       }
     }
   };
@@ -275,27 +382,25 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
     auto step = [&](auto do_qk_c, auto do_pv_c, f32x16_t (&sCur)[QT], f32x16_t (&sNext)[QT], u32x4_t (&pCur)[QT][2],
                     u32x4_t (&pPrev)[QT][2], uint32_t kOff, uint32_t vOff, auto&& hook) __attribute__((always_inline)) {
       constexpr bool DO_QK = decltype(do_qk_c)::value, DO_PV = decltype(do_pv_c)::value;
-      constexpr int NPV = DO_PV ? 2 * MT * QT : 0, NQK = DO_QK ? KS * QT : 0, NS = NPV + NQK;
-      constexpr int KSLOT = 3, VS0 = NPV + 1;
-      const uint32_t va0 = vlane0 + vOff, va1 = vlane1 + vmul * vOff;
+      constexpr int PPS = PV16 ? 2 : 1;                                   // PV instructions per slot (a slot = 32 matrix-pipe cycles)
+      constexpr int NPV = DO_PV ? NPVI / PPS : 0, NQK = DO_QK ? KS * QT : 0, NS = NPV + NQK;
+      constexpr int KSLOT = NPV >= 4 ? 3 : 0, VS0 = NPV + 1;              // K fragments early in the PV block; V halves VPS per slot from VS0
+      constexpr int VPS = DO_QK ? (NVH + NQK - 2) / (NQK - 1) : 1;
+      const uint32_t va0 = vlane0 + vOff, va1 = __umul24(vmul, vOff) + vlane1;
       float e[NEXP];
       auto do_cvt = [&](auto c_c) __attribute__((always_inline)) {
         constexpr int c = decltype(c_c)::value;
         constexpr int qs = c / 8, h = (c / 4) % 2, jj = c % 4;
         pCur[qs][h][jj] = pack16(e[2 * c], e[2 * c + 1]);
       };
-      auto read_vh = [&](auto i_c) __attribute__((always_inline)) {      // half i of the 8 V^T fragment halves of sub-tile j
-        constexpr int i = decltype(i_c)::value, mt = i / 4, h = (i / 2) % 2, rr = i % 2;
-        const u32x2_t t = dm_ldstr((mt ? va1 : va0) + (16 * h + rr) * DM_ROWB);
-        vf[mt][h][2 * rr] = t[0];
-        vf[mt][h][2 * rr + 1] = t[1];
-      };
+      // conversions complete before slot s ends: pairs [0, cdone(s)); a swap needs pair qs*8 + 4 + jj and waits one more slot (the
+      // permlane reads two wait states after a VALU write)
+      auto cdone = [](int s) constexpr { return s < 0 ? 0 : (NEXP * s / NS) / 2; };
       __builtin_amdgcn_sched_barrier(0);
       static_for<NS>([&](auto s_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
         if constexpr (s < NPV) {
-          constexpr int mt = s / (2 * QT), h = (s / QT) % 2, qs = s % QT;
-          oacc[qs][mt] = mfma32(vf[mt][h], pPrev[qs][h], oacc[qs][mt]);
+          static_for<PPS>([&](auto i_c) __attribute__((always_inline)) { pv_mfma(std::integral_constant<int, PPS * s + decltype(i_c)::value>{}, pPrev); });
         } else {
           constexpr int i = s - NPV, ks = i / QT, qs = i % QT;
           if constexpr (ks == 0) {
@@ -308,9 +413,11 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
           }
         }
         if constexpr (DO_QK && DO_PV && s == KSLOT) read_k(kOff);
-        if constexpr (DO_QK && s >= VS0 && s < VS0 + 4) {
-          read_vh(std::integral_constant<int, 2 * (s - VS0)>{});
-          read_vh(std::integral_constant<int, 2 * (s - VS0) + 1>{});
+        if constexpr (DO_QK && s >= VS0 && VPS * (s - VS0) < NVH) {
+          static_for<VPS>([&](auto i_c) __attribute__((always_inline)) {
+            constexpr int i = VPS * (s - VS0) + decltype(i_c)::value;
+            if constexpr (i < NVH) read_vhalf(std::integral_constant<int, i>{}, va0, va1);
+          });
         }
         hook(s_c);
         constexpr int E0 = NEXP * s / NS, E1 = NEXP * (s + 1) / NS;
@@ -318,13 +425,25 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
           constexpr int x = E0 + decltype(x_c)::value;
           e[x] = __builtin_amdgcn_exp2f(sCur[x / 16][x % 16]);
         });
-        constexpr int C0 = (s == 0) ? 0 : (NEXP * (s - 1) / NS) / 2, C1 = E0 / 2;
+        constexpr int C0 = cdone(s - 1), C1 = cdone(s);
         static_for<C1 - C0>([&](auto c_c) __attribute__((always_inline)) { do_cvt(std::integral_constant<int, C0 + decltype(c_c)::value>{}); });
+        if constexpr (PV16) {
+          static_for<4 * QT>([&](auto k_c) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_c)::value, need = (k / 4) * 8 + 4 + (k % 4);
+            if constexpr (need < cdone(s - 1) && !(need < cdone(s - 2))) swap_p(k_c, pCur);
+          });
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
       {
-        constexpr int C0 = (NEXP * (NS - 1) / NS) / 2;
+        constexpr int C0 = cdone(NS - 1);
         static_for<NCVT - C0>([&](auto c_c) __attribute__((always_inline)) { do_cvt(std::integral_constant<int, C0 + decltype(c_c)::value>{}); });
+        if constexpr (PV16) {
+          static_for<4 * QT>([&](auto k_c) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_c)::value, need = (k / 4) * 8 + 4 + (k % 4);
+            if constexpr (!(need < cdone(NS - 2))) swap_p(k_c, pCur);
+          });
+        }
       }
     };
 
@@ -352,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
       if constexpr (!LAST) {
         // tile t+2 (requested one iteration ago) must be complete for everybody; tile t+3's two requests may stay in flight.
         // LDS reads stay in flight too: no buffer is re-used within four iterations.
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
     };
@@ -365,21 +484,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
     iteration(nt - 1, N, Y, N);
     {   // O += V(nt-1)[32..63] P(2nt-1)
       read_v((uint32_t)(((nt - 1) & (DM_RING - 1)) * DM_TILEB + DM_VOFF + DM_UNITB));
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vf[mt][h], pB[qs][h], oacc[qs][mt]);
+      static_for<NPVI>([&](auto i_c) __attribute__((always_inline)) { pv_mfma(i_c, pB); });
     }
-    float inv[QT];
-    bool bad = false;
-#pragma unroll
-    for (int qs = 0; qs < QT; ++qs) {
-      const float l_tot = __shfl(oacc[qs][1][4], l31);        // O^T row 40 = register 4 of the second tile, half 0
-      bad = bad || !(l_tot < DM_L_BAD) || !(l_tot > 0.f);
-      inv[qs] = p.out_scale / l_tot;
-    }
+    float inv[NINV];
+    const bool bad = row_sums(inv);
     if (__syncthreads_or(bad ? 1 : 0)) return false;          // (also: every wave is done with the LDS images)
     store_out(inv);
     return true;
@@ -420,10 +528,21 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
               const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
               for (int r = 0; r < 16; ++r) sc[qs][r] -= delta;
+              if constexpr (PV16) {          // the query of O block 2 qs + a, lane i16 is the score tile's lane 16 a + i16
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt)
+                for (int a = 0; a < 2; ++a) {
+                  const float alpha_o = __shfl(alpha, 16 * a + i16);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
+                  for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc16[mb][2 * qs + a][r] *= alpha_o;
+                }
+              } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) oacc[qs][mt][r] *= alpha;
+              }
               if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);
             }
           }
@@ -436,22 +555,17 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
               pf[qs][h][jj] = pack16(__builtin_amdgcn_exp2f(sc[qs][8 * h + 2 * jj]), __builtin_amdgcn_exp2f(sc[qs][8 * h + 2 * jj + 1]));
+        if constexpr (PV16) static_for<4 * QT>([&](auto k_c) __attribute__((always_inline)) { swap_p(k_c, pf); });
         read_v(tb + DM_VOFF + sub * DM_UNITB);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int qs = 0; qs < QT; ++qs) oacc[qs][mt] = mfma32(vf[mt][h], pf[qs][h], oacc[qs][mt]);
+        static_for<NPVI>([&](auto i_c) __attribute__((always_inline)) { pv_mfma(i_c, pf); });
       }
       if (t + 1 < nt) {
-        if (more) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
-    float inv[QT];
-#pragma unroll
-    for (int qs = 0; qs < QT; ++qs) inv[qs] = p.out_scale / __shfl(oacc[qs][1][4], l31);
+    float inv[NINV];
+    row_sums(inv);
     store_out(inv);
   };
 
@@ -463,26 +577,33 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm_kernel(const AttnParams 
   }
 }
 
-template <int FLAGS>
+template <int FLAGS, int QT>
 int launch_dm(int groups, hipStream_t s, const AttnParams& p) {
   static uint64_t attr_done = 0;
   if (int rc = a3d_once_per_device(attr_done, [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_dm_kernel<FLAGS>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_dm_kernel<FLAGS, QT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, DM_SMEM_BYTES); })) return rc;
   const int q_tiles = (p.q_len + 511) / 512;
-  flash_attn_dm_kernel<FLAGS><<<dim3((unsigned)(p.heads * q_tiles), (unsigned)groups), dim3(512), DM_SMEM_BYTES, s>>>(p);
+  flash_attn_dm_kernel<FLAGS, QT><<<dim3((unsigned)(p.heads * q_tiles), (unsigned)groups), dim3(1024 / QT), DM_SMEM_BYTES, s>>>(p);
   return a3d_launch_status();
 }
 
 }  // namespace
 
-// flags: see flash_attn_dm_kernel.  Shapes: head_dim 40, kv_len % 64 == 0, kv_len >= 256, aligned segments (checked by the caller).
+// flags: see flash_attn_dm_kernel; + 8 = 16 waves x 32 queries instead of 8 x 64.  Shapes: head_dim 40, kv_len % 64 == 0, kv_len >= 256,
+// aligned segments (checked by the caller).
 int A3D_FN(a3d_launch_flash_dm)(int flags, int groups, hipStream_t s, const AttnParams& p) {
   switch (flags) {
-    case 0: return launch_dm<0>(groups, s, p);
-    case 1: return launch_dm<1>(groups, s, p);
-    case 2: return launch_dm<2>(groups, s, p);
-    case 3: return launch_dm<3>(groups, s, p);
+    case 0: return launch_dm<0, 2>(groups, s, p);
+    case 1: return launch_dm<1, 2>(groups, s, p);
+    case 2: return launch_dm<2, 2>(groups, s, p);
+    case 3: return launch_dm<3, 2>(groups, s, p);
+    case 4: return launch_dm<4, 2>(groups, s, p);
+    case 5: return launch_dm<5, 2>(groups, s, p);
+    case 7: return launch_dm<7, 2>(groups, s, p);
+    case 9: return launch_dm<1, 1>(groups, s, p);
+    case 12: return launch_dm<4, 1>(groups, s, p);
+    case 13: return launch_dm<5, 1>(groups, s, p);
     default: return A3D_EINVAL;
   }
 }

@@ -46,7 +46,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         flops = 4.0 * G * S * S * C
         ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in ((0, 16, 7, 5, 0, 16) if D == 40 else ((17, 8, 0, 17, 8) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
+        for var in ((0, 19, 16, 5, 0, 19) if D == 40 else ((17, 8, 41, 17, 8, 41) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
             if ops.lib.a3d_tune_flash(var) != 0:      # ablation variants exist only in -DA3D_ABLATIONS builds
                 continue
             out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
@@ -56,7 +56,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         ops.lib.a3d_tune_flash(0)
 
 
-def bench_flashdm(ops, variants=(0, 21, 23, 20, 0, 21, 23), scales=(1.0, 0.0, 3.0)):
+def bench_flashdm(ops, variants=(19, 21, 25, 29, 33, 32, 19, 21, 25, 29, 33), scales=(1.0, 0.0, 3.0)):
     """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel
     (a3d_tune_flash(20 + flags)) against the interleaved kernel (0), interleaved rounds in one process; err vs the interleaved
     kernel's output.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
