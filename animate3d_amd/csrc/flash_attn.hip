@@ -1272,7 +1272,7 @@ extern int g_a3d_ta_pix;      // temporal_attn.hip
 #ifndef A3D_STORAGE_F16
 extern "C" int a3d_tune_flash(int variant) {
   if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
-  if (variant == 8 || variant == 17 || (variant >= 20 && variant <= 41)) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
+  if (variant == 8 || variant == 17 || (variant >= 20 && variant <= 43)) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
 #ifdef A3D_ABLATIONS
   if ((variant < 0 || variant > 7) && variant != 13 && variant != 15 && variant != 16 && variant != 19 && (variant < 1000 || variant >= 2024)) return A3D_EINVAL;
 #else
@@ -1363,6 +1363,19 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
       // long sequences (level 1 of the 512-px configurations): two query sub-tiles per wave, 32-key tiles — every K / V^T
       // fragment read feeds two MFMAs, which relieves the LDS port that bounds the one-sub-tile kernel (+4-8 %,
       // profiles/r2_microbench_flash80_ab.log); short ones keep one sub-tile per wave (more workgroups).  a3d_tune_flash(8 | 17) forces either.
+      // LDS-DMA staged kernel (flash_attn_dm80.hip): the bf16 default from 512 tokens; a3d_tune_flash(42) forces it (43: its exact pass only),
+      // 8 / 17 force the kernels below
+      {
+        const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256;
+        int dm_flags = g_flash_variant == 42 ? 1 : (g_flash_variant == 43 ? 0 : -1);
+#ifndef A3D_STORAGE_F16
+        if (g_flash_variant == 0 && kv_len >= 512 && q_len >= 512) dm_flags = 1;
+#endif
+        if (long_aligned && dm_flags >= 0) {
+          if (int rc = A3D_FN(a3d_launch_flash_dm80)(dm_flags, groups, s, p)) return rc;
+          break;
+        }
+      }
 #ifndef A3D_STORAGE_F16
       // bf16, long aligned sequences: max-free first pass with the offset in the MFMA's C operand (a3d_tune_flash(40); 41: one query sub-tile)
       if (g_flash_variant == 40 && aligned && kv_len % 32 == 0 && kv_len >= 128) { launch<80, 32, 2, OFS_ACC, 0, 1>(true, groups, s, p); break; }

@@ -41,36 +41,6 @@ constexpr int DM_SMEM_BYTES = DM_CV + DM_CV_BYTES;
 constexpr float DM_L_BAD = 1.2676506e30f;          // 2^100: beyond this the max-free result is not trusted
 constexpr float DM_BIAS = 40.f;                    // max-free offset = maximum of the first 32 scores + 40 (log2 units)
 
-// LDS-DMA: 64 lanes x 16 B, lane i -> LDS[lds_dst + 16 i]; source = scalar base + per-lane byte offset.  Not counted by the
-// compiler: s_waitcnt vmcnt by hand.
-A3D_DEV void dm_glds16(uint32_t voff, const void* sbase, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
-}
-// the same for lanes 0..15 only; the exec mask is switched inside the statement (a compiler-visible branch in a pipeline step
-// lets the optimiser sink the step's v_exp below it)
-A3D_DEV void dm_glds16_q(uint32_t voff, const void* sbase, uint32_t lds_dst) {
-  unsigned keep;
-  uint64_t ex;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
-}
-// the same under a wave-uniform lane mask (0 = this wave has no share of the tile)
-A3D_DEV void dm_glds16_m(uint32_t voff, const void* sbase, uint32_t lds_dst, uint64_t mask) {
-  unsigned keep;
-  uint64_t ex;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(mask) : "memory");
-}
-A3D_DEV const uint16_t* dm_scalar(const uint16_t* ptr) {      // wave-uniform by construction; say so
-  const uint64_t a = (uint64_t)(uintptr_t)ptr;
-  return (const uint16_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
-}
-
 extern __shared__ __attribute__((aligned(16))) uint8_t dm_smem[];
 
 A3D_DEV u32x4_t dm_lds128(uint32_t off) { return *reinterpret_cast<const u32x4_t*>(dm_smem + off); }

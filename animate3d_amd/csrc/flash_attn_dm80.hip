@@ -1,0 +1,393 @@
+// Level-1 multi-view / first-frame attention (head_dim 80, long aligned K/V): LDS-DMA staging, PV-first software pipeline, max-free
+// bf16 softmax with an exact re-run — flash_attn_dm.hip's design at head_dim 80.  Replaces xformers.ops.memory_efficient_attention at
+// attention_processor.py:405, 416, 656 for the 4 096-key level-1 shapes (38 ms of the 462 ms denoise step in round 2's kernel, which
+// was stall-bound at 0.29 of the matrix peak: one un-pipelined {QK^T, max, fma, exp, PV} sequence per tile).
+//
+//  * One workgroup = 8 waves x 32 queries (a wave's registers: O^T 3 x 16, two score tiles 2 x 16, P 2 x 8, Q^T 20, K 20, V^T 24, the
+//    offset tile 16).  64 queries per wave, the D = 40 arrangement, does not fit 256 registers at head_dim 80.
+//  * A 64-key tile is 1 280 chunks of 16 B (K 640, V 640) = 20 LDS-DMA wave-instructions: every wave issues three per tile (64 + 64 + 32
+//    lanes), so the hand-counted wait before the per-tile barrier is vmcnt(3).  Tiles are requested three ahead into a ring of 5 buffers.
+//  * Dense 160-byte rows.  40 r mod 64 repeats after 8 rows, so K chunks are stored with their position XOR (row >> 3) & 1 (applied on the
+//    DMA source address and again on the fragment address): the 16 rows of one ds_read_b128 service group then cover all 64 banks.
+//    V rows are stored with the two key quads of every 8-key group interleaved (key k of the group in row 2 (k & 3) + (k >> 2)): the four
+//    keys one ds_read_b64_tr_b16 group touches lie 2 rows = 80 dwords = 16 banks apart.  The ones "dimension" 80 of V (row sums out of the
+//    matrix pipe) and the zero rows 81..95 are read from a constant region by the lanes concerned.
+//  * The contraction has no spare slot at head_dim 80: the softmax offset enters as the C operand of the first QK^T MFMA (a 16-register
+//    tile holding -m in every element).  Max-free pass: m = exact maximum of the first 32 scores + 40, fixed; the row sum is checked once
+//    at the end and an overflowing workgroup re-runs with the lazy running maximum (see flash_attn_dm.hip for the argument).
+//  * Step j of the pipeline: O += V^T(j-1)·P(j-1) (6 MFMAs), then S(j+1) = K(j+1)·Q^T (5 MFMAs); the VALU turns S(j) into P(j) in the
+//    MFMAs' shadow (one v_exp + half a v_cvt_pk per score: 16 + 8 per step against 352 matrix-pipe cycles — this kernel is matrix-bound).
+#include "flash_common.h"
+
+namespace {
+
+constexpr int E_ROWB = 160;                        // bytes per K / V row in LDS
+constexpr int E_UNITB = 32 * E_ROWB;               // one 32-key sub-tile of K or of V
+constexpr int E_KB = 2 * E_UNITB;                  // K (or V) image of a 64-key tile
+constexpr int E_TILEB = 2 * E_KB;                  // [K keys 0..63 (chunks swizzled) | V keys 0..63 (rows permuted)]
+constexpr int E_RING = 5;
+constexpr int E_CV = E_RING * E_TILEB + 32;        // constant region: (1,0,0,0) at + {0, 160, 2560, 2720}, zero elsewhere; first bank 8 mod 16
+constexpr int E_CV_BYTES = 2752;
+constexpr int E_SMEM_BYTES = E_CV + E_CV_BYTES;
+constexpr float E_L_BAD = 1.2676506e30f;           // 2^100
+constexpr float E_BIAS = 40.f;
+
+extern __shared__ __attribute__((aligned(16))) uint8_t e_smem[];
+A3D_DEV u32x4_t e_lds128(uint32_t off) { return *reinterpret_cast<const u32x4_t*>(e_smem + off); }
+A3D_DEV u32x2_t e_ldstr(uint32_t off) { return lds_tr16_b64(reinterpret_cast<const uint16_t*>(e_smem + off)); }
+
+// FLAGS: 1 = max-free first pass (bf16 storage only)
+template <int FLAGS>
+__global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParams p) {
+  constexpr int D = 80, KS = 5, MT = 3, NT = 512, BQ = 256;
+  constexpr int NEXP = 16, NCVT = 8, NDMA = 3;
+#ifdef A3D_STORAGE_F16
+  constexpr bool TRY_NOMAX = false;
+#else
+  constexpr bool TRY_NOMAX = (FLAGS & 1) != 0;
+#endif
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(wid);
+  const int l31 = lane & 31, g = lane >> 5, i16 = lane & 15, q4 = lane >> 4;
+  const int head = blockIdx.x % p.heads;
+  const int qt = blockIdx.x / p.heads;
+  const int64_t grp = blockIdx.y;
+  const int64_t hoff = (int64_t)head * D;
+  const uint32_t lds0 = fa_lds_addr(e_smem);
+
+  for (int i = tid; i < E_CV_BYTES / 2; i += NT) {
+    const int vb = 2 * i;
+    reinterpret_cast<uint16_t*>(e_smem + E_CV)[i] = (vb == 0 || vb == 160 || vb == 2560 || vb == 2720) ? ONE16 : (uint16_t)0;
+  }
+
+  // ---- Q^T fragments (pre-scaled by scale * log2 e)
+  const int q_idx = qt * BQ + wid * 32 + l31;
+  u32x4_t qf[KS];
+  {
+    const int64_t q_row = map_row(p.qm, grp, q_idx < p.q_len ? q_idx : p.q_len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4_t wq = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + 16 * ks + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wq[j] = pack16(lo16(wq[j]) * p.scale_log2, hi16(wq[j]) * p.scale_log2);
+      qf[ks] = wq;
+    }
+  }
+
+  // ---- DMA lanes.  Chunk slot s of a tile buffer (16 B at byte 16 s): s < 640 is K row s / 10, position s % 10 = chunk ^ ((row >> 3) & 1);
+  // s >= 640 is V physical row (s - 640) / 10, chunk (s - 640) % 10; physical row r holds key (r & ~7) | ((r & 7) >> 1) + 4 (r & 1).
+  // Wave w issues slots 64 w .. (A: K), 512 + 64 w .. (B: K for w < 2, V otherwise), 1024 + 32 w .. + 31 (C, 32 lanes: V).
+  const int64_t ld = p.km.ld;
+  const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
+  const uint32_t seg_len = (uint32_t)p.km.seg_len;
+  const int64_t tile_step = (int64_t)64 * ld;
+  const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;
+  auto slot_src = [&](int slot) -> uint32_t {
+    const bool isk = slot < 640;
+    const int s2 = isk ? slot : slot - 640;
+    const int prow = s2 / 10, cpos = s2 % 10;
+    const int c = isk ? (cpos ^ ((prow >> 3) & 1)) : cpos;
+    const int key = isk ? prow : ((prow & ~7) | (((prow & 7) >> 1) + 4 * (prow & 1)));
+    return (uint32_t)(((int64_t)key * ld + c * 8) * 2);
+  };
+  const uint32_t voffA = slot_src(64 * w + lane);
+  const uint32_t voffB = slot_src(512 + 64 * w + lane);
+  const uint32_t voffC = slot_src(1024 + 32 * w + l31);
+
+  // ---- fragment addressing (byte offsets into e_smem; the tile / sub-tile offset is added per step, times 0 for constant lanes)
+  const int krow = kperm(l31);
+  const uint32_t klane = (uint32_t)(krow * E_ROWB + 16 * (g ^ ((krow >> 3) & 1)));           // + 32 ks
+  const int c4 = i16 & 3;
+  const uint32_t vrow = (uint32_t)((8 * (q4 >> 1) + 2 * (i16 >> 2)) * E_ROWB);
+  const uint32_t vlane01 = vrow + (uint32_t)(2 * (16 * (q4 & 1) + 4 * c4));                   // O^T rows 0..63: + 64 mt
+  const bool v2_data = (q4 & 1) == 0;                                                        // O^T rows 64..95: dims 64..79 | ones | zeros
+  const uint32_t vlane2 = v2_data ? vrow + (uint32_t)(2 * (64 + 4 * c4)) : (c4 == 0 ? (uint32_t)E_CV : (uint32_t)(E_CV + 8));
+  uint32_t vmul = v2_data ? 1u : 0u;
+  asm volatile("" : "+v"(vmul));
+
+  const uint16_t* gA = nullptr;
+  const uint16_t* gB = nullptr;
+  const uint16_t* gC = nullptr;
+  uint32_t seg_off = 0;
+  auto dma_reset = [&]() __attribute__((always_inline)) {
+    gA = dm_scalar(p.K + hoff + kgbase * ld);
+    gB = dm_scalar((w < 2 ? p.K : p.V) + hoff + kgbase * ld);
+    gC = dm_scalar(p.V + hoff + kgbase * ld);
+    seg_off = 0;
+  };
+  auto tile_base = [&](int tile) __attribute__((always_inline)) -> uint32_t { return (uint32_t)((tile % E_RING) * E_TILEB); };
+  auto dma_a = [&](int tile) __attribute__((always_inline)) { dm_glds16(voffA, gA, lds0 + tile_base(tile) + 1024 * w); };
+  auto dma_b = [&](int tile) __attribute__((always_inline)) { dm_glds16(voffB, gB, lds0 + tile_base(tile) + 8192 + 1024 * w); };
+  auto dma_c = [&](int tile) __attribute__((always_inline)) {       // third instruction of a tile; then the bases move on
+    dm_glds16_m(voffC, gC, lds0 + tile_base(tile) + 16384 + 512 * w, 0xffffffffull);
+    seg_off += 64;
+    int64_t stp = tile_step;
+    if (seg_off >= seg_len) { stp += wrap_step; seg_off = 0; }
+    gA += stp; gB += stp; gC += stp;
+  };
+
+  f32x16_t oacc[MT];
+  f32x16_t minit;             // -offset in every element: C operand of the first QK^T MFMA
+  u32x4_t kf[KS];
+  u32x4_t vf[MT][2];
+  auto read_k = [&](uint32_t koff) __attribute__((always_inline)) {
+    const uint32_t a = klane + koff;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = e_lds128(a + 32 * ks);
+  };
+  auto read_vhalf = [&](auto i_c, uint32_t a01, uint32_t a2) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value, h = i / 6, mt = (i / 2) % 3, rr = i % 2;      // key-half major, as the MFMAs consume them
+    const u32x2_t t = e_ldstr((mt == 2 ? a2 : a01 + 64 * mt) + (16 * h + rr) * E_ROWB);
+    vf[mt][h][2 * rr] = t[0];
+    vf[mt][h][2 * rr + 1] = t[1];
+  };
+  auto read_v = [&](uint32_t voff) __attribute__((always_inline)) {
+    const uint32_t a01 = vlane01 + voff, a2 = __umul24(vmul, voff) + vlane2;
+    static_for<12>([&](auto i_c) __attribute__((always_inline)) { read_vhalf(i_c, a01, a2); });
+  };
+  auto pv_mfma = [&](auto i_c, u32x4_t (&P)[2]) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value, h = i / 3, mt = i % 3;       // the two MFMAs of one accumulator are three issues apart
+    oacc[mt] = mfma32(vf[mt][h], P[h], oacc[mt]);
+  };
+  auto clear_o = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[mt][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  };
+  const int nt = p.kv_len / 64;               // launcher guarantees kv_len % 64 == 0, nt >= 4, aligned segments
+  auto prologue_dma = [&]() __attribute__((always_inline)) {      // tiles 0, 1, 2 requested; 0 and 1 complete
+    dma_reset();
+    dma_a(0); dma_b(0); dma_c(0);
+    dma_a(1); dma_b(1); dma_c(1);
+    dma_a(2); dma_b(2); dma_c(2);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
+  };
+  // first offset: exact maximum of the query's first 32 scores (+ bias); leaves the re-based scores in s
+  auto first_scores = [&](f32x16_t& s, float& m_off, float bias) __attribute__((always_inline)) {
+    read_k(0u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(kf[ks], qf[ks], s);
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    m_off = mx + bias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] -= m_off; minit[r] = -m_off; }
+  };
+  auto finish = [&](bool check) __attribute__((always_inline)) -> bool {      // row sums (O^T row 80 = register 8 of tile 2, half 0), stores
+    const float l_tot = __shfl(oacc[2][8], l31);
+    const bool bad = !(l_tot < E_L_BAD) || !(l_tot > 0.f);
+    if (check) {
+      if (__syncthreads_or(bad ? 1 : 0)) return false;          // (also: every wave is done with the LDS images)
+    }
+    const float inv = p.out_scale / l_tot;
+    if (q_idx < p.q_len) {      // lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j]
+      uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d = 32 * mt + 8 * qd + 4 * g;
+          if (d < D) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = oacc[mt][4 * qd + j] * inv;
+            if (p.accumulate) {
+              const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
+              v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
+            }
+            u32x2_t o;
+            o[0] = pack16(v[0], v[1]);
+            o[1] = pack16(v[2], v[3]);
+            *reinterpret_cast<u32x2_t*>(orow + d) = o;
+          }
+        }
+    }
+    return true;
+  };
+
+  // ================================================================================================================
+  // Max-free pass: branch-free software pipeline
+  // ================================================================================================================
+  auto run_fast = [&]() __attribute__((always_inline)) -> bool {
+    clear_o();
+    f32x16_t sA, sB;
+    u32x4_t pA[2], pB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { pA[h] = u32x4_t{0u, 0u, 0u, 0u}; pB[h] = u32x4_t{0u, 0u, 0u, 0u}; }
+
+    // step j: kOff / vOff = LDS byte offsets of K sub-tile j+1 and V sub-tile j
+    auto step = [&](auto do_qk_c, auto do_pv_c, f32x16_t& sCur, f32x16_t& sNext, u32x4_t (&pCur)[2], u32x4_t (&pPrev)[2],
+                    uint32_t kOff, uint32_t vOff, auto&& hook) __attribute__((always_inline)) {
+      constexpr bool DO_QK = decltype(do_qk_c)::value, DO_PV = decltype(do_pv_c)::value;
+      constexpr int NPV = DO_PV ? 2 * MT : 0, NQK = DO_QK ? KS : 0, NS = NPV + NQK;
+      constexpr int KSLOT = 2, VS0 = NPV + 1, VPS = 3;
+      const uint32_t va01 = vlane01 + vOff, va2 = __umul24(vmul, vOff) + vlane2;
+      float e[NEXP];
+      auto do_cvt = [&](auto c_c) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_c)::value, h = c / 4, jj = c % 4;
+        pCur[h][jj] = pack16(e[2 * c], e[2 * c + 1]);
+      };
+      auto cdone = [](int s) constexpr { return s < 0 ? 0 : (NEXP * s / NS) / 2; };
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NS>([&](auto s_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value;
+        if constexpr (s < NPV) {
+          pv_mfma(s_c, pPrev);
+        } else {
+          constexpr int ks = s - NPV;
+          if constexpr (ks == 0) sNext = mfma32(kf[0], qf[0], minit);
+          else sNext = mfma32(kf[ks], qf[ks], sNext);
+        }
+        if constexpr (DO_QK && DO_PV && s == KSLOT) read_k(kOff);
+        if constexpr (DO_QK && s >= VS0 && VPS * (s - VS0) < 12) {
+          static_for<VPS>([&](auto i_c) __attribute__((always_inline)) {
+            constexpr int i = VPS * (s - VS0) + decltype(i_c)::value;
+            if constexpr (i < 12) read_vhalf(std::integral_constant<int, i>{}, va01, va2);
+          });
+        }
+        hook(s_c);
+        constexpr int E0 = NEXP * s / NS, E1 = NEXP * (s + 1) / NS;
+        static_for<E1 - E0>([&](auto x_c) __attribute__((always_inline)) {
+          constexpr int x = E0 + decltype(x_c)::value;
+          e[x] = __builtin_amdgcn_exp2f(sCur[x]);
+        });
+        constexpr int C0 = cdone(s - 1), C1 = cdone(s);
+        static_for<C1 - C0>([&](auto c_c) __attribute__((always_inline)) { do_cvt(std::integral_constant<int, C0 + decltype(c_c)::value>{}); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      {
+        constexpr int C0 = cdone(NS - 1);
+        static_for<NCVT - C0>([&](auto c_c) __attribute__((always_inline)) { do_cvt(std::integral_constant<int, C0 + decltype(c_c)::value>{}); });
+      }
+    };
+
+    prologue_dma();
+    {
+      float m_off;
+      first_scores(sA, m_off, E_BIAS);
+      read_k((uint32_t)E_UNITB);               // K(0) keys 32..63 for step 0
+    }
+
+    auto iteration = [&](int t, auto first_c, auto last_c, auto dma_c_) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value, DMA = decltype(dma_c_)::value;
+      auto even_hook = [&](auto s_c) __attribute__((always_inline)) {
+        if constexpr (DMA && decltype(s_c)::value == 1) dma_a(t + 3);
+      };
+      auto odd_hook = [&](auto s_c) __attribute__((always_inline)) {
+        if constexpr (DMA && decltype(s_c)::value == 1) dma_b(t + 3);
+        if constexpr (DMA && decltype(s_c)::value == 4) dma_c(t + 3);
+      };
+      const uint32_t tb = tile_base(t), tn = tile_base(t + 1);
+      // even step j = 2t:  O += V(t-1)[32..63] P(2t-1), S(2t+1) from K(t) keys 32..63, P(2t) from S(2t); reads V(t)[0..31]
+      step(std::true_type{}, std::integral_constant<bool, !FIRST>{}, sA, sB, pA, pB, tb + E_UNITB, tb + E_KB, even_hook);
+      // odd step j = 2t+1: O += V(t)[0..31] P(2t), S(2t+2) from K(t+1) keys 0..31, P(2t+1) from S(2t+1); reads V(t)[32..63]
+      step(std::integral_constant<bool, !LAST>{}, std::true_type{}, sB, sA, pB, pA, tn, tb + E_KB + E_UNITB, odd_hook);
+      if constexpr (!LAST) {
+        // tile t+2 (requested one iteration ago) complete for everybody; tile t+3's requests may stay in flight
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    iteration(0, Y, N, Y);
+    for (int t = 1; t < nt - 3; ++t) iteration(t, N, N, Y);
+    iteration(nt - 3, N, N, N);
+    iteration(nt - 2, N, N, N);
+    iteration(nt - 1, N, Y, N);
+    {   // O += V(nt-1)[32..63] P(2nt-1)
+      read_v(tile_base(nt - 1) + E_KB + E_UNITB);
+      static_for<2 * MT>([&](auto i_c) __attribute__((always_inline)) { pv_mfma(i_c, pB); });
+    }
+    return finish(true);
+  };
+
+  // ================================================================================================================
+  // Exact pass: lazy running maximum per 32-key sub-tile, un-pipelined (after an overflow of the max-free pass, or always)
+  // ================================================================================================================
+  auto run_exact = [&]() __attribute__((always_inline)) {
+    clear_o();
+    float m_off;
+    f32x16_t sc;
+    prologue_dma();
+    first_scores(sc, m_off, 0.f);
+    for (int t = 0; t < nt; ++t) {
+      const bool more = t + 3 < nt;
+      if (more) { dma_a(t + 3); dma_b(t + 3); dma_c(t + 3); }
+      const uint32_t tb = tile_base(t);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if (t > 0 || sub > 0) {
+          read_k(tb + sub * E_UNITB);
+          sc = minit;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) sc = mfma32(kf[ks], qf[ks], sc);
+          float mx = sc[0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+          if (__any(mx > LAZY_THR)) {
+            const float delta = fmaxf(fmaxf(mx, __shfl_xor(mx, 32)), 0.f);
+            m_off += delta;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] -= delta; minit[r] = -m_off; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) oacc[mt][r] *= alpha;
+          }
+        }
+        u32x4_t pf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            pf[h][jj] = pack16(__builtin_amdgcn_exp2f(sc[8 * h + 2 * jj]), __builtin_amdgcn_exp2f(sc[8 * h + 2 * jj + 1]));
+        read_v(tb + E_KB + sub * E_UNITB);
+        static_for<2 * MT>([&](auto i_c) __attribute__((always_inline)) { pv_mfma(i_c, pf); });
+      }
+      if (t + 1 < nt) {
+        if (more) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    finish(false);
+  };
+
+  __syncthreads();        // constant region written
+  if constexpr (TRY_NOMAX) {
+    if (!run_fast()) run_exact();
+  } else {
+    run_exact();
+  }
+}
+
+template <int FLAGS>
+int launch_dm80(int groups, hipStream_t s, const AttnParams& p) {
+  static uint64_t attr_done = 0;
+  if (int rc = a3d_once_per_device(attr_done, [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_dm80_kernel<FLAGS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, E_SMEM_BYTES); })) return rc;
+  const int q_tiles = (p.q_len + 255) / 256;
+  flash_attn_dm80_kernel<FLAGS><<<dim3((unsigned)(p.heads * q_tiles), (unsigned)groups), dim3(512), E_SMEM_BYTES, s>>>(p);
+  return a3d_launch_status();
+}
+
+}  // namespace
+
+// flags: 0 = exact pass only, 1 = max-free first pass.  Shapes: head_dim 80, kv_len % 64 == 0, kv_len >= 256, aligned segments.
+int A3D_FN(a3d_launch_flash_dm80)(int flags, int groups, hipStream_t s, const AttnParams& p) {
+  switch (flags) {
+    case 0: return launch_dm80<0>(groups, s, p);
+    case 1: return launch_dm80<1>(groups, s, p);
+    default: return A3D_EINVAL;
+  }
+}

@@ -351,7 +351,7 @@ def test_flash_attn_d80_kernel_variants(ops, ref):
                 k[900] = q[13] * 20.0
             qm, k0 = _mv_maps(n, F, L)
             want = ref.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L)
-            for var in (0, 8, 17, 40, 41):
+            for var in (0, 8, 17, 40, 41, 42, 43):
                 assert ops.lib.a3d_tune_flash(var) == 0
                 check(f"D80 n{n} L{L} spike{spike} kernel variant {var}", ops.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L), want,
                       tol=4e-3 if spike < 2 else 1e-2)

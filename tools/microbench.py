@@ -46,7 +46,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         flops = 4.0 * G * S * S * C
         ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in ((0, 19, 16, 5, 0, 19) if D == 40 else ((17, 8, 41, 17, 8, 41) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
+        for var in ((0, 19, 16, 5, 0, 19) if D == 40 else ((17, 8, 42, 43, 17, 8, 42) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
             if ops.lib.a3d_tune_flash(var) != 0:      # ablation variants exist only in -DA3D_ABLATIONS builds
                 continue
             out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
