@@ -38,6 +38,7 @@ class _Gemm(torch.autograd.Function):
     def forward(ctx, aops, x, w, bias, residual, rowbias, alpha_t, alpha, beta, rb_div):
         base = aops.base
         ctx.aops, ctx.alpha, ctx.beta = aops, alpha, beta
+        ctx.has_rowbias = rowbias is not None
         ctx.save_for_backward(x, w, bias)
         return base.gemm(x, w, bias, residual=residual, alpha=alpha, beta=beta, rowbias=rowbias, rb_div=rb_div)
 
@@ -48,6 +49,8 @@ class _Gemm(torch.autograd.Function):
         need = ctx.needs_input_grad
         if need[5]:
             raise NotImplementedError("gradient of a GEMM row-bias (time-embedding projection) is not part of the training path")
+        if need[6] and ctx.has_rowbias:
+            raise NotImplementedError("gradient of a tensor merge weight on a GEMM that also carries a row-bias (d alpha would need the row-bias term)")
         dx = dw = db = dres = dalpha = None
         if need[1]:
             dx = base.gemm(dy, aops.transposed_weight(w), alpha=ctx.alpha)
@@ -263,6 +266,8 @@ class AutogradOps:
     def __init__(self, base):
         self.base = base
         self._persistent = {}       # data_ptr -> (weight, derived operand): frozen weights of the persistent pack only
+
+    flash_attn2 = None       # no differentiable fused text + image-token attention: the UNet issues the two differentiable calls
 
     def __getattr__(self, name):
         return getattr(self.base, name)

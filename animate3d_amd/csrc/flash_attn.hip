@@ -51,7 +51,9 @@ namespace {
 // maximum of the first tile + 40 and never moves (bf16 P has fp32's exponent range; fp32 accumulation), so the per-score VALU work is
 // one v_exp and half a v_cvt_pk; the row sums out of the matrix pipe are checked once at the end and a workgroup whose sums
 // left [0, 2^100) re-runs with the exact lazy running maximum (flash_attn_dm.hip has the long form of the argument).
-template <int D, int BKV, int QT, int OFS, bool ALIGNED, int VAR, int NM = 0>
+// TWO: a second key set (p.K2 / V2 / km2 / kv_len2 / out_scale2) is attended to after the first, with its own softmax; the first
+// result waits in registers and one sum is stored (IPAdapter processor: text tokens + image tokens, attention_processor.py:233, 268-283).
+template <int D, int BKV, int QT, int OFS, bool ALIGNED, int VAR, int NM = 0, bool TWO = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) {
   constexpr int NU = BKV / 32;             // 32-key sub-tiles per KV tile
   constexpr int VROW = BKV + 8;            // V^T image row stride (elements): odd number of 16-B slots
@@ -126,21 +128,28 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 #endif
   static_assert(NM == 0 || (OFS != OFS_FMA && ALIGNED && ONES), "the max-free pass needs the offset inside the matrix pipe and MFMA row sums");
   // One complete pass over the keys; returns false when the max-free result must be discarded.
-  auto pass = [&](auto nm_c) __attribute__((always_inline)) -> bool {
+  f32x16_t osave[TWO ? QT : 1][TWO ? MT : 1];      // normalised result of the first key set
+  auto pass = [&](auto nm_c, auto set_c) __attribute__((always_inline)) -> bool {
   constexpr bool NOMAX = decltype(nm_c)::value;
+  constexpr bool SET1 = decltype(set_c)::value;       // this pass reads the second key set
+  const uint16_t* const Kp = SET1 ? p.K2 : p.K;
+  const uint16_t* const Vp = SET1 ? p.V2 : p.V;
+  const a3d_rowmap& kmp = SET1 ? p.km2 : p.km;
+  const int kvl = SET1 ? p.kv_len2 : p.kv_len;
+  const float oscale = SET1 ? p.out_scale2 : p.out_scale;
   if constexpr (OFS == OFS_PAD) {
 #pragma unroll
     for (int qs = 0; qs < QT; ++qs)
       if (g == G_PAD) qf[qs][KS_PAD][0] = 0u;
   }
   // ---- K/V staging: per-thread source pointers, advanced tile by tile
-  const int64_t ld = p.km.ld;
-  const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
-  const uint16_t* const Kh = p.K + hoff;
-  const uint16_t* const Vh = p.V + hoff;
-  const uint32_t seg_len = (uint32_t)p.km.seg_len;
+  const int64_t ld = kmp.ld;
+  const int64_t kgbase = (grp / kmp.gdiv) * kmp.ga + (grp % kmp.gdiv) * kmp.gb;
+  const uint16_t* const Kh = Kp + hoff;
+  const uint16_t* const Vh = Vp + hoff;
+  const uint32_t seg_len = (uint32_t)kmp.seg_len;
   const int64_t tile_step = (int64_t)BKV * ld;                                  // elements per tile
-  const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;             // extra jump at a segment end
+  const int64_t wrap_step = (kmp.seg_stride - kmp.seg_len) * ld;             // extra jump at a segment end
   int kr[KPT], kc[KPT], vq[VPT], vc[VPT];
   const uint16_t* kptr[KPT];
   const uint16_t* vptr[VPT];
@@ -160,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   int next_kv0 = 0;         // first key of the next tile to load
 
   auto row_generic = [&](int s) -> int64_t {      // clamp + 32-bit div/mod (generic path, tails)
-    if (s >= p.kv_len) s = p.kv_len - 1;
+    if (s >= kvl) s = kvl - 1;
     const uint32_t seg = (uint32_t)s / seg_len;
-    return kgbase + (int64_t)seg * p.km.seg_stride + ((uint32_t)s - seg * seg_len);
+    return kgbase + (int64_t)seg * kmp.seg_stride + ((uint32_t)s - seg * seg_len);
   };
 
   u32x4_t kreg[KPT];
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) >= p.kv_len) {
+          if (kv0 + 32 * u + 16 * (r >> 3) + 8 * g + (r & 7) >= kvl) {
 #pragma unroll
             for (int qs = 0; qs < QT; ++qs) sacc[qs][u][r] = -INFINITY;
           }
@@ -432,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     }
   };
 
-  const int ntiles = (p.kv_len + BKV - 1) / BKV;
-  const bool has_tail = (p.kv_len % BKV) != 0;
+  const int ntiles = (kvl + BKV - 1) / BKV;
+  const bool has_tail = (kvl % BKV) != 0;
   auto load_tile = [&](int t) {     // t = index of the tile being requested
     if (has_tail && t == ntiles - 1) load_kv(std::true_type{}); else load_kv(std::false_type{});
   };
@@ -484,10 +493,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
       l_tot = l_run + __shfl_xor(l_run, 32);
     }
     bad = bad || !(l_tot < 1.2676506e30f) || !(l_tot > 0.f);
-    inv[qs] = p.out_scale / l_tot;
+    inv[qs] = oscale / l_tot;
   }
   if constexpr (NOMAX) {
     if (__syncthreads_or(bad ? 1 : 0)) return false;       // (every wave is also done with the LDS images)
+  }
+  if constexpr (TWO && !SET1) {
+    if (p.K2 != nullptr) {                                 // first key set of two: keep the normalised result in registers
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) osave[qs][mt][r] = oacc[qs][mt][r] * inv[qs];
+      return true;
+    }
   }
 #pragma unroll
   for (int qs = 0; qs < QT; ++qs) {
@@ -501,7 +521,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
           if (d < D) {
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = oacc[qs][mt][4 * qd + j] * inv[qs];
+            for (int j = 0; j < 4; ++j) {
+              v[j] = oacc[qs][mt][4 * qd + j] * inv[qs];
+              if constexpr (TWO && SET1) v[j] += osave[qs][mt][4 * qd + j];
+            }
             if (p.accumulate) {
               const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
               v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
@@ -518,9 +541,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   };    // pass
 
   if constexpr (TRY_NOMAX) {
-    if (!pass(std::true_type{})) pass(std::false_type{});
+    if (!pass(std::true_type{}, std::false_type{})) pass(std::false_type{}, std::false_type{});
   } else {
-    pass(std::false_type{});
+    pass(std::false_type{}, std::false_type{});
+  }
+  if constexpr (TWO) {
+    if (p.K2 != nullptr) {
+      __syncthreads();                                     // the LDS images are re-used
+      pass(std::false_type{}, std::true_type{});
+    }
   }
 }
 
@@ -1265,6 +1294,14 @@ void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
   else flash_attn_kernel<D, BKV, QT, OFS, false, 0><<<grid, dim3(256), 0, s>>>(p);
 }
 
+template <int D, int BKV, int OFS>
+void launch_two(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
+  const int q_tiles = (p.q_len + 127) / 128;
+  const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
+  if (aligned) flash_attn_kernel<D, BKV, 1, OFS, true, 0, 0, true><<<grid, dim3(256), 0, s>>>(p);
+  else flash_attn_kernel<D, BKV, 1, OFS, false, 0, 0, true><<<grid, dim3(256), 0, s>>>(p);
+}
+
 }  // namespace
 
 extern int g_a3d_ta_pix;      // temporal_attn.hip
@@ -1322,7 +1359,7 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
       // pass + P·V through the 16x16x32 MFMA); a3d_tune_flash(20 + flags) forces a flag set, 19 forces the interleaved kernel below.
       // fp16 storage keeps the interleaved kernel (the max-free pass needs bf16's exponent range; forced flag sets run the exact pass).
       {
-        const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512;
+        const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 256;      // (a workgroup covers 512 queries)
         int dm_flags = (g_flash_variant >= 20 && g_flash_variant <= 35) ? g_flash_variant - 20 : -1;
 #ifndef A3D_STORAGE_F16
         if (g_flash_variant == 0) dm_flags = 5;
@@ -1369,7 +1406,7 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
         const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256;
         int dm_flags = g_flash_variant == 42 ? 1 : (g_flash_variant == 43 ? 0 : -1);
 #ifndef A3D_STORAGE_F16
-        if (g_flash_variant == 0 && kv_len >= 512 && q_len >= 512) dm_flags = 1;
+        if (g_flash_variant == 0 && kv_len >= 512 && q_len >= 256) dm_flags = 1;
 #endif
         if (long_aligned && dm_flags >= 0) {
           if (int rc = A3D_FN(a3d_launch_flash_dm80)(dm_flags, groups, s, p)) return rc;
@@ -1388,5 +1425,33 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
     case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;
     default: return A3D_EUNSUPPORTED;
   }
+  return a3d_launch_status();
+}
+
+// Two key sets in one launch: O = out_scale * softmax(Q K^T * scale) V + out_scale2 * softmax(Q K2^T * scale) V2 (+ previous O if
+// accumulate).  Replaces the text attention + per-adapter image-token attention + `hidden += scale * ip` sequence of the IPAdapter
+// processor (attention_processor.py:233, 254-283) by one pass over Q and O.  head_dim 40 / 80 (others: A3D_EUNSUPPORTED, call twice).
+extern "C" int A3D_FN(a3d_flash_attn2)(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* K2, const void* V2, void* O,
+                                    const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* kmap2, const a3d_rowmap* omap,
+                                    int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int64_t kv_len2,
+                                    float scale, float out_scale, float out_scale2, int accumulate) {
+  if (!Q || !K || !V || !K2 || !V2 || !O || groups <= 0 || heads <= 0 || q_len <= 0 || kv_len <= 0 || kv_len2 <= 0) return A3D_EINVAL;
+  if (!map_ok(qmap, head_dim) || !map_ok(kmap, head_dim) || !map_ok(kmap2, head_dim) || !map_ok(omap, head_dim)) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(K2) |
+       reinterpret_cast<uintptr_t>(V2)) & 15u) return A3D_EINVAL;
+  if (reinterpret_cast<uintptr_t>(O) & 7u) return A3D_EINVAL;
+  if (groups > 65535 || q_len > 0x3fffffffLL || kv_len > 0x3fffffffLL || kv_len2 > 0x3fffffffLL || kmap->seg_len > 0x3fffffffLL ||
+      kmap2->seg_len > 0x3fffffffLL) return A3D_EINVAL;
+  if (head_dim != 40 && head_dim != 80) return A3D_EUNSUPPORTED;
+  AttnParams p{};
+  p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.O = (uint16_t*)O;
+  p.K2 = (const uint16_t*)K2; p.V2 = (const uint16_t*)V2;
+  p.qm = *qmap; p.km = *kmap; p.km2 = *kmap2; p.om = *omap;
+  p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len; p.kv_len2 = (int)kv_len2;
+  p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.out_scale2 = out_scale2; p.accumulate = accumulate & 1; p.causal = 0;
+  const bool aligned = ((kmap->seg_len % 64 == 0) || (kv_len <= kmap->seg_len)) && ((kmap2->seg_len % 64 == 0) || (kv_len2 <= kmap2->seg_len));
+  hipStream_t s = (hipStream_t)stream;
+  if (head_dim == 40) launch_two<40, 64, OFS_PAD>(aligned, groups, s, p);
+  else launch_two<80, 64, OFS_ACC>(aligned, groups, s, p);
   return a3d_launch_status();
 }

@@ -441,6 +441,9 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
       if constexpr (!LAST) {
         // tile t+2 (requested one iteration ago) must be complete for everybody; tile t+3's two requests may stay in flight.
         // LDS reads stay in flight too: no buffer is re-used within four iterations.
+#ifdef A3D_ABLATIONS
+        if constexpr ((FLAGS & 16) != 0) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NDMA) : "memory"); } else      // timing ablation: no barrier (results may be wrong)
+#endif
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
@@ -574,6 +577,10 @@ int A3D_FN(a3d_launch_flash_dm)(int flags, int groups, hipStream_t s, const Attn
     case 9: return launch_dm<1, 1>(groups, s, p);
     case 12: return launch_dm<4, 1>(groups, s, p);
     case 13: return launch_dm<5, 1>(groups, s, p);
+#ifdef A3D_ABLATIONS
+    case 14: return launch_dm<5 + 16, 2>(groups, s, p);      // no per-tile barrier
+    case 15: return launch_dm<1 + 16, 2>(groups, s, p);
+#endif
     default: return A3D_EINVAL;
   }
 }

@@ -12,6 +12,9 @@ struct AttnParams {
   int heads; int q_len, kv_len;
   float scale_log2, out_scale; int accumulate;
   int causal;      // key s may only be seen by queries >= s of the same group (CLIP text tower); generic kernel only
+  // second key set (a3d_flash_attn2: text tokens + IP-Adapter image tokens in one launch): O = out_scale * attn(Q, K, V) +
+  // out_scale2 * attn(Q, K2, V2), each with its own softmax.  K2 == nullptr: single key set.
+  const uint16_t* K2; const uint16_t* V2; a3d_rowmap km2; int kv_len2; float out_scale2;
 };
 
 namespace {

@@ -21,6 +21,7 @@ extern int g_conv_chunk_major;
 extern int g_gemm_vm_counted;
 extern int g_gemm_persist;
 extern int g_gemm_bk;
+extern int g_gemm_reserved_cus;
 #else
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
                               // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
@@ -32,6 +33,8 @@ int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a til
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
 int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
+int g_gemm_reserved_cus = 0;   // a3d_tune_gemm(200 + k): the persistent grid leaves k CUs free (set by the sharded path while an RCCL
+                               // all-gather is in flight: its kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
 #endif
 
 namespace {
@@ -823,7 +826,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
     cus_of[dev] = n > 0 ? n : 256;
   }
-  const int cus = cus_of[dev];
+  const int cus = cus_of[dev] - g_gemm_reserved_cus > 32 ? cus_of[dev] - g_gemm_reserved_cus : 32;
   if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return -1000;
   const int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
   if (nb == 0) return -1000;
@@ -966,6 +969,7 @@ extern "C" int a3d_tune_gemm(int bk) {
 #ifdef A3D_EXP_CHUNK_MAJOR
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
 #endif
+  if (bk >= 200 && bk <= 264) { g_gemm_reserved_cus = bk - 200; return A3D_OK; }
   if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                     c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
+    "a3d_flash_attn2_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
+                                     ctypes.POINTER(_RowMapC), c_int, c_int, c_int, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32, c_int]),
     "a3d_tune_flash": (c_int, [c_int]),
     "a3d_tune_gemm": (c_int, [c_int]),
     "a3d_temporal_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
@@ -263,6 +265,23 @@ class HipOps:
         rc = self.lib.a3d_flash_attn_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
                                           groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, (1 if accumulate else 0) | (2 if causal else 0))
         _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
+        return o
+
+    def flash_attn2(self, q, k, v, k2, v2, qmap: RowMap, kmap: RowMap, kmap2: RowMap, groups: int, heads: int, q_len: int, kv_len: int,
+                    kv_len2: int, *, out_scale2: float = 1.0):
+        """attn(q, k, v) + out_scale2 * attn(q, k2, v2) in one launch (each key set with its own softmax); None when the head
+        dimension has no fused kernel (the caller then issues two ``flash_attn`` calls)."""
+        D = q.shape[1] // heads
+        if D not in (40, 80):
+            return None
+        q, k, v, k2, v2 = self._act(q, "attn.q"), self._act(k, "attn.k"), self._act(v, "attn.v"), self._act(k2, "attn.k2"), self._act(v2, "attn.v2")
+        assert k.stride(0) == v.stride(0) and k2.stride(0) == v2.stride(0)
+        o = self.empty(q.shape[0], q.shape[1])
+        qm, km, km2, om = qmap.c(q.stride(0)), kmap.c(k.stride(0)), kmap2.c(k2.stride(0)), qmap.c(o.stride(0))
+        rc = self.lib.a3d_flash_attn2_bf16(self._stream(), _p(q), _p(k), _p(v), _p(k2), _p(v2), _p(o), ctypes.byref(qm), ctypes.byref(km),
+                                           ctypes.byref(km2), ctypes.byref(om), groups, heads, D, q_len, kv_len, kv_len2, float(D) ** -0.5,
+                                           1.0, out_scale2, 0)
+        _check(rc, f"a3d_flash_attn2_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len} kv_len2={kv_len2}")
         return o
 
     def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int, *, q_f0: int = 0, q_frames: Optional[int] = None):

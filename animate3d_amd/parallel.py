@@ -56,6 +56,11 @@ class ShardPlan:
         self.gather_bytes = 0            # bytes received by this rank in data-path collectives (telemetry)
         self.collectives = 0
         self.gather_tokens = True        # all-gather the attention's input tokens (C wide) instead of projected K|V (2C wide)
+        # while a gather is in flight the persistent GEMM / conv kernels (one workgroup per CU) leave this many CUs to the
+        # collective's own kernels; ``cu_knob`` = the C-ABI's a3d_tune_gemm (set by shard_unet on the HIP op set, None on CPU)
+        self.reserve_cus = 16
+        self.cu_knob = None
+        self._in_flight = 0
 
     # ---- layout: world = cfg_shards x view_shards x frame_shards
     @staticmethod
@@ -120,6 +125,12 @@ class ShardPlan:
         self.gather_bytes += int(received_bytes)
         self.collectives += 1
 
+    def _overlap(self, delta: int):
+        """Book-keeping of asynchronous collectives in flight: the first one reserves CUs for RCCL, the last one to finish frees them."""
+        before, self._in_flight = self._in_flight, max(0, self._in_flight + delta)
+        if self.cu_knob is not None and self.reserve_cus > 0 and (before == 0) != (self._in_flight == 0):
+            self.cu_knob(200 + (self.reserve_cus if self._in_flight else 0))
+
     # ---- view axis
     def all_gather_views_start(self, kv: torch.Tensor):
         """Launch the all-gather of this rank's tokens (or projected K|V) ``[(b_l n_l f) l, width]`` over the view group and
@@ -131,6 +142,7 @@ class ShardPlan:
         out = torch.empty((S * rows, width), dtype=kv.dtype, device=kv.device)
         work = dist.all_gather_into_tensor(out, kv, group=self.view_group, async_op=True)
         self._count((S - 1) * rows * width * kv.element_size())
+        self._overlap(+1)
         return work, out, kv
 
     def all_gather_views_finish(self, handle, b_local: int) -> torch.Tensor:
@@ -138,6 +150,7 @@ class ShardPlan:
         unsharded row order."""
         work, out, kv = handle
         work.wait()
+        self._overlap(-1)
         S = self.view_shards
         rows, width = kv.shape
         if b_local == 1:
@@ -158,12 +171,13 @@ class ShardPlan:
         out = torch.empty((S * rows, width), dtype=kv.dtype, device=kv.device)
         work = dist.all_gather_into_tensor(out, kv, group=self.frame_group, async_op=True)
         self._count((S - 1) * rows * width * kv.element_size())
+        self._overlap(+1)
         return work, out, kv
 
-    @staticmethod
-    def all_gather_frames_finish(handle) -> torch.Tensor:
+    def all_gather_frames_finish(self, handle) -> torch.Tensor:
         work, out, _ = handle
         work.wait()
+        self._overlap(-1)
         return out
 
     def broadcast_frame0(self, x0: Optional[torch.Tensor], shape, dtype, device) -> torch.Tensor:
@@ -200,6 +214,8 @@ def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: 
     frame_shards) or None for the default (CFG halves, then views, then frames); ``shape`` = (b, n, F) of the calls to come
     creates the process groups now instead of inside the first forward."""
     unet.parallel = ShardPlan(group, layout)
+    lib = getattr(getattr(unet, "ops", None), "lib", None)          # HIP op set: reserve CUs for RCCL while a gather overlaps the GEMMs
+    unet.parallel.cu_knob = getattr(lib, "a3d_tune_gemm", None) if lib is not None else None
     if shape is not None:
         unet.parallel.configure(*shape)
     return unet.parallel

@@ -20,6 +20,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .denoise import randn_like_reference
+
 TRAINABLE_MODULES = ("i2v.", "motion_modules.")        # configs/training/train.yaml: trainable_modules
 
 
@@ -95,6 +97,18 @@ class FlatAdamW(torch.optim.Optimizer):
         for p, off in zip(self.params, self.offsets):
             yield off, p.numel()
 
+    def _check_homes(self) -> None:
+        """The fused step updates the flat buffers: every parameter (and its gradient) must still live there.  ``unet.to()`` / ``.half()``
+        after construction re-binds ``p.data``; ``model.zero_grad(set_to_none=True)`` without ``optimizer.zero_grad()`` drops ``p.grad``."""
+        es = self.flat_p.element_size()
+        for p, off in zip(self.params, self.offsets):
+            if p.data_ptr() != self.flat_p.data_ptr() + off * es:
+                raise RuntimeError("FlatAdamW: a parameter no longer aliases the flat parameter buffer (the model was moved / cast after the "
+                                   "optimiser was built: build the optimiser after unet.to(...), as train.py:456 orders it)")
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * es:
+                raise RuntimeError("FlatAdamW: a gradient no longer aliases the flat gradient buffer (call optimizer.zero_grad(), not "
+                                   "model.zero_grad(set_to_none=True), between steps)")
+
     def scale(self, loss: torch.Tensor) -> torch.Tensor:
         return loss if self.loss_scale is None else loss * self.loss_scale
 
@@ -115,6 +129,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, world: int = 1) -> Dict[str, float]:
         """Unscale (+ average over ``world`` ranks), clip to ``max_grad_norm``, AdamW; skipped when the gradient is not finite.
         One host read-back per step (the three control floats), as GradScaler.update() has."""
+        self._check_homes()
         self.step_count += 1
         inv = 1.0 / (world * (self.loss_scale if self.loss_scale is not None else 1.0))
         ctrl = self.ops.clip_ctrl(self.ops.sqnorm(self.flat_g), self.max_grad_norm, inv)
@@ -167,9 +182,10 @@ def training_step(unet, optimizer: FlatAdamW, latents: torch.Tensor, text_embeds
     dev = latents.device
     first, rest = latents[:, :, :, 0:1], latents[:, :, :, 1:]                               # :540-543 first frame stays clean
     if noise is None:
-        noise = torch.randn(rest.shape, generator=generator, device=dev, dtype=rest.dtype)
+        noise = randn_like_reference(rest.shape, generator, dev, rest.dtype)              # a CPU generator is the usual idiom
     if timesteps is None:
-        timesteps = torch.randint(0, alphas_cumprod.shape[0], (b,), generator=generator, device=dev).long()
+        gdev = generator.device if generator is not None else dev
+        timesteps = torch.randint(0, alphas_cumprod.shape[0], (b,), generator=generator, device=gdev).long().to(dev)
     noisy = torch.cat([first, add_noise(rest, noise, timesteps, alphas_cumprod)], dim=3)      # :553-555
     noisy = noisy.reshape(b * n, c, f, h, w)
     ehs = text_embeds[:, None].expand(b, n, *text_embeds.shape[1:]).reshape(b * n, *text_embeds.shape[1:])      # :565-566

@@ -669,11 +669,19 @@ class MVUNetMotionModel(nn.Module):
         q2 = ops.gemm(n2, pk.q2)
         kvt = ops.gemm(text_rows, pk.kv_text)
         qc = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
-        ca = ops.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), B2, pk.heads, L, T)
-        for ipr, w, scale, nt in zip(ip_rows, pk.kv_ip, pk.ip_scale, pk.ip_tokens):
-            kvi = ops.gemm(ipr, w)
-            ops.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), B2, pk.heads, L, nt,
-                           out=ca, out_scale=scale, accumulate=True)
+        ca = None
+        fused = getattr(ops, "flash_attn2", None)
+        if fused is not None and len(ip_rows) == 1:          # one adapter (the released configuration): text + image tokens in one launch
+            kvi = ops.gemm(ip_rows[0], pk.kv_ip[0])
+            nt = pk.ip_tokens[0]
+            ca = fused(q2, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), B2, pk.heads,
+                       L, T, nt, out_scale2=pk.ip_scale[0])
+        if ca is None:
+            ca = ops.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), B2, pk.heads, L, T)
+            for ipr, w, scale, nt in zip(ip_rows, pk.kv_ip, pk.ip_scale, pk.ip_tokens):
+                kvi = ops.gemm(ipr, w)
+                ops.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), B2, pk.heads, L, nt,
+                               out=ca, out_scale=scale, accumulate=True)
         return ops.gemm(ca, pk.o2[0], pk.o2[1], residual=residual)
 
     def _self_attention(self, n1, residual, pk, V, n, F, L):
@@ -853,8 +861,12 @@ class MVUNetMotionModel(nn.Module):
         """Pack for one differentiable forward: sub-modules without a trainable parameter come from a persistent detached pack
         (so that the autograd op set can cache their transposed / flipped dgrad operands), the others are packed again with
         ``_pack_grad`` on — a cast / cat / interleave per step, the price of fp32 master weights behind 16-bit kernels."""
-        if self._packed_frozen is None:
+        # the frozen pack is valid for ONE set of trainable parameters: requires_grad_() / select_trainable() / freeze_unet2d_params()
+        # between steps (staged training: a module trained first and frozen later) must not leave its pre-training weights in the pack
+        sig = tuple(p.requires_grad for p in self.parameters())
+        if self._packed_frozen is None or sig != getattr(self, "_packed_frozen_sig", None):
             self._packed_frozen = self._pack()
+            self._packed_frozen_sig = sig
             self._packed = None                    # (_pack stored it as the inference pack; that one is rebuilt on demand)
             self._mark_persistent(self._packed_frozen)
         Pf = self._packed_frozen

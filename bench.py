@@ -14,17 +14,19 @@ Inputs are resident in HBM before the timed region.  For N > 1 the SAME job is s
 frames, animate3d_amd/parallel.py) => strong scaling; value = steps/s of the whole job.
 
 Rank 0 prints ONE JSON line.  It carries
-  roofline     — the dominant kernel as rocprofv3 names it (flash_attn_il_kernel<2, 8, 0>: level-0 multi-view / first-frame
-                 attention, head_dim 40): algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
+  roofline     — the dominant kernel as rocprofv3 names it (bf16: flash_attn_dm_kernel<5, 2>, fp16: flash_attn_il_kernel<2, 8, 0>:
+                 level-0 multi-view / first-frame attention, head_dim 40): algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
                  launch stream inside the timed region, against the dense bf16 MFMA peak; ``ceilings`` adds the second
                  ceiling that binds at head_dim 40 — the v_exp issue rate measured with tools/ubench_exp.hip — and ``traffic``
                  the HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (read from
-                 profiles/r2_flash_pmc_traffic.json; null when that file does not describe this launch shape);
+                 profiles/r3_flash_pmc_traffic.json; null when that file does not describe this kernel and launch shape);
   groups       — per kernel family (attention by head dim, GEMM, fused GEGLU GEMM, 3x3 conv, norms, ...): ms per step and
                  achieved TFLOP/s or GB/s, from one extra instrumented forward OUTSIDE the timed region;
   cpu_baseline — the CPU oracle (plain-PyTorch fp32 restatement of the reference forward; the reference itself cannot be
-                 imported offline) timed on this host on BASELINE config 1: seeded weights, 1 warm-up + up to 3 timed forwards
-                 inside a time budget, thread count chosen by a 2-second matmul probe over the CPUs this process may use.
+                 imported offline) timed on this host on BASELINE config 1: seeded weights, 1 warm-up + 3 timed forwards
+                 (fewer only past a 150-s budget), thread count chosen by a 2-second matmul probe over the CPUs this process may use.
+``--dtype`` selects the storage type of the kernels; the default is the dtype BASELINE.json states for the configuration (2: bf16, 4 and
+5: fp16) and the line's ``dtype`` reports what ran.  ``--graph`` adds the same steps replayed from a HIP graph (capture_graph).
 """
 import argparse
 import json
@@ -41,10 +43,15 @@ if ROOT not in sys.path:
 METRIC = "UNet denoise-steps/sec, 4view×16frame×512² MV-VDM @1/2/4/8 GPU"     # BASELINE.json, verbatim
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 GB/s achievable (MI355X_MICROARCH.md)
-# v_exp_f32 issue rate next to the kernel's own MFMA / v_cvt_pk / v_max3 mix, two waves per SIMD (tools/ubench_exp.hip,
-# profiles/r2_ubench_exp.log): 8.5e12 exp/s chip-wide; every score costs one exp and 4 * head_dim MFMA FLOPs
-EXP_PER_S_IN_MIX = 8.5e12
-DOMINANT_KERNEL = "flash_attn_il_kernel<2, 8, 0>"
+# v_exp_f32 issue rate next to the kernel's own MFMA / v_cvt_pk mix, two waves per SIMD (tools/ubench_exp.hip,
+# profiles/r2_ubench_exp.log): 9.4e12 exp/s chip-wide without the v_max3 chain (bf16 kernel), 8.5e12 with it (fp16 kernel); every score
+# costs one exp and 4 * head_dim MFMA FLOPs
+EXP_PER_S_IN_MIX = {"bf16": 9.4e12, "fp16": 8.5e12}
+# level-0 attention kernel per storage type, and the share of its issued MFMA work that is useful (QK^T contraction 40 -> 48;
+# O^T rows 41 -> 48 through 16x16x32 in the bf16 kernel, 41 -> 64 through 32x32x16 in the fp16 kernel)
+DOMINANT_KERNEL = {"bf16": "flash_attn_dm_kernel<5, 2>", "fp16": "flash_attn_il_kernel<2, 8, 0>"}
+USEFUL_MFMA_SHARE = {"bf16": 640.0 / 768.0, "fp16": 655360.0 / 917504.0}
+CONFIG_DTYPE = {2: "bf16", 4: "fp16", 5: "fp16"}      # BASELINE.json
 
 CONFIGS = {     # BASELINE.json configs that fit one GPU: (views, frames, latent, label)
     2: (4, 16, 64, "BASELINE config 2: 4 views x 16 frames x 512^2 px (64x64 latent)"),
@@ -87,9 +94,19 @@ class TimedOps:
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            self.records.append((self._family(name, a, k), e0, e1, self._work(name, a, k, out)))
+            self.records.append((self._family(name, a, k), e0, e1, self._work(name, a, k, out), self._shape(name, a, k)))
             return out
         return timed
+
+    @staticmethod
+    def _shape(name, a, k):
+        if name in ("gemm", "gemm_geglu"):
+            return f"{name} M={a[0].shape[0]} N={a[1].shape[0]} K={a[0].shape[1]}" + (" +res" if k.get("residual") is not None else "") + (" +rowbias" if k.get("rowbias") is not None else "")
+        if name == "conv3x3":
+            return f"conv3x3 B={a[1]} {a[2]}x{a[3]} Cin={a[0].shape[1]} Cout={a[4].shape[0]}" + (f" stride={k['stride']}" if k.get("stride", 1) != 1 else "") + (" up2x" if k.get("up2x") else "") + (" +res" if k.get("residual") is not None else "")
+        if name in ("group_norm", "layer_norm", "concat", "temporal_attn"):
+            return f"{name} {tuple(a[0].shape)}"
+        return name
 
     @staticmethod
     def _family(name, a, k):
@@ -128,7 +145,7 @@ class TimedOps:
             out = self._ops.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, **kw)
             e1.record()
             fam = f"flash_attn D={D}" + (" (cross: text / IP tokens)" if kv_len <= 128 else "")
-            self.records.append((fam, e0, e1, (work, 0.0)))
+            self.records.append((fam, e0, e1, (work, 0.0), f"{fam} G={groups} Sq={q_len} Skv={kv_len}"))
             return out
         if not (self.enabled and D == self._hd and kv_len >= self._min_kv):
             return self._ops.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, **kw)
@@ -140,9 +157,18 @@ class TimedOps:
         self.flops.append(work)
         return out
 
+    def shape_summary(self, top=40):
+        agg = {}
+        for _, e0, e1, (fl, by), shp in self.records:
+            d = agg.setdefault(shp, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl; d[3] += by
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        return [{"op": k, "launches": c, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if fl else None, "gbs": round(by / ms / 1e6) if by else None}
+                for k, (c, ms, fl, by) in rows]
+
     def group_summary(self):
         agg = {}
-        for fam, e0, e1, (fl, by) in self.records:
+        for fam, e0, e1, (fl, by), _ in self.records:
             d = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl; d[3] += by
         out = {}
@@ -188,7 +214,7 @@ def _pick_threads(limit):
     return best, seen
 
 
-def cpu_baseline(threads, budget_s=75.0):
+def cpu_baseline(threads, budget_s=150.0):
     """Bounded CPU sample: the oracle (plain-PyTorch fp32 restatement of the reference forward) on BASELINE config 1
     (1 view x 4 frames x 64x64 latent = 512^2 px, fp32, no CFG; 6.45 TFLOP): seeded weights, 1 warm-up + up to 3 timed
     forwards, stopping when the time budget is used.  The config-2 figure is a FLOP-ratio extrapolation."""
@@ -221,11 +247,11 @@ def cpu_baseline(threads, budget_s=75.0):
             "config2_equivalent_steps_per_s": (1.0 / dt) * f_cfg1 / f_cfg2}
 
 
-def _pmc_traffic(S0, groups):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass, if it matches this launch shape."""
+def _pmc_traffic(S0, groups, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass, if it matches this kernel and launch shape."""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_flash_pmc_traffic.json")))
-        if rec.get("kernel") == DOMINANT_KERNEL and rec.get("kv_len") == S0 and rec.get("groups") == groups:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r3_flash_pmc_traffic.json")))
+        if rec.get("kernel") == kernel and rec.get("kv_len") == S0 and rec.get("groups") == groups:
             return rec
     except Exception:
         pass
@@ -244,6 +270,9 @@ def main():
     ap.add_argument("--layout", type=str, default="", help="multi-GPU: cfg,views,frames shard counts (default: CFG halves, then views, then frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-groups", action="store_true", help="skip the instrumented forward behind the 'groups' object")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default=None, help="kernel storage type (default: what BASELINE.json states for the configuration)")
+    ap.add_argument("--graph", action="store_true", help="also time the same steps replayed from a HIP graph (capture_graph)")
+    ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 40 by time)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
     args = ap.parse_args()
 
@@ -277,10 +306,14 @@ def main():
         label = f"custom: {n} views x {F} frames x {lat * 8}^2 px ({lat}x{lat} latent)"
     V = 2 * n
     S0 = n * hw[0] * hw[1]
-    ops = TimedOps(HipOps(dev), head_dim=cfg.block_out_channels[0] // cfg.num_attention_heads, min_kv=S0)
+    dtype_name = args.dtype or CONFIG_DTYPE[args.config]
+    torch_dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    ops = TimedOps(HipOps(dev, act_dtype=torch_dtype), head_dim=cfg.block_out_channels[0] // cfg.num_attention_heads, min_kv=S0)
     model = MVUNetMotionModel(cfg, ops=ops, num_views=n, device=dev)
     model.init_synthetic(seed=0)
-    model = model.to(torch.bfloat16).eval()
+    model = model.to(torch_dtype).eval()
+    assert model.ops.act_dtype == torch_dtype
+    dom_kernel = DOMINANT_KERNEL[dtype_name]
     par = None
     if world > 1:
         from animate3d_amd.parallel import shard_unet
@@ -325,16 +358,17 @@ def main():
         flops = sum(ops.flops) / len(ops.flops)
         achieved = flops / mean_dur / 1e12
         D = ops._hd
-        exp_ceiling = EXP_PER_S_IN_MIX * 4.0 * D / 1e12
-        pmc = _pmc_traffic(S0, (V // n) * F) if world == 1 else None
-        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (level-0 multi-view / first-frame attention, head_dim 40)",
+        exp_ceiling = EXP_PER_S_IN_MIX[dtype_name] * 4.0 * D / 1e12
+        pmc = _pmc_traffic(S0, (V // n) * F, dom_kernel) if world == 1 else None
+        roofline = {"bound": "mfma", "kernel": dom_kernel + " (level-0 multi-view / first-frame attention, head_dim 40)",
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                     "ceilings": {"mfma_dense_bf16_tflops": PEAK_BF16_TFLOPS,
-                                 "mfma_after_padding_tflops": round(PEAK_BF16_TFLOPS * 655360 / 917504, 1),
+                                 "mfma_after_padding_tflops": round(PEAK_BF16_TFLOPS * USEFUL_MFMA_SHARE[dtype_name], 1),
                                  "exp_issue_tflops_equivalent": round(exp_ceiling, 1), "frac_of_exp_ceiling": achieved / exp_ceiling,
-                                 "note": "head_dim 40: one v_exp_f32 per 160 MFMA FLOPs and 29 % of the issued MFMA work is padding (QK^T contraction "
-                                         "40->48, O^T rows 41->64); the exp ceiling is the v_exp rate measured next to this kernel's MFMA / cvt / max mix "
-                                         "(tools/ubench_exp.hip); the kernel is also clock-limited by power (zero inputs run 22-29 % faster)"},
+                                 "note": "head_dim 40: one v_exp_f32 per 160 MFMA FLOPs; padding of the issued MFMA work: QK^T contraction 40->48, O^T rows "
+                                         "41->48 (bf16 kernel, 16x16x32 MFMA) or 41->64 (fp16 kernel); the exp ceiling is the v_exp rate measured next to the "
+                                         "kernel's MFMA / cvt mix (tools/ubench_exp.hip); the kernel is clock-limited by power: zero inputs run it 22-29 % faster and "
+                                         "removing its per-tile barrier changes nothing on random data (profiles/README.md)"},
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                     "traffic_source": (pmc or {}).get("source", "no committed PMC pass for this launch shape"),
                     "algorithmic_bytes_per_launch": 4.0 * (V // n) * F * S0 * D * 8 * 2,      # Q, K, V read + O written once, bf16
@@ -367,6 +401,18 @@ def main():
         comm["ms_per_step_without_collectives"] = dry / max(1, min(args.steps, 3)) * 1e3
         comm["exposed_communication_ms_per_step"] = ms_per_step - comm["ms_per_step_without_collectives"]
 
+    graph_ms = None
+    if args.graph and world == 1:
+        gstep = model.capture_graph(**inp)
+        for _ in range(max(1, args.warmup)):
+            gstep(**inp)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gstep(**inp)
+        sync()
+        graph_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
     groups = None
     if not args.no_groups:
         ops.profile = True
@@ -374,6 +420,9 @@ def main():
         torch.cuda.synchronize()
         ops.profile = False
         groups = ops.group_summary()
+        if args.shapes and rank == 0:
+            for r in ops.shape_summary():
+                print(f"[shape] {r['ms']:8.3f} ms  x{r['launches']:3d}  {r['tflops'] or '':>7} TF/s  {r['gbs'] or '':>6} GB/s  {r['op']}", file=sys.stderr)
 
     if rank == 0:
         from animate3d_amd.flops import step_flops
@@ -381,7 +430,7 @@ def main():
         line = {
             "metric": METRIC, "value": value, "unit": "denoise-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": f"{label}, CFG-doubled batch V={V} videos, one MVUNetMotionModel.forward per step, SD1.5 MV-VDM UNet "
                                    "1.53 B params, seeded synthetic weights",
                        "parallelism": "single GPU" if world == 1 else
@@ -392,6 +441,9 @@ def main():
         }
         if args.config == 2 and (n, F, lat) == (n0, F0, lat0):
             line["config2_25_ddim_steps_seconds"] = 25.0 * ms_per_step / 1e3
+        if graph_ms is not None:
+            line["hip_graph_replay"] = {"ms_per_step": graph_ms, "eager_ms_per_step": ms_per_step,
+                                        "note": "the same forward captured once (MVUNetMotionModel.capture_graph) and replayed; inputs copied into the static buffers per step"}
         if groups is not None:
             line["groups"] = groups
         if comm is not None:

@@ -113,6 +113,16 @@ int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
                         float scale, float out_scale, int accumulate);
 
+/* Two key sets in one launch, each with its own softmax:
+ *   O = out_scale * attn(Q, K, V) + out_scale2 * attn(Q, K2, V2)   (+ previous O contents if accumulate)
+ * Replaces the text-token attention, the per-adapter image-token attention and `hidden_states = hidden_states + scale * ip` of the
+ * IPAdapter processor (attention_processor.py:233, 254-283) with ONE pass over Q and O.  head_dim 40 or 80 (A3D_EUNSUPPORTED otherwise:
+ * the caller then issues two a3d_flash_attn calls, the second with accumulate). */
+int a3d_flash_attn2_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* K2, const void* V2, void* O,
+                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* kmap2, const a3d_rowmap* omap,
+                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int64_t kv_len2,
+                         float scale, float out_scale, float out_scale2, int accumulate);
+
 /* Tuning knob (diagnostics, used by tools/microbench.py for in-process A/B timing): 0 = default dispatch,
  * 5 = never use the 8-wave ping-pong kernel for head_dim 40.  Results are identical for both. */
 int a3d_tune_flash(int variant);
@@ -304,6 +314,10 @@ int a3d_flash_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const 
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
                         float scale, float out_scale, int accumulate);
+int a3d_flash_attn2_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* K2, const void* V2, void* O,
+                        const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* kmap2, const a3d_rowmap* omap,
+                        int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int64_t kv_len2,
+                        float scale, float out_scale, float out_scale2, int accumulate);
 int a3d_temporal_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
                            void* O, int64_t ldo, int videos, int frames, int64_t L, int heads,
                            int head_dim, float scale);

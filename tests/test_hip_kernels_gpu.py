@@ -252,6 +252,26 @@ def test_flash_attn_cross_text_ip(ops, ref, D):
     check(f"text+ip cross-attn D{D}", o, o_r2, tol=6e-3)
 
 
+@pytest.mark.parametrize("D", [40, 80, 160])
+@pytest.mark.parametrize("V,F,L", [(2, 3, 64), (1, 2, 300)])
+def test_flash_attn_two_key_sets_in_one_launch(ops, ref, D, V, F, L):
+    """a3d_flash_attn2: text tokens (77) + IP-Adapter image tokens (4) in one launch, each with its own softmax, against the two-call
+    sequence of the fp32 reference (attention_processor.py:233, 254-283); head_dim 160 has no fused kernel and must say so (None)."""
+    heads, T, nt = 8, 77, 4
+    C = heads * D
+    q = rnd(V * F * L, C, seed=1)
+    kvt, kvi = rnd(V * T, 2 * C, seed=2), rnd(V * nt, 2 * C, seed=3)
+    qc = RowMap(1, L, 0, L, 0)
+    got = ops.flash_attn2(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), V * F, heads,
+                          L, T, nt, out_scale2=0.7)
+    if D == 160:
+        assert got is None
+        return
+    want = ref.flash_attn2(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), V * F, heads,
+                           L, T, nt, out_scale2=0.7)
+    check(f"text + ip attention in one launch D{D} V{V} F{F} L{L}", got, want)
+
+
 def test_flash_attn_rescale_branch(ops, ref):
     """One key per tile far above the rest forces the running-max rescale at a chosen tile."""
     heads, D, L = 8, 40, 512

@@ -41,7 +41,11 @@ def _worker(rank, world, port, n, F, hw, videos, layout, q, backend="gloo"):
         cfg = UNetConfig()
         model = MVUNetMotionModel(cfg, num_views=n, device="cuda")
         model.init_synthetic(seed=0)
-        model = model.to(torch.bfloat16).eval()
+        # frame layouts re-associate the GroupNorm sums, which re-draws the roundings of everything behind them: in bf16 storage two
+        # such runs are ~1e-2 apart (the size of the bf16 error against the oracle itself), which would hide a layout bug of that
+        # size.  They are therefore compared in fp16 storage, where rounding noise is 8x smaller and a wrong row is not.
+        frames_sharded = layout is not None and layout[2] > 1
+        model = model.to(torch.float16 if frames_sharded else torch.bfloat16).eval()
         inp = O.synthetic_inputs(O.UNetConfig(), videos, n, F, hw, seed=11, cfg_doubled=videos >= 2 * n)
         inp = {k: (v.cuda() if torch.is_tensor(v) else ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v)) for k, v in inp.items()}
         full = model(**inp).sample
@@ -51,6 +55,8 @@ def _worker(rank, world, port, n, F, hw, videos, layout, q, backend="gloo"):
         sharded_kv = model(**inp).sample
         scale = full.abs().max().item()
         err = max((sharded - full).abs().max().item(), (sharded_kv - full).abs().max().item()) / scale
+        l2 = max(((sharded - full).float().norm() / full.float().norm()).item(), ((sharded_kv - full).float().norm() / full.float().norm()).item())
+        err = (err, l2)
         q.put((rank, err, (par.cfg_shards, par.view_shards, par.frame_shards), par.gather_bytes, tuple(sharded.shape), bool(torch.isfinite(sharded).all())))
     except Exception as e:
         q.put((rank, repr(e), (0, 0, 0), 0, (), False))
@@ -75,6 +81,7 @@ def _run(world, n, F, videos, layout, backend="gloo"):
 
 @pytest.mark.parametrize("world,n,F,videos,layout,expect", [
     (2, 4, 2, 4, None, (1, 2, 1)), (2, 2, 2, 4, None, (2, 1, 1)), (4, 4, 2, 8, None, (2, 2, 1)),
+    (4, 4, 2, 4, (1, 4, 1), (1, 4, 1)),          # BASELINE config 3's layout: the views of one CFG half over 4 ranks
     (2, 2, 4, 2, (1, 1, 2), (1, 1, 2)),          # frames: sharded temporal attention, split 3-D GroupNorm, frame-0 broadcast
     (4, 2, 4, 2, (1, 2, 2), (1, 2, 2)),          # views x frames (BASELINE config 4's wording)
 ])
@@ -82,12 +89,18 @@ def test_sharded_forward_on_gpu_equals_unsharded(world, n, F, videos, layout, ex
     for rank, err, got, gbytes, shape, finite in _run(world, n, F, videos, layout):
         assert not isinstance(err, str), err
         assert got == expect and shape == (videos, 4, F, 16, 16) and finite
-        # Same kernels and the same per-row arithmetic; what differs is which launch shapes the rows go through (the sharded
-        # GEMMs see fewer rows, so some take the 128x128 kernel instead of the persistent one: same K order, bit-identical)
-        # and, with frame shards, the association of the fp64 GroupNorm sums.  Observed: exact equality for CFG / view
-        # layouts; the bar leaves room for a bf16 ulp flipping after the re-associated norm statistics.
-        print(f"[parity] sharded {expect} vs unsharded on the GPU, rank {rank}: max |diff| / max |ref| = {err:.3e}")
-        assert err < 2e-2, (rank, err)
+        # Same kernels and the same per-row arithmetic.  CFG / view layouts: which launch shapes the rows go through differs (the
+        # sharded GEMMs see fewer rows, so some take the 128x128 kernel instead of the persistent one: same K order, bit-identical;
+        # the attention kernels compute every query independently of its tile) => bit-for-bit equality is REQUIRED.  Frame layouts
+        # re-associate the fp64 GroupNorm sums of the 21 motion modules and so re-draw the 16-bit roundings behind them; they run in
+        # fp16 storage here (see _worker) and must stay within fp16 rounding noise: relative L2 <= 3e-3, worst element <= 1e-2 of the
+        # output scale (round 3, bf16 storage for reference: 1.1e-2 / 1.25e-2 — indistinguishable from bf16 noise, hence fp16).
+        err, l2 = err
+        print(f"[parity] sharded {expect} vs unsharded on the GPU, rank {rank}: max |diff| / max |ref| = {err:.3e}, relative L2 = {l2:.3e}")
+        if expect[2] == 1:
+            assert err == 0.0, (rank, err)
+        else:
+            assert err <= 1e-2 and l2 <= 3e-3, (rank, err, l2)
         assert (gbytes > 0) == (expect[1] > 1 or expect[2] > 1)
 
 
@@ -99,11 +112,11 @@ def test_sharded_forward_over_rccl():
     world = 8 if ndev >= 8 else (4 if ndev >= 4 else 2)
     for rank, err, got, gbytes, shape, finite in _run(world, 4, 4, 8, None, backend="nccl"):
         assert not isinstance(err, str), err
-        assert finite and err < 2e-2 and shape == (8, 4, 4, 16, 16)
+        assert finite and err[0] == 0.0 and shape == (8, 4, 4, 16, 16)
     if world >= 4:
         for rank, err, got, gbytes, shape, finite in _run(world, 4, 4, 8, (world // 4, 2, 2), backend="nccl"):
             assert not isinstance(err, str), err
-            assert finite and err < 2e-2 and got == (world // 4, 2, 2)
+            assert finite and err[0] < 2e-2 and err[1] <= 3e-3 and got == (world // 4, 2, 2)
 
 
 def _rccl_worker(port, q):

@@ -214,6 +214,10 @@ class TorchRefOps:
 
     # ------------------------------------------------------------------ training path (include/animate3d_hip.h "Training path")
     # References of the backward kernels: torch autograd through the forward references above, in fp32.
+    def flash_attn2(self, q, k, v, k2, v2, qmap, kmap, kmap2, groups, heads, q_len, kv_len, kv_len2, *, out_scale2=1.0):
+        o = self.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len)
+        return self.flash_attn(q, k2, v2, qmap, kmap2, groups, heads, q_len, kv_len2, out=o, out_scale=out_scale2, accumulate=True)
+
     def flash_attn_bwd(self, q, k, v, do, qmap, kmap, groups, heads, q_len, kv_len, *, q_per_kv=1, do_scale=1.0, need_dq=True, need_dkv=True):
         with torch.enable_grad():
             qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
