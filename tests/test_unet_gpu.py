@@ -234,6 +234,32 @@ def test_full_size_batch_independence():
     assert full.shape == (8, 4, 16, 64, 64)
 
 
+@pytest.mark.parametrize("dtype,bar", [(torch.bfloat16, 3e-2), (torch.float16, 6e-3)])
+def test_config2_full_size_against_the_oracle_golden(dtype, bar):
+    """BASELINE config 2 at FULL size against the CPU oracle: 4 views x 16 frames x 64x64 latent (512^2 px), one CFG half (V = 4; the
+    other half is independent of it bit for bit, test_full_size_batch_independence), level-0 multi-view attention over 16 384 keys —
+    the launch shape that is half of the benchmark.  The oracle's output was computed once (tests/golden/make_config2_golden.py,
+    ~45 min of CPU) and committed as fp16 (tests/golden/config2_full.npz); weights and inputs are re-drawn here from the same seeds.
+    Bars: the end-to-end bars of the small shapes (bf16 3e-2, fp16 6e-3 relative L2; the golden's fp16 storage adds 3e-4)."""
+    import os
+    import numpy as np
+    from tests.golden.make_config2_golden import FRAMES, HW, SEED_IN, SEED_W, VIEWS
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_full.npz"))
+    want = torch.from_numpy(gold["sample"].astype(np.float32))
+    ocfg = O.UNetConfig()
+    ref = O.build_fast(ocfg, VIEWS, FRAMES, HW, seed=SEED_W)
+    inp = O.synthetic_inputs(ocfg, VIEWS, VIEWS, FRAMES, HW, seed=SEED_IN)
+    assert abs(inp["sample"].double().sum().item() - float(gold["in_checksum"])) < 1e-6 * max(1.0, abs(float(gold["in_checksum"])))
+    hip = MVUNetMotionModel(UNetConfig(), num_views=VIEWS, device="cuda")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    del ref
+    hip = hip.to(dtype).eval()
+    y = hip(**_cuda(inp)).sample
+    e, mx, sc = _rel(y, want)
+    print(f"[parity] unet config 2 FULL size (4v x 16f x 64x64, {dtype}) vs the oracle golden: rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e})")
+    assert y.shape == want.shape and torch.isfinite(y).all() and e <= bar
+
+
 def test_config4_full_size_fp16():
     """BASELINE config 4 at FULL size on one GPU: 8 views x 32 frames x 64x64 latent, CFG-doubled V = 16, fp16 model and inputs
     (2.58 PFLOP per step, ~100 GB working set).  The oracle cannot run this; checked instead: finite output of the right shape,
