@@ -22,6 +22,7 @@ extern int g_gemm_vm_counted;
 extern int g_gemm_persist;
 extern int g_gemm_bk;
 extern int g_gemm_reserved_cus;
+extern int g_gemm_stagger;
 #else
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
                               // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
@@ -33,6 +34,7 @@ int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a til
 int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
                          // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
 int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
+int g_gemm_stagger = 0;        // a3d_tune_gemm(500 + u): start-time stagger of the persistent workgroups (A/B experiment: de-phase the epilogue store bursts)
 int g_gemm_reserved_cus = 0;   // a3d_tune_gemm(200 + k): the persistent grid leaves k CUs free (set by the sharded path while an RCCL
                                // all-gather is in flight: its kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
 #endif
@@ -65,6 +67,7 @@ struct GemmParams {
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
+  int stagger;          // persistent kernel (experiment, a3d_tune_gemm(500 + u)): CUs start (blockIdx / 8) % 4 * u * ~0.5 us apart
 #ifdef A3D_EXP_CHUNK_MAJOR
   int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
 #endif
@@ -484,6 +487,10 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   int64_t t = xcd_remap(blockIdx.x, G);
   if (t >= ntiles) return;
   const int nk = (int)(p.K / 64);
+  if (p.stagger > 0) {
+    const int phase = (int)((blockIdx.x >> 3) & 3);
+    for (int i = 0; i < phase * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);      // ~1 000 cycles each
+  }
 
   // fragment reads: lane reads row (.. + l31), logical chunk 2*ks + g, stored at chunk ^ ((row >> 1) & 7); every block
   // base row is a multiple of 16, so the swizzle term depends on the lane only: offset(ks) = koff0 ^ (ks << 5)
@@ -841,6 +848,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   if (ntiles * 100 < rounds * cus * g_gemm_min_fill) return -1000;                  // average fill of the rounds (per cent)
   p.tiles_m = tiles_m; p.tiles_n = tiles_n;
   p.vm_counted = g_gemm_vm_counted;
+  p.stagger = g_gemm_stagger;
   if constexpr (EPI == EPI_GEGLU) {
     return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
   } else {
@@ -970,6 +978,7 @@ extern "C" int a3d_tune_gemm(int bk) {
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
 #endif
   if (bk >= 200 && bk <= 264) { g_gemm_reserved_cus = bk - 200; return A3D_OK; }
+  if (bk >= 500 && bk <= 600) { g_gemm_stagger = bk - 500; return A3D_OK; }
   if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
   if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
   g_gemm_bk = bk;

@@ -416,3 +416,26 @@ def test_reference_training_loop_with_torch_ddp_over_gloo():
         assert not isinstance(err, str), err
         print(f"[parity] rank {rank}: DDP-averaged, clipped gradient vs mean of the ranks' local gradients: {err:.2e}; parameters identical across ranks: {same}")
         assert err < 1e-3 and same          # two fp32 evaluations of the clip norm
+
+
+def test_staged_training_refreezing_a_module_drops_its_stale_frozen_pack():
+    """Staged training (train a module, then freeze it and train another in the same process): the persistent pack of the FROZEN
+    sub-modules is valid for one set of trainable parameters only.  After the motion modules were trained and then frozen by
+    ``requires_grad_(False)`` (no ``_invalidate()`` involved), the next grad-enabled forward must read their UPDATED weights — i.e. equal
+    the ``no_grad`` forward, which always re-packs — and not the weights of the first pack."""
+    ocfg, ref, model = _pair(2, 2, (8, 8))
+    inp = O.synthetic_inputs(ocfg, 2, 2, 2, (8, 8), seed=3, cfg_doubled=False)
+    model.enable_training()
+    y0 = model(**inp).sample                              # builds the frozen pack (motion modules + i2v trainable)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "motion_modules." in name and p.ndim >= 2:
+                p.mul_(1.5)                               # "training" moved the motion modules
+    for name, p in model.named_parameters():              # stage 2: freeze them, keep i2v trainable
+        if "motion_modules." in name:
+            p.requires_grad_(False)
+    y_train = model(**inp).sample
+    with torch.no_grad():
+        y_eval = model(**inp).sample
+    assert not torch.allclose(y_train, y0)                # the new weights are seen ...
+    torch.testing.assert_close(y_train.detach(), y_eval, rtol=1e-5, atol=1e-6)      # ... exactly as the re-packing inference path sees them
