@@ -95,9 +95,40 @@ A3D_DEV float gelu_erf(float gte) {
   poly *= t;
   const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
   const float erfx = fmaf(-poly, e, 1.0f);                     // erf(|g|/sqrt2)
-  const float erfs = gte < 0.f ? -erfx : erfx;
   const float hg = __fmul_rn(0.5f, gte);            // 0.5 g (1 + erf): roundings pinned, identical in every kernel variant
-  return __fmaf_rn(hg, erfs, hg);
+  // erf is odd: hg * erf(g/sqrt2) = |hg| * erf(|g|/sqrt2) exactly (same product, same fma rounding as the sign-select form it replaces:
+  // two VALU per value less in an epilogue that is as long as the K = 320 main loop)
+  return __fmaf_rn(fabsf(hg), erfx, hg);
+}
+
+// The same arithmetic on a pair of values held as a 64-bit register pair: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 without the
+// register shuffling the compiler's own pairing of scalar code needs (4 v_mov per value in the fused GEGLU epilogue).  Per element the
+// operations and roundings are exactly gelu_erf's.
+A3D_DEV f32x2_t splat2(float v) { return f32x2_t{v, v}; }
+A3D_DEV f32x2_t gelu_erf2(f32x2_t g) {
+  const f32x2_t x = __builtin_elementwise_abs(g) * 0.70710678118654752f;
+  const f32x2_t den = __builtin_elementwise_fma(splat2(0.3275911f), x, splat2(1.0f));
+  const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2_t poly = __builtin_elementwise_fma(splat2(1.061405429f), t, splat2(-1.453152027f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(1.421413741f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(-0.284496736f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(0.254829592f));
+  poly = poly * t;
+  const f32x2_t a = (-x) * x * 1.4426950408889634f;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const f32x2_t erfx = __builtin_elementwise_fma(-poly, e, splat2(1.0f));
+  const f32x2_t hg = g * 0.5f;
+  return __builtin_elementwise_fma(__builtin_elementwise_abs(hg), erfx, hg);
+}
+// y[0..7] = (h + b_h) * gelu(g + b_g) on four register pairs
+A3D_DEV void geglu8(const float (&hv)[8], const float (&gv)[8], const float (&bh)[8], const float (&bg)[8], float (&y)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x2_t gg = f32x2_t{gv[2 * e], gv[2 * e + 1]} + f32x2_t{bg[2 * e], bg[2 * e + 1]};
+    const f32x2_t hh = f32x2_t{hv[2 * e], hv[2 * e + 1]} + f32x2_t{bh[2 * e], bh[2 * e + 1]};
+    const f32x2_t yy = hh * gelu_erf2(gg);
+    y[2 * e] = yy[0]; y[2 * e + 1] = yy[1];
+  }
 }
 
 // CONV: 0 = dense A, 1 = 3x3 conv gather (pad 1, stride 1|2), 2 = 3x3 conv over a nearest-2x upsampled input
@@ -332,8 +363,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
         const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         float y[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = (hv[e] + bh[e]) * gelu_erf(gv[e] + bg[e]);
+        geglu8(hv, gv, bh, bg, y);
         u32x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack16(y[2 * e], y[2 * e + 1]);
@@ -753,8 +783,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
           const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
           const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
           float y[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = (hv[e] + bh[e]) * gelu_erf(gv[e] + bg[e]);
+          geglu8(hv, gv, bh, bg, y);
           u32x4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = pack16(y[2 * e], y[2 * e + 1]);
