@@ -1,0 +1,244 @@
+// Shared pieces of the GEMM / implicit-GEMM convolution kernels (gemm_conv.hip: 128 x 128 and persistent two-stage kernels,
+// gemm_ring.hip: persistent four-stage ring kernel): launch parameters, epilogue arithmetic, LDS-DMA helpers and the
+// LDS-transposing epilogue of the persistent 256 x (NB*64) tiles.
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+  const uint16_t* X; int64_t ldx;
+  const uint16_t* W; int64_t ldw;
+  const float* bias;
+  const uint16_t* rowbias; int64_t rb_div;
+  const uint16_t* R; int64_t ldr;
+  uint16_t* Y; int64_t ldy;
+  int64_t M, N, K;
+  float alpha, beta;
+  int vec16;            // output / residual / rowbias rows allow 16-byte accesses
+  int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
+  int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
+  int ring_spread;      // ring kernel: DMA pieces interleaved with the MFMAs (a3d_tune_gemm(10)) instead of issued back to back (9)
+  int stagger;          // persistent kernel (experiment, a3d_tune_gemm(500 + u)): CUs start (blockIdx / 8) % 4 * u * ~0.5 us apart
+#ifdef A3D_EXP_CHUNK_MAJOR
+  int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
+#endif
+  // conv geometry (CONV only)
+  int B, H, Wd, Cin, Ho, Wo, stride, up, He, We;   // He x We: extent of the (virtual) upsampled image of the up2x conv
+  int64_t tiles_n, tiles_m;
+};
+
+constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;
+
+// alpha * v and + beta * r with the roundings pinned (no compiler-chosen fma contraction), so that every kernel variant
+// produces bit-identical outputs for any alpha (the AlphaBlender mix uses alpha = sigmoid(mix_factor))
+A3D_DEV float epi_scale(float v, float alpha) { return __fmul_rn(v, alpha); }
+A3D_DEV float epi_axpy(float v, float beta, float r) { return __fmaf_rn(beta, r, v); }
+
+// erf-GELU with Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below bf16 resolution): 2 transcendentals +
+// ~10 VALU instead of libm erff's ~25-instruction polynomial ladder — this runs in a GEMM epilogue.
+A3D_DEV float gelu_erf(float gte) {
+  const float x = fabsf(gte) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+  const float erfx = fmaf(-poly, e, 1.0f);                     // erf(|g|/sqrt2)
+  const float hg = __fmul_rn(0.5f, gte);            // 0.5 g (1 + erf): roundings pinned, identical in every kernel variant
+  // erf is odd: hg * erf(g/sqrt2) = |hg| * erf(|g|/sqrt2) exactly (same product, same fma rounding as the sign-select form it replaces:
+  // two VALU per value less in an epilogue that is as long as the K = 320 main loop)
+  return __fmaf_rn(fabsf(hg), erfx, hg);
+}
+
+// The same arithmetic on a pair of values held as a 64-bit register pair: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 without the
+// register shuffling the compiler's own pairing of scalar code needs (4 v_mov per value in the fused GEGLU epilogue).  Per element the
+// operations and roundings are exactly gelu_erf's.
+A3D_DEV f32x2_t splat2(float v) { return f32x2_t{v, v}; }
+A3D_DEV f32x2_t gelu_erf2(f32x2_t g) {
+  const f32x2_t x = __builtin_elementwise_abs(g) * 0.70710678118654752f;
+  const f32x2_t den = __builtin_elementwise_fma(splat2(0.3275911f), x, splat2(1.0f));
+  const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2_t poly = __builtin_elementwise_fma(splat2(1.061405429f), t, splat2(-1.453152027f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(1.421413741f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(-0.284496736f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(0.254829592f));
+  poly = poly * t;
+  const f32x2_t a = (-x) * x * 1.4426950408889634f;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const f32x2_t erfx = __builtin_elementwise_fma(-poly, e, splat2(1.0f));
+  const f32x2_t hg = g * 0.5f;
+  return __builtin_elementwise_fma(__builtin_elementwise_abs(hg), erfx, hg);
+}
+// y[0..7] = (h + b_h) * gelu(g + b_g) on four register pairs
+A3D_DEV void geglu8(const float (&hv)[8], const float (&gv)[8], const float (&bh)[8], const float (&bg)[8], float (&y)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x2_t gg = f32x2_t{gv[2 * e], gv[2 * e + 1]} + f32x2_t{bg[2 * e], bg[2 * e + 1]};
+    const f32x2_t hh = f32x2_t{hv[2 * e], hv[2 * e + 1]} + f32x2_t{bh[2 * e], bh[2 * e + 1]};
+    const f32x2_t yy = hh * gelu_erf2(gg);
+    y[2 * e] = yy[0]; y[2 * e + 1] = yy[1];
+  }
+}
+
+static __device__ u32x4_t g_zero_page[4];      // 64 zero bytes: source of out-of-image conv taps (device globals are zero-filled)
+
+A3D_DEV uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// LDS-DMA: 64 lanes x 16 B -> LDS[lds_dst + 16 * lane]; the compiler does not count these (s_waitcnt vmcnt by hand)
+A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+  unsigned keep;
+#ifdef A3D_EXP_CHUNK_MAJOR
+  const uint64_t a = (uint64_t)(uintptr_t)sbase;      // wave-uniform by construction; say so (folds away when already scalar)
+  sbase = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+#endif
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+// a wave-uniform pointer the compiler computed on the vector ALU (64-bit divisions): move it to scalar registers for an "s" operand
+A3D_DEV const uint16_t* scalar_ptr(const uint16_t* ptr) {
+  const uint64_t a = (uint64_t)(uintptr_t)ptr;
+  return (const uint16_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+}
+A3D_DEV void wave_lds_fence() {          // orders this wave's LDS writes before its later LDS reads (LDS executes a wave's ops in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- epilogue of one 256 x (NB*64) tile held as acc[tn][tm] by 8 waves (4(M) x 2(N); wave (wm, wn) owns rows wm*64 .. +63 and the
+//      32-column blocks wblk .. wblk + NB - 2 and wblk_last).  stg: this wave's private 32 x 68 fp32 LDS buffer; bias_lds / rowbias_lds:
+//      the tile's bias (fp32, tile columns) and rowbias row (16-bit) as the main loop's DMA left them in LDS.
+template <int EPI, int NB, bool RES>
+A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float* const stg, const float* const bias_lds,
+                              const uint16_t* const rowbias_lds, const int64_t m0, const int64_t n0, const int wm, const int wblk,
+                              const int wblk_last, const int lane) {
+  const int l31 = lane & 31, g = lane >> 5;
+  // ---- epilogue: per 32-row half and <= 64-column pass, transpose through a wave-private LDS buffer so that each
+  //      lane owns 8 consecutive output columns (16-byte bias / rowbias / residual / output accesses)
+  constexpr int SROW = 68;
+  constexpr int NP = (NB + 1) / 2;                       // passes of <= 64 columns per 32-row half
+  u32x4_t rres[RES ? 2 : 1][RES ? 4 : 1];
+  auto pass_cols = [&](int ps) { return (2 * ps + 1 < NB) ? 64 : 32; };
+  auto pass_col0 = [&](int ps) { return ((2 * ps + 1 < NB) ? wblk + 2 * ps : wblk_last) * 32; };   // first tile column of pass ps
+  auto load_res = [&](int pi, int slot) {
+    if constexpr (RES) {
+      const int tm = pi / NP, ps = pi % NP;
+      const int64_t mbase = m0 + wm * 64 + tm * 32;
+      const int64_t nbase = n0 + pass_col0(ps);
+      if (pass_cols(ps) == 64) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t m = mbase + 8 * j + (lane >> 3);
+          rres[slot][j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + nbase + 8 * (lane & 7));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t m = mbase + 16 * j + (lane >> 2);
+          rres[slot][j] = *reinterpret_cast<const u32x4_t*>(p.R + m * p.ldr + nbase + 8 * (lane & 3));
+        }
+      }
+    }
+  };
+  if constexpr (RES) load_res(0, 0);
+#pragma unroll
+  for (int pi = 0; pi < 2 * NP; ++pi) {
+    const int tm = pi / NP, ps = pi % NP;
+    const int ncol = pass_cols(ps);
+    if constexpr (RES) { if (pi + 1 < 2 * NP) load_res(pi + 1, (pi + 1) & 1); }
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int tn = 2 * ps + tl;
+      if (tn < NB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v;
+          v.x = acc[tn][tm][4 * q]; v.y = acc[tn][tm][4 * q + 1]; v.z = acc[tn][tm][4 * q + 2]; v.w = acc[tn][tm][4 * q + 3];
+          *reinterpret_cast<float4*>(stg + l31 * SROW + tl * 32 + 8 * q + 4 * g) = v;
+        }
+      }
+    }
+    wave_lds_fence();
+    const int64_t mbase = m0 + wm * 64 + tm * 32;
+    const int64_t nbase = n0 + pass_col0(ps);               // first column of this pass
+
+    if constexpr (EPI == EPI_GEGLU) {
+      // NB is even here: columns [0,32) of the pass are h, [32,64) the matching gates
+      const int cc = lane & 3;
+      const int64_t oc = nbase / 2 + 8 * cc;
+      float bh[8], bg[8];
+      {
+        const float* bl = bias_lds + (pass_col0(ps) + 8 * cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? bl[e] : 0.f; bg[e] = p.bias ? bl[32 + e] : 0.f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 16 * j + (lane >> 2);
+        const int64_t m = mbase + row;
+        const float4 h0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
+        const float4 h1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(stg + row * SROW + 32 + 8 * cc);
+        const float4 g1 = *reinterpret_cast<const float4*>(stg + row * SROW + 32 + 8 * cc + 4);
+        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float y[8];
+        geglu8(hv, gv, bh, bg, y);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack16(y[2 * e], y[2 * e + 1]);
+        *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
+      }
+    } else {
+      const int lpr = ncol / 8;                                // lanes per row: 8 (64 columns) or 4 (32 columns)
+      const int cc = lane & (lpr - 1);
+      const int64_t n = nbase + 8 * cc;
+      const int ncl = pass_col0(ps) + 8 * cc;                   // column within the tile
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = p.bias ? bias_lds[ncl + e] : 0.f;
+      u32x4_t tb = {0u, 0u, 0u, 0u};
+      if (p.rowbias) tb = *reinterpret_cast<const u32x4_t*>(rowbias_lds + ncl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j * (64 / lpr) >= 32) continue;                    // 32-column pass: two row groups of 16
+        const int row = (64 / lpr) * j + lane / lpr;
+        const int64_t m = mbase + row;
+        const float4 a0 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc);
+        const float4 a1 = *reinterpret_cast<const float4*>(stg + row * SROW + 8 * cc + 4);
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        if (p.rowbias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += lo16(tb[e]); v[2 * e + 1] += hi16(tb[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = epi_scale(v[e], p.alpha);
+        if constexpr (RES) {
+          const u32x4_t tr = rres[pi & 1][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] = epi_axpy(v[2 * e], p.beta, lo16(tr[e])); v[2 * e + 1] = epi_axpy(v[2 * e + 1], p.beta, hi16(tr[e])); }
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack16(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + n) = o;
+      }
+    }
+    wave_lds_fence();
+  }
+}
+
+// gemm_ring.hip: the four-stage ring variant of the persistent kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller
+// (try_launch_persist) has filled tiles_m / tiles_n / vm_counted and checked the shape
+__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_ring)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);

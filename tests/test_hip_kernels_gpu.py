@@ -95,7 +95,8 @@ def test_gemm_layout_asymmetric(ops):
     assert torch.equal(y, w.t().contiguous())
 
 
-# The big token matrices (M % 256 == 0, >= 192 output tiles of 256 x 320 / 256 x 256) take the persistent LDS-DMA kernel;
+# The big token matrices (M % 256 == 0, >= 192 output tiles of 256 x 320 / 256 x 256) take the persistent LDS-DMA kernels (default: the
+# two-stage one of csrc/gemm_conv.hip; a3d_tune_gemm(9) / (10): the four-stage ring kernel of csrc/gemm_ring.hip, a measured experiment);
 # a3d_tune_gemm(1) forces the 128 x 128 kernel, whose K order and epilogue arithmetic are identical => bit-equal outputs.
 def _persistent_eligible(M, N, geglu=False, cus=256):
     nb = (4 if N % 256 == 0 else 0) if geglu else (5 if N % 320 == 0 else (4 if N % 256 == 0 else 0))
@@ -115,8 +116,17 @@ def _both_paths(ops, fn):
         assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(4) == 0     # every store drained before each tile
         drained = fn()
         assert torch.equal(drained[0] if isinstance(drained, tuple) else drained, classic[0] if isinstance(classic, tuple) else classic)
+        assert ops.lib.a3d_tune_gemm(5) == 0 and ops.lib.a3d_tune_gemm(8) == 0     # the two-stage persistent kernel (round 1-2 default)
+        two_stage = fn()
+        assert torch.equal(two_stage[0] if isinstance(two_stage, tuple) else two_stage, classic[0] if isinstance(classic, tuple) else classic)
+        assert ops.lib.a3d_tune_gemm(9) == 0 and ops.lib.a3d_tune_gemm(4) == 0     # four-stage ring kernel, stores drained at tile starts
+        ring_drained = fn()
+        assert torch.equal(ring_drained[0] if isinstance(ring_drained, tuple) else ring_drained, classic[0] if isinstance(classic, tuple) else classic)
+        assert ops.lib.a3d_tune_gemm(10) == 0 and ops.lib.a3d_tune_gemm(5) == 0    # ring kernel, DMA pieces interleaved with the MFMAs
+        ring_spread = fn()
+        assert torch.equal(ring_spread[0] if isinstance(ring_spread, tuple) else ring_spread, classic[0] if isinstance(classic, tuple) else classic)
     finally:
-        assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(5) == 0     # the defaults
+        assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(5) == 0 and ops.lib.a3d_tune_gemm(8) == 0     # the defaults
     got = fn()
     for _ in range(2):                              # the counted-vmcnt pipeline must be deterministic run to run
         again = fn()

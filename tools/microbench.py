@@ -165,10 +165,10 @@ def bench_convk(ops):
 
 
 def bench_persist(ops):
-    """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernel (3) with all stores drained before each
-    tile (4) or left in flight behind a counted vmcnt wait (5, default)."""
-    print("== persistent GEMM A/B: median ms / TFLOP/s / effective GB/s;  classic | persistent, drained | persistent, counted wait   [+res = with residual]")
-    MODES = ((1, 5), (3, 4), (3, 5))
+    """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernels: two 64-wide stages (8, rounds 1-2) and the
+    four-stage ring of 32-wide half-tiles (9, default)."""
+    print("== persistent GEMM A/B: median ms / TFLOP/s / effective GB/s;  classic | two-stage persistent | four-stage ring | ring, spread DMA issue   [+res = with residual]")
+    MODES = ((1, 9), (3, 8), (3, 9), (3, 10))
 
     def set_mode(m):
         ops.lib.a3d_tune_gemm(m[0]); ops.lib.a3d_tune_gemm(m[1])
@@ -187,7 +187,7 @@ def bench_persist(ops):
                 ref = y if ref is None else ref
                 med, mn = timeit(lambda: ops.gemm(x, w, bias, **kw), reps=7)
                 outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s {byts / med / 1e6:5.0f} GB/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-            set_mode((3, 5))
+            set_mode((3, 8))
             print(f"M={M:7d} N={N:5d} K={K:5d}{tag}: " + " | ".join(outs))
     print("-- fused GEGLU projection")
     for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
@@ -201,7 +201,7 @@ def bench_persist(ops):
             ref = y if ref is None else ref
             med, mn = timeit(lambda: ops.gemm_geglu(x, w, bias), reps=7)
             outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        set_mode((3, 5))
+        set_mode((3, 8))
         print(f"M={M:7d} N2={N2:5d} K={K:5d}: " + " | ".join(outs))
     print("-- conv3x3")
     for (B, H, W, Cin, Cout, st, up) in [(128, 64, 64, 320, 320, 1, False), (128, 64, 64, 640, 320, 1, False), (128, 32, 32, 640, 640, 1, False),
@@ -219,8 +219,33 @@ def bench_persist(ops):
             ref = y if ref is None else ref
             med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
             outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        set_mode((3, 5))
+        set_mode((3, 8))
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + " | ".join(outs))
+
+
+def bench_gemmscale(ops):
+    """Per-K-tile time of the persistent GEMM against the number of active CUs: G output tiles of 256 x 320 (one per workgroup),
+    K = 5120 (80 K-tiles per tile), so the time of a launch is 80 x the K-tile period (+ one epilogue).  Flat in G = latency /
+    issue bound per CU; growing with G = shared bandwidth (L2 / fabric) bound; zeros vs random data separates the power share."""
+    for kern, name in ((8, "two-stage"), (9, "ring"), (10, "ring-spread")):
+        ops.lib.a3d_tune_gemm(kern)
+        print(f"== persistent GEMM ({name}): period per 64 of K vs active CUs (M = 256 G, N = 320, K = 5120)")
+        for scale in (1.0,):
+            for G in (1, 32, 64, 128, 256, 1024):
+                x = rnd(256 * G, 5120, scale=scale)
+                w = rnd(320, 5120, scale=0.02 * scale)
+                med, mn = timeit(lambda: ops.gemm(x, w), reps=7, warm=2)
+                rounds = (G + 255) // 256
+                print(f"{name} data x{scale:.0f} G={G:4d}: {med * 1e3:8.1f} us   K-tile period {mn * 1e3 / (80 * rounds):6.3f} us  "
+                      f"({2.0 * 256 * G * 320 * 5120 / mn / 1e9:7.1f} TF/s best)")
+        print("== same, N = 1280 (4 column tiles share each A tile through L2)")
+        for G in (8, 64, 256, 1024):
+            x = rnd(64 * G, 5120)
+            w = rnd(1280, 5120, scale=0.02)
+            med, mn = timeit(lambda: ops.gemm(x, w), reps=7, warm=2)
+            rounds = (G + 255) // 256
+            print(f"{name} G={G:4d}: {med * 1e3:8.1f} us   K-tile period {mn * 1e3 / (80 * rounds):6.3f} us  ({2.0 * 64 * G * 1280 * 5120 / mn / 1e9:7.1f} TF/s best)")
+    ops.lib.a3d_tune_gemm(8)
 
 
 def bench_fill(ops):
@@ -350,7 +375,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl, "flashdm": bench_flashdm,
+         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
