@@ -1357,13 +1357,11 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
 #endif
       // LDS-DMA staged kernel (flash_attn_dm.hip).  bf16 storage: the default for the long aligned shapes (flags 5: max-free first
       // pass + P·V through the 16x16x32 MFMA); a3d_tune_flash(20 + flags) forces a flag set, 19 forces the interleaved kernel below.
-      // fp16 storage keeps the interleaved kernel (the max-free pass needs bf16's exponent range; forced flag sets run the exact pass).
+      // fp16 storage runs the same flag set with a sampled offset and fp16's narrower window (flash_attn_dm.hip, DM_BIAS).
       {
         const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 256;      // (a workgroup covers 512 queries)
         int dm_flags = (g_flash_variant >= 20 && g_flash_variant <= 35) ? g_flash_variant - 20 : -1;
-#ifndef A3D_STORAGE_F16
         if (g_flash_variant == 0) dm_flags = 5;
-#endif
         if (long_aligned && dm_flags >= 0) {
           if (int rc = A3D_FN(a3d_launch_flash_dm)(dm_flags, groups, s, p)) return rc;
           break;
@@ -1400,14 +1398,12 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
       // long sequences (level 1 of the 512-px configurations): two query sub-tiles per wave, 32-key tiles — every K / V^T
       // fragment read feeds two MFMAs, which relieves the LDS port that bounds the one-sub-tile kernel (+4-8 %,
       // profiles/r2_microbench_flash80_ab.log); short ones keep one sub-tile per wave (more workgroups).  a3d_tune_flash(8 | 17) forces either.
-      // LDS-DMA staged kernel (flash_attn_dm80.hip): the bf16 default from 512 tokens; a3d_tune_flash(42) forces it (43: its exact pass only),
+      // LDS-DMA staged kernel (flash_attn_dm80.hip): the default from 512 tokens (both storage types); a3d_tune_flash(42) forces it (43: its exact pass only),
       // 8 / 17 force the kernels below
       {
         const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256;
         int dm_flags = g_flash_variant == 42 ? 1 : (g_flash_variant == 43 ? 0 : -1);
-#ifndef A3D_STORAGE_F16
         if (g_flash_variant == 0 && kv_len >= 512 && q_len >= 256) dm_flags = 1;
-#endif
         if (long_aligned && dm_flags >= 0) {
           if (int rc = A3D_FN(a3d_launch_flash_dm80)(dm_flags, groups, s, p)) return rc;
           break;

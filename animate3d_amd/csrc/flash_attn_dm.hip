@@ -16,14 +16,12 @@
 //    1.0 in contraction slot 40 of K that carries the softmax offset, the ones "dimension" 40 of V that produces the row
 //    sums, the zero padding up to 48 / 64 — are not part of the images: the lanes that would read them point at a small
 //    constant region instead (all lanes of a read that share an address are one broadcast).
-//  * bf16 storage only: NO row maximum.  P = exp2(S - m) is stored in bf16, whose exponent range is fp32's, and accumulated in
-//    fp32; the result does not depend on m as long as nothing overflows.  m is the exact maximum of the first 32 keys; after
-//    that the kernel only watches the row sums that the matrix pipe produces anyway (O^T row 40): once per 64-key tile one
-//    compare per query sub-tile; when a sum passes 2^30 the offset moves by log2(sum) (same rare path as the exact kernel:
-//    the pending P is folded in first).  A probability that still overflows (a score more than ~2^7 log2 units above
-//    everything seen before it, inside one check interval) makes the row sum non-finite or > 2^100: the workgroup then
-//    discards its result and re-runs with the exact running maximum (the interleaved kernel's arithmetic).  The exact path
-//    is also what the fp16 build always runs (fp16 P overflows at 2^16).
+//  * NO running row maximum.  P = exp2(S - m) is stored in 16 bits and accumulated in fp32; the result does not depend on m as long
+//    as nothing overflows or vanishes.  m is fixed per query before the key loop (maximum of 32 sample scores + DM_BIAS, carried in
+//    contraction slot 40 of Q) and nothing is checked inside the loop; at the end the row sum that the matrix pipe produces anyway
+//    (O^T row 40) must be positive, finite and < 2^100, otherwise the workgroup discards its result and re-runs with the exact
+//    running maximum (run_exact: the arithmetic of flash_attn_kernel).  bf16 storage: P has fp32's exponent range, the window around
+//    the estimate is ~2^100 wide either way and the first 32 keys are sample enough.  fp16 storage: P holds 2^-24 .. 2^16, see DM_BIAS.
 #include "flash_common.h"
 
 namespace {
@@ -37,9 +35,26 @@ constexpr int DM_CK = DM_RING * DM_TILEB;          // K constant chunk (16 B): 1
 constexpr int DM_CV = DM_CK + 80;                  // V constant region: (1,0,0,0) pieces at DM_CV + {0, 80, 1280, 1360}, zero elsewhere; its first
                                                    // bank is 4 mod 8 (mod 16), where no data lane of the same read lands
 constexpr int DM_CV_BYTES = 1408;
-constexpr int DM_SMEM_BYTES = DM_CV + DM_CV_BYTES;
+constexpr int DM_SAMPLE = DM_CV + DM_CV_BYTES;     // one 32-key K sub-tile of sample keys (fp16 storage: the offset estimate)
+constexpr int DM_SMEM_BYTES = DM_SAMPLE + DM_UNITB;
 constexpr float DM_L_BAD = 1.2676506e30f;          // 2^100: beyond this the max-free result is not trusted
-constexpr float DM_BIAS = 40.f;                    // max-free offset = maximum of the first 32 scores + 40 (log2 units)
+// Max-free offset = maximum of 32 sample scores + DM_BIAS (log2 units).  P is stored in 16 bits: bf16 has fp32's exponent range, so any
+// row maximum within ~2^100 of the estimate works and the first 32 keys are sample enough.  fp16 holds 2^-24 .. 2^16: the window is
+// [estimate - 4, estimate + 20) — the sample is 32 keys spread evenly over the whole key range (one extra 2.5-KB DMA and 3 MFMAs per
+// query sub-tile), the bias is small so that the row maximum stays a normal number, and a row that still overflows (P = inf, the
+// row sum is not finite) sends its workgroup to the exact pass like any other overflow.
+#ifdef A3D_STORAGE_F16
+constexpr float DM_BIAS = 4.f;
+constexpr bool DM_SAMPLED = true;
+// ... and a row whose sample already predicts an overflow never starts the max-free pass: with sample standard deviation sd (log2
+// units) the maximum of 16 384 scores is expected ~2.4 sd above the maximum of 32 (Gaussian tails: 4.4 sd vs 2.0 sd); the workgroup
+// goes straight to the exact pass when 3.4 sd (one sd of safety) would leave the 20-unit window, i.e. sd^2 > DM_VAR_MAX.
+constexpr float DM_VAR_MAX = 28.f;
+#else
+constexpr float DM_BIAS = 40.f;
+constexpr bool DM_SAMPLED = false;
+constexpr float DM_VAR_MAX = 0.f;           // (unused)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t dm_smem[];
 
@@ -62,11 +77,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
   constexpr int KS_PAD = 2, G_PAD = 1;                    // fragment slot of contraction index 40
   constexpr int NEXP = 16 * QT, NCVT = 8 * QT;
   constexpr bool PV16 = (FLAGS & 4) != 0;
-#ifdef A3D_STORAGE_F16
-  constexpr bool TRY_NOMAX = false;
-#else
   constexpr bool TRY_NOMAX = (FLAGS & 1) != 0;
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int w = __builtin_amdgcn_readfirstlane(wid);
@@ -130,6 +141,14 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
   const uint32_t voffA = slot_src(w < 10 ? 64 * w + lane : lane);
   const uint32_t voffB = slot_src(QT == 2 ? 512 + 16 * w + i16 : 0);
   const uint64_t maskA = w < 10 ? ~0ull : 0ull;
+  // sample sub-tile (DM_SAMPLED): slot s = 64 w + lane < 160 is piece s % 5 of sample row s / 5 = key (s / 5) * (kv_len / 32)
+  uint32_t voffS = 0;
+  if constexpr (DM_SAMPLED) {
+    const int ss = (64 * w + lane) % 160;
+    const int64_t key = (int64_t)(ss / 5) * (p.kv_len / 32);
+    voffS = (uint32_t)((((key / p.km.seg_len) * p.km.seg_stride + key % p.km.seg_len) * ld + (ss % 5) * 8) * 2);
+  }
+  const uint64_t maskS = w < 2 ? ~0ull : (w == 2 ? 0xffffffffull : 0ull);
 
   // ---- fragment addressing (byte offsets into dm_smem; the tile / sub-tile offset is added per step, scaled by 0 for the
   // lanes that read constants)
@@ -248,16 +267,20 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
       for (int nb = 0; nb < 2 * QT; ++nb) oacc16[mb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
   const int nt = p.kv_len / 64;               // launcher guarantees kv_len % 64 == 0, nt >= 4, aligned segments
-  auto prologue_dma = [&]() __attribute__((always_inline)) {      // tiles 0, 1, 2 requested; 0 and 1 complete
+  auto prologue_dma = [&]() __attribute__((always_inline)) {      // (sample sub-tile,) tiles 0, 1, 2 requested; all but tile 2 complete
     dma_reset();
+    if constexpr (DM_SAMPLED && TRY_NOMAX)
+      dm_glds16_m(voffS, dm_scalar(p.K + hoff + kgbase * ld), lds0 + (uint32_t)(DM_SAMPLE + 1024 * (w < 3 ? w : 0)), maskS);
     dma_a(0); dma_b(0);
     dma_a(1); dma_b(1);
     dma_a(2); dma_b(2);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
   };
-  // first offset of a query: exact maximum of its first 32 scores (+ bias); leaves the re-based scores in s
-  auto first_scores = [&](f32x16_t (&s)[QT], float (&m_off)[QT], float bias) __attribute__((always_inline)) {
-    read_k(0u);
+  // first offset of a query: exact maximum of its scores against the 32-key sub-tile at koff (+ bias); leaves the re-based scores in s
+  // (fp16 max-free pass: also returns whether the spread of the sample scores predicts an overflow of fp16's window)
+  auto first_scores = [&](f32x16_t (&s)[QT], float (&m_off)[QT], float bias, uint32_t koff = 0u) __attribute__((always_inline)) -> bool {
+    read_k(koff);
+    bool wide = false;
 #pragma unroll
     for (int qs = 0; qs < QT; ++qs) {
 #pragma unroll
@@ -268,12 +291,21 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qs][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if constexpr (DM_SAMPLED) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm += s[qs][r]; sq = fmaf(s[qs][r], s[qs][r], sq); }
+        sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+        const float mean = sm * (1.f / 32.f);
+        wide = wide || !(sq * (1.f / 32.f) - mean * mean <= DM_VAR_MAX);
+      }
       const float new_off = round16(mx + bias);
       m_off[qs] = new_off;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[qs][r] -= new_off;
       if (g == G_PAD) qf[qs][KS_PAD][0] = pack16(-new_off, 0.f);
     }
+    return wide;
   };
   // row sums (O^T row 40): 32x32 layout: register 4 of the second row tile, half 0 (query l31); 16x16 layout: register 0 of row
   // tile 2 in lanes 32..47 (query i16 of block nb).  Returns 1 / sum scaled for the store; `bad` = sum unusable (max-free pass).
@@ -420,7 +452,20 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
     prologue_dma();
     {
       float m_off[QT];
-      first_scores(sA, m_off, DM_BIAS);
+      if constexpr (DM_SAMPLED) {
+        const bool wide = first_scores(sA, m_off, DM_BIAS, (uint32_t)DM_SAMPLE);      // offset from the sample keys (now in Q's pad slot)
+        if (__syncthreads_or(wide ? 1 : 0)) return false;           // a row too peaked for fp16's window: exact pass right away
+        read_k(0u);                                                 // ... then S(0) of keys 0..31 under it
+#pragma unroll
+        for (int qs = 0; qs < QT; ++qs) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sA[qs][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) sA[qs] = mfma32(kf[ks], qf[qs][ks], sA[qs]);
+        }
+      } else {
+        first_scores(sA, m_off, DM_BIAS);
+      }
       read_k((uint32_t)DM_UNITB);               // K(0) keys 32..63 for step 0
     }
 

@@ -28,24 +28,31 @@ constexpr int E_TILEB = 2 * E_KB;                  // [K keys 0..63 (chunks swiz
 constexpr int E_RING = 5;
 constexpr int E_CV = E_RING * E_TILEB + 32;        // constant region: (1,0,0,0) at + {0, 160, 2560, 2720}, zero elsewhere; first bank 8 mod 16
 constexpr int E_CV_BYTES = 2752;
-constexpr int E_SMEM_BYTES = E_CV + E_CV_BYTES;
+constexpr int E_SAMPLE = E_CV + E_CV_BYTES;         // one 32-key K sub-tile of sample keys (fp16 storage: the offset estimate)
+constexpr int E_SMEM_BYTES = E_SAMPLE + E_UNITB;
 constexpr float E_L_BAD = 1.2676506e30f;           // 2^100
+// max-free offset = maximum of 32 sample scores + E_BIAS: bf16 keeps the first 32 keys and a wide margin, fp16 (P within 2^-24 .. 2^16)
+// samples 32 keys spread over the key range and keeps the row maximum a normal number (flash_attn_dm.hip, DM_BIAS)
+#ifdef A3D_STORAGE_F16
+constexpr float E_BIAS = 4.f;
+constexpr bool E_SAMPLED = true;
+constexpr float E_VAR_MAX = 28.f;                   // sample variance (log2 units squared) above which the workgroup skips the max-free pass
+#else
 constexpr float E_BIAS = 40.f;
+constexpr bool E_SAMPLED = false;
+constexpr float E_VAR_MAX = 0.f;           // (unused)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t e_smem[];
 A3D_DEV u32x4_t e_lds128(uint32_t off) { return *reinterpret_cast<const u32x4_t*>(e_smem + off); }
 A3D_DEV u32x2_t e_ldstr(uint32_t off) { return lds_tr16_b64(reinterpret_cast<const uint16_t*>(e_smem + off)); }
 
-// FLAGS: 1 = max-free first pass (bf16 storage only)
+// FLAGS: 1 = max-free first pass
 template <int FLAGS>
 __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParams p) {
   constexpr int D = 80, KS = 5, MT = 3, NT = 512, BQ = 256;
   constexpr int NEXP = 16, NCVT = 8, NDMA = 3;
-#ifdef A3D_STORAGE_F16
-  constexpr bool TRY_NOMAX = false;
-#else
   constexpr bool TRY_NOMAX = (FLAGS & 1) != 0;
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int w = __builtin_amdgcn_readfirstlane(wid);
@@ -94,6 +101,14 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
   const uint32_t voffA = slot_src(64 * w + lane);
   const uint32_t voffB = slot_src(512 + 64 * w + lane);
   const uint32_t voffC = slot_src(1024 + 32 * w + l31);
+  // sample sub-tile (E_SAMPLED): slot s = 64 w + lane < 320 is chunk s % 10 (swizzled like every K row) of sample row s / 10 = key (s / 10) * (kv_len / 32)
+  uint32_t voffS = 0;
+  if constexpr (E_SAMPLED) {
+    const int ss = (64 * w + lane) % 320, prow = ss / 10;
+    const int64_t key = (int64_t)prow * (p.kv_len / 32);
+    voffS = (uint32_t)((((key / p.km.seg_len) * p.km.seg_stride + key % p.km.seg_len) * ld + ((ss % 10) ^ ((prow >> 3) & 1)) * 8) * 2);
+  }
+  const uint64_t maskS = w < 5 ? ~0ull : 0ull;
 
   // ---- fragment addressing (byte offsets into e_smem; the tile / sub-tile offset is added per step, times 0 for constant lanes)
   const int krow = kperm(l31);
@@ -159,16 +174,18 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     for (int r = 0; r < 16; ++r) minit[r] = 0.f;
   };
   const int nt = p.kv_len / 64;               // launcher guarantees kv_len % 64 == 0, nt >= 4, aligned segments
-  auto prologue_dma = [&]() __attribute__((always_inline)) {      // tiles 0, 1, 2 requested; 0 and 1 complete
+  auto prologue_dma = [&]() __attribute__((always_inline)) {      // (sample sub-tile,) tiles 0, 1, 2 requested; all but tile 2 complete
     dma_reset();
+    if constexpr (E_SAMPLED && TRY_NOMAX)
+      dm_glds16_m(voffS, dm_scalar(p.K + hoff + kgbase * ld), lds0 + (uint32_t)(E_SAMPLE + 1024 * (w < 5 ? w : 0)), maskS);
     dma_a(0); dma_b(0); dma_c(0);
     dma_a(1); dma_b(1); dma_c(1);
     dma_a(2); dma_b(2); dma_c(2);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
   };
   // first offset: exact maximum of the query's first 32 scores (+ bias); leaves the re-based scores in s
-  auto first_scores = [&](f32x16_t& s, float& m_off, float bias) __attribute__((always_inline)) {
-    read_k(0u);
+  auto first_scores = [&](f32x16_t& s, float& m_off, float bias, uint32_t koff = 0u) __attribute__((always_inline)) -> bool {
+    read_k(koff);
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
@@ -177,9 +194,19 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    bool wide = false;
+    if constexpr (E_SAMPLED) {      // spread of the sample scores: does it predict an overflow of fp16's window? (flash_attn_dm.hip, DM_VAR_MAX)
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sm += s[r]; sq = fmaf(s[r], s[r], sq); }
+      sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+      const float mean = sm * (1.f / 32.f);
+      wide = !(sq * (1.f / 32.f) - mean * mean <= E_VAR_MAX);
+    }
     m_off = mx + bias;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] -= m_off; minit[r] = -m_off; }
+    return wide;
   };
   auto finish = [&](bool check) __attribute__((always_inline)) -> bool {      // row sums (O^T row 80 = register 8 of tile 2, half 0), stores
     const float l_tot = __shfl(oacc[2][8], l31);
@@ -272,7 +299,16 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     prologue_dma();
     {
       float m_off;
-      first_scores(sA, m_off, E_BIAS);
+      if constexpr (E_SAMPLED) {
+        const bool wide = first_scores(sA, m_off, E_BIAS, (uint32_t)E_SAMPLE);       // offset from the sample keys (now in minit)
+        if (__syncthreads_or(wide ? 1 : 0)) return false;          // a row too peaked for fp16's window: exact pass right away
+        read_k(0u);                                                // ... then S(0) of keys 0..31 under it
+        sA = minit;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) sA = mfma32(kf[ks], qf[ks], sA);
+      } else {
+        first_scores(sA, m_off, E_BIAS);
+      }
       read_k((uint32_t)E_UNITB);               // K(0) keys 32..63 for step 0
     }
 

@@ -14,7 +14,7 @@ Inputs are resident in HBM before the timed region.  For N > 1 the SAME job is s
 frames, animate3d_amd/parallel.py) => strong scaling; value = steps/s of the whole job.
 
 Rank 0 prints ONE JSON line.  It carries
-  roofline     — the dominant kernel as rocprofv3 names it (bf16: flash_attn_dm_kernel<5, 2>, fp16: flash_attn_il_kernel<2, 8, 0>:
+  roofline     — the dominant kernel as rocprofv3 names it (flash_attn_dm_kernel<5, 2> in both storage types:
                  level-0 multi-view / first-frame attention, head_dim 40): algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
                  launch stream inside the timed region, against the dense bf16 MFMA peak; ``ceilings`` adds the second
                  ceiling that binds at head_dim 40 — the v_exp issue rate measured with tools/ubench_exp.hip — and ``traffic``
@@ -44,13 +44,13 @@ METRIC = "UNet denoise-steps/sec, 4view×16frame×512² MV-VDM @1/2/4/8 GPU"    
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 GB/s achievable (MI355X_MICROARCH.md)
 # v_exp_f32 issue rate next to the kernel's own MFMA / v_cvt_pk mix, two waves per SIMD (tools/ubench_exp.hip,
-# profiles/r2_ubench_exp.log): 9.4e12 exp/s chip-wide without the v_max3 chain (bf16 kernel), 8.5e12 with it (fp16 kernel); every score
+# profiles/r2_ubench_exp.log): 9.4e12 exp/s chip-wide without the v_max3 chain of the round-2 kernel (8.5e12 with it); every score
 # costs one exp and 4 * head_dim MFMA FLOPs
-EXP_PER_S_IN_MIX = {"bf16": 9.4e12, "fp16": 8.5e12}
+EXP_PER_S_IN_MIX = {"bf16": 9.4e12, "fp16": 9.4e12}
 # level-0 attention kernel per storage type, and the share of its issued MFMA work that is useful (QK^T contraction 40 -> 48;
-# O^T rows 41 -> 48 through 16x16x32 in the bf16 kernel, 41 -> 64 through 32x32x16 in the fp16 kernel)
-DOMINANT_KERNEL = {"bf16": "flash_attn_dm_kernel<5, 2>", "fp16": "flash_attn_il_kernel<2, 8, 0>"}
-USEFUL_MFMA_SHARE = {"bf16": 640.0 / 768.0, "fp16": 655360.0 / 917504.0}
+# O^T rows 41 -> 48 through 16x16x32); fp16 storage runs the same kernel with a sampled softmax offset (csrc/flash_attn_dm.hip, DM_BIAS)
+DOMINANT_KERNEL = {"bf16": "flash_attn_dm_kernel<5, 2>", "fp16": "flash_attn_dm_kernel<5, 2>"}
+USEFUL_MFMA_SHARE = {"bf16": 640.0 / 768.0, "fp16": 640.0 / 768.0}
 CONFIG_DTYPE = {2: "bf16", 4: "fp16", 5: "fp16"}      # BASELINE.json
 
 CONFIGS = {     # BASELINE.json configs that fit one GPU: (views, frames, latent, label)
@@ -359,14 +359,14 @@ def main():
         achieved = flops / mean_dur / 1e12
         D = ops._hd
         exp_ceiling = EXP_PER_S_IN_MIX[dtype_name] * 4.0 * D / 1e12
-        pmc = _pmc_traffic(S0, (V // n) * F, dom_kernel) if world == 1 else None
+        pmc = _pmc_traffic(S0, (V // n) * F, dom_kernel) if world == 1 and dtype_name == "bf16" else None      # the committed PMC pass ran the bf16 build
         roofline = {"bound": "mfma", "kernel": dom_kernel + " (level-0 multi-view / first-frame attention, head_dim 40)",
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                     "ceilings": {"mfma_dense_bf16_tflops": PEAK_BF16_TFLOPS,
                                  "mfma_after_padding_tflops": round(PEAK_BF16_TFLOPS * USEFUL_MFMA_SHARE[dtype_name], 1),
                                  "exp_issue_tflops_equivalent": round(exp_ceiling, 1), "frac_of_exp_ceiling": achieved / exp_ceiling,
                                  "note": "head_dim 40: one v_exp_f32 per 160 MFMA FLOPs; padding of the issued MFMA work: QK^T contraction 40->48, O^T rows "
-                                         "41->48 (bf16 kernel, 16x16x32 MFMA) or 41->64 (fp16 kernel); the exp ceiling is the v_exp rate measured next to the "
+                                         "41->48 (16x16x32 MFMA); the exp ceiling is the v_exp rate measured next to the "
                                          "kernel's MFMA / cvt mix (tools/ubench_exp.hip); the kernel is clock-limited by power: zero inputs run it 22-29 % faster and "
                                          "removing its per-tile barrier changes nothing on random data (profiles/README.md)"},
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",

@@ -579,6 +579,58 @@ def test_fp16_storage_attention(ops16, ref, D):
     check(f"f16 temporal attn D{D}", ops16.temporal_attn(q, k, v, V, F, L, heads), ref.temporal_attn(q, k, v, V, F, L, heads), tol=1.5e-3)
 
 
+@pytest.mark.parametrize("var", [20, 21, 25, 29])
+@pytest.mark.parametrize("spikes,gain", [((), 1.0), ((3,), 1.5), ((40, 70), 1.5), ((250,), 2.2), ((500,), 4.0), ((-1,), 12.0), ((16, 48, 80), 2.0)])
+@pytest.mark.parametrize("L,q_len", [(512, 512), (1024, 700)])
+def test_fp16_flash_attn_dma_kernel(ops16, ref, var, spikes, gain, L, q_len):
+    """fp16 storage through flash_attn_dm_kernel: the max-free pass (flags 1 / 5 / 9) estimates the offset from 32 keys spread over the
+    key range (rows 0, L/32, 2L/32, ...) and keeps P inside fp16's 2^-24 .. 2^16: spikes of 9-14 log2 units above the sample stay inside
+    the window (gain 1.5 - 2.2: also when the spike IS a sample key), larger ones (gain >= 4) overflow to inf and must take the exact
+    re-run; flags 0 is the exact pass alone.  Bar: the fp16 attention bar (1.5e-3)."""
+    heads, D = 8, 40
+    C = heads * D
+    q, k, v = rnd(q_len, C, seed=1, dtype=H16), rnd(L, C, seed=2, dtype=H16), rnd(L, C, seed=3, dtype=H16)
+    for t, row in enumerate(spikes):
+        k[row % L] = q[7 + 3 * t] * (gain + 0.25 * t)
+    qm, km = RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0)
+    want = ref.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
+    try:
+        assert ops16.lib.a3d_tune_flash(var) == 0
+        got = ops16.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
+    finally:
+        ops16.lib.a3d_tune_flash(0)
+    check(f"f16 dm attn var{var} spikes {spikes} x{gain} L{L} q{q_len}", got, want, tol=1.5e-3)
+
+
+def test_fp16_flash_attn_dma_kernels_multiview_maps(ops16, ref):
+    """fp16 storage, default dispatch (LDS-DMA kernels at head_dim 40 and 80, sampled max-free pass) through the multi-view and
+    first-frame row maps — the sample keys are spread over all the views' segments —, against the fp32 reference and against the
+    round-2 kernels (a3d_tune_flash(19): interleaved, 8: two-sub-tile D = 80)."""
+    heads, b, n, F = 8, 2, 4, 2
+    try:
+        for D, L, old in ((40, 256, 19), (80, 256, 8)):
+            C = heads * D
+            qkv = rnd(b * n * F * L, 3 * C, seed=21 + D, dtype=H16)
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            qm, k0 = _mv_maps(n, F, L)
+            S = n * L
+            for km, nm in ((qm, "mv"), (k0, "i2v")):
+                want = ref.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
+                assert ops16.lib.a3d_tune_flash(0) == 0
+                got = ops16.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
+                check(f"f16 dm D{D} {nm} attn", got, want, tol=1.5e-3)
+                assert ops16.lib.a3d_tune_flash(old) == 0
+                check(f"f16 dm D{D} {nm} attn vs round-2 kernel", got, ops16.flash_attn(q, k, v, qm, km, b * F, heads, S, S), tol=1.5e-3)
+            q2, k2, v2 = q.contiguous(), k.clone(), v.contiguous()
+            k2[5 * L + 17] = q2[9] * 9.0         # far outside the fp16 window: exact re-run of the workgroups that see it
+            assert ops16.lib.a3d_tune_flash(0) == 0
+            check(f"f16 dm D{D} overflow re-run", ops16.flash_attn(q2, k2, v2, qm, qm, b * F, heads, S, S), ref.flash_attn(q2, k2, v2, qm, qm, b * F, heads, S, S), tol=1.5e-3)
+            qw, kw = (q2.float() * 2.5).to(H16), (k2.float() * 2.5).to(H16)      # scores 6 x wider: the sample's spread sends every workgroup to the exact pass
+            check(f"f16 dm D{D} wide scores", ops16.flash_attn(qw, kw, v2, qm, qm, b * F, heads, S, S), ref.flash_attn(qw, kw, v2, qm, qm, b * F, heads, S, S), tol=1.5e-3)
+    finally:
+        ops16.lib.a3d_tune_flash(0)
+
+
 def test_fp16_storage_norms_and_elementwise(ops16, ref):
     x = rnd(2 * 300, 640, seed=3, dtype=H16) + 0.5
     gamma, beta = 1 + 0.1 * rnd(640, seed=1, dtype=torch.float32), 0.1 * rnd(640, seed=2, dtype=torch.float32)

@@ -248,6 +248,30 @@ def bench_gemmscale(ops):
     ops.lib.a3d_tune_gemm(8)
 
 
+def bench_flash16(_ops):
+    """fp16 storage: LDS-DMA kernels with the sampled max-free pass (default) against the round-2 kernels, BASELINE config-2 launch shapes."""
+    ops = HipOps(act_dtype=torch.float16)
+    print("== fp16 storage flash attention: default (LDS-DMA, sampled max-free) vs round-2 kernels; median ms / TFLOP/s; err = rel L2 vs round-2 kernel")
+    for (D, n, F, L, b, old) in ((40, 4, 16, 4096, 2, 19), (80, 4, 16, 1024, 2, 8)):
+        heads, C = 8, 8 * D
+        rows = b * n * F * L
+        for scale in (1.0, 2.0):
+            qkv = (torch.randn(rows, 3 * C, device="cuda") * scale).to(torch.float16)
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            qm = RowMap(F, n * F * L, L, L, F * L)
+            S, G = n * L, b * F
+            flops = 4.0 * G * S * S * C
+            ops.lib.a3d_tune_flash(old)
+            ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+            for var in (old, 0, old, 0):
+                ops.lib.a3d_tune_flash(var)
+                out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+                err = ((out - ref).norm() / ref.norm()).item()
+                med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5 if D == 40 else 10)
+                print(f"f16 D={D:3d} S={S:5d} scale={scale} var={var:2d}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
+    ops.lib.a3d_tune_flash(0)
+
+
 def bench_fill(ops):
     print("== persistent kernel on partially filled grids: median ms for 128x128 classic | persistent (a3d_tune_gemm(300 + 40): min fill 40 %)")
     def ab(fn):
@@ -375,7 +399,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale,
+         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
