@@ -138,11 +138,20 @@ class _Conv3x3(torch.autograd.Function):
 
 class _FlashAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, aops, q, k, v, out_in, qmap, kmap, groups, heads, q_len, kv_len, out_scale):
+    def forward(ctx, aops, q, k, v, out_in, qmap, kmap, groups, heads, q_len, kv_len, out_scale, may_keep_out=True):
         ctx.aops, ctx.args = aops, (qmap, kmap, groups, heads, q_len, kv_len, out_scale)
-        ctx.save_for_backward(q, k, v)
         if out_in is None:
+            # the forward hands its log-sum-exp to the backward (and autograd keeps the output anyway, as the next GEMM's input): the
+            # backward's statistics pass — a third of its time at head_dim 40 — is not run
+            if aops.keep_lse and may_keep_out:
+                o, lse = aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out_scale=out_scale, with_lse=True)
+                ctx.save_for_backward(q, k, v, o, lse)
+                return o
+            ctx.save_for_backward(q, k, v)
             return aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out_scale=out_scale)
+        # accumulated into a caller's buffer (the IP-Adapter image tokens on top of the text attention): that buffer is not this
+        # attention's output, the backward recomputes the statistics
+        ctx.save_for_backward(q, k, v)
         aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out=out_in, out_scale=out_scale, accumulate=True)
         ctx.mark_dirty(out_in)
         return out_in
@@ -150,7 +159,8 @@ class _FlashAttn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         base = ctx.aops.base
-        q, k, v = ctx.saved_tensors
+        q, k, v, *kept = ctx.saved_tensors
+        o, lse = kept if kept else (None, None)
         qmap, kmap, groups, heads, q_len, kv_len, out_scale = ctx.args
         need = ctx.needs_input_grad
         dq = dk = dv = None
@@ -159,8 +169,8 @@ class _FlashAttn(torch.autograd.Function):
             # the F frames of a video in the first-frame branches
             g_share = kmap.gdiv if (kmap.gb == 0 and kmap.gdiv > 1 and groups % kmap.gdiv == 0) else 1
             dq, dk, dv = base.flash_attn_bwd(q, k, v, _c(dy), qmap, kmap, groups, heads, q_len, kv_len, q_per_kv=g_share, do_scale=out_scale,
-                                             need_dq=need[1], need_dkv=need[2] or need[3])
-        return None, dq, dk, dv, (dy if need[4] else None), None, None, None, None, None, None, None
+                                             need_dq=need[1], need_dkv=need[2] or need[3], **({} if lse is None else dict(o=o, lse=lse)))
+        return None, dq, dk, dv, (dy if need[4] else None), None, None, None, None, None, None, None, None
 
 
 class _TemporalAttn(torch.autograd.Function):
@@ -266,6 +276,8 @@ class AutogradOps:
     def __init__(self, base):
         self.base = base
         self._persistent = {}       # data_ptr -> (weight, derived operand): frozen weights of the persistent pack only
+        self.keep_lse = bool(getattr(base, "has_attn_lse", False))     # forward log-sum-exp -> backward (HipOps; the torch reference op set has none)
+        self._host_scalars = {}     # id(0-dim tensor) -> (tensor, python float): merge weights read back in ONE transfer per step
 
     flash_attn2 = None       # no differentiable fused text + image-token attention: the UNet issues the two differentiable calls
 
@@ -304,12 +316,26 @@ class AutogradOps:
             return out
         return self._cached(w, "ds", make)
 
+    def prefetch_scalars(self, tensors):
+        """The kernels take merge weights by value (``a3d_gemm``'s ``alpha``): a trainable weight (AlphaBlender ``mix_factor``) has to be read
+        back from the device.  One ``float(t)`` per GEMM is a host synchronisation in the middle of the forward (~130 per training step:
+        the launch queue drains every time); this reads all of them in one transfer before the forward starts."""
+        ts = [t for t in tensors if torch.is_tensor(t)]
+        self._host_scalars = {}
+        if ts:
+            vals = torch.stack([t.detach().float().reshape(()) for t in ts]).tolist()
+            self._host_scalars = {id(t): (t, v) for t, v in zip(ts, vals)}       # (the tensor is kept alive so that its id stays its own)
+
+    def _scalar(self, t) -> float:
+        hit = self._host_scalars.get(id(t))
+        return hit[1] if hit is not None and hit[0] is t else float(t.detach())
+
     # ---- the op set
     def gemm(self, x, w, bias=None, *, residual=None, alpha=1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None):
         if out is not None:
             raise NotImplementedError("gemm(out=...) has no autograd form")
         alpha_t = alpha if torch.is_tensor(alpha) else None
-        return _Gemm.apply(self, x, w, bias, residual, rowbias, alpha_t, float(alpha.detach()) if alpha_t is not None else float(alpha), beta, rb_div)
+        return _Gemm.apply(self, x, w, bias, residual, rowbias, alpha_t, self._scalar(alpha) if alpha_t is not None else float(alpha), beta, rb_div)
 
     def gemm_geglu(self, x, w_il, bias_il):
         return _GemmGeglu.apply(self, x, w_il, bias_il)
@@ -320,12 +346,14 @@ class AutogradOps:
         return y, (He - 1) // stride + 1, (We - 1) // stride + 1
 
     def flash_attn(self, q, k, v, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
-                   out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False):
+                   out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False, accumulation_target: bool = False):
+        """``accumulation_target``: a later call will add into this call's result in place (the IP-Adapter attention on top of the text
+        attention): the result then is not this attention's output any more and must not be kept for the backward."""
         if causal:
             raise NotImplementedError("causal attention (CLIP text tower) is not on the training path")
         if (out is None) != (not accumulate):
             raise NotImplementedError("flash_attn(out=...) is differentiable only as an accumulation into an existing result")
-        return _FlashAttn.apply(self, q, k, v, out, qmap, kmap, groups, heads, q_len, kv_len, out_scale)
+        return _FlashAttn.apply(self, q, k, v, out, qmap, kmap, groups, heads, q_len, kv_len, out_scale, not accumulation_target)
 
     def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int, *, q_f0: int = 0, q_frames=None):
         if q_frames is not None and q_frames != frames:

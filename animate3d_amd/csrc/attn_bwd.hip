@@ -422,6 +422,28 @@ int dispatch(hipStream_t s, const BwdParams& p, int head_dim, int groups_y) {
   }
 }
 
+// delta[g][h][q] = sum_d dO[row(q)][h D + d] * O[row(q)][h D + d]: the row sums  sum_k P_qk dP_qk  of the statistics pass taken from the
+// forward's output instead (dO V^T P^T = dO · (P V) = dO · O / out_scale, times do_scale = out_scale), for callers that kept O and the
+// forward's log-sum-exp (a3d_flash_attn_lse).  One thread per (query, head); the heads of a row are adjacent threads.
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ dO, const uint16_t* __restrict__ O, const a3d_rowmap dom,
+                                                         const a3d_rowmap om, float* __restrict__ delta, int heads, int q_len) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t grp = blockIdx.y;
+  if (t >= (int64_t)q_len * heads) return;
+  const int q = (int)(t / heads), h = (int)(t % heads);
+  const u32x4_t* a = reinterpret_cast<const u32x4_t*>(dO + map_row(dom, grp, q) * dom.ld + (int64_t)h * D);
+  const u32x4_t* b = reinterpret_cast<const u32x4_t*>(O + map_row(om, grp, q) * om.ld + (int64_t)h * D);
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < D / 8; ++i) {
+    const u32x4_t x = a[i], y = b[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = fmaf(lo16(x[e]), lo16(y[e]), fmaf(hi16(x[e]), hi16(y[e]), acc));
+  }
+  delta[(grp * heads + h) * q_len + q] = acc;
+}
+
 bool map_ok(const a3d_rowmap* m, int head_dim, int heads) {
   return m && m->gdiv > 0 && m->seg_len > 0 && m->ld >= (int64_t)heads * head_dim && m->ld % 8 == 0;
 }
@@ -449,10 +471,32 @@ extern "C" int A3D_FN(a3d_flash_attn_bwd)(a3d_stream_t stream, const void* Q, co
   p.qm = *qmap; p.km = *kmap; p.dom = *domap;
   p.dqm = dQ ? *dqmap : *qmap; p.dkm = dK ? *dkmap : *kmap;
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len; p.q_per_kv = q_per_kv;
-  p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.do_scale = do_scale; p.accumulate = accumulate;
+  // accumulate: bit 0 = add to dQ / dK / dV; bit 1 = lse2 and delta hold the statistics already (a3d_flash_attn_lse + a3d_attn_delta):
+  // the statistics pass (a third of the backward's time at head_dim 40) is skipped
+  p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f; p.do_scale = do_scale; p.accumulate = accumulate & 1;
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = dispatch<MODE_STATS>(s, p, head_dim, groups)) return rc;
+  if (!((accumulate >> 1) & 1)) {
+    if (int rc = dispatch<MODE_STATS>(s, p, head_dim, groups)) return rc;
+  }
   if (dQ) { if (int rc = dispatch<MODE_DQ>(s, p, head_dim, groups)) return rc; }
   if (dK) { if (int rc = dispatch<MODE_DKV>(s, p, head_dim, groups / q_per_kv)) return rc; }
   return A3D_OK;
+}
+
+extern "C" int A3D_FN(a3d_attn_delta)(a3d_stream_t stream, const void* dO, const void* O, const a3d_rowmap* domap, const a3d_rowmap* omap,
+                                       float* delta, int groups, int heads, int head_dim, int64_t q_len) {
+  if (!dO || !O || !delta || groups <= 0 || groups > 65535 || heads <= 0 || q_len <= 0 || q_len > 0x7fffffffLL) return A3D_EINVAL;
+  if (!map_ok(domap, head_dim, heads) || !map_ok(omap, head_dim, heads)) return A3D_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(dO) | reinterpret_cast<uintptr_t>(O)) & 15u) return A3D_EINVAL;
+  const int64_t n = q_len * heads;
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)groups);
+  hipStream_t s = (hipStream_t)stream;
+  switch (head_dim) {
+    case 40: attn_delta_kernel<40><<<grid, dim3(256), 0, s>>>((const uint16_t*)dO, (const uint16_t*)O, *domap, *omap, delta, heads, (int)q_len); break;
+    case 64: attn_delta_kernel<64><<<grid, dim3(256), 0, s>>>((const uint16_t*)dO, (const uint16_t*)O, *domap, *omap, delta, heads, (int)q_len); break;
+    case 80: attn_delta_kernel<80><<<grid, dim3(256), 0, s>>>((const uint16_t*)dO, (const uint16_t*)O, *domap, *omap, delta, heads, (int)q_len); break;
+    case 160: attn_delta_kernel<160><<<grid, dim3(256), 0, s>>>((const uint16_t*)dO, (const uint16_t*)O, *domap, *omap, delta, heads, (int)q_len); break;
+    default: return A3D_EUNSUPPORTED;
+  }
+  return a3d_launch_status();
 }

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   else compute((ntiles - 1) & 1, (ntiles - 1) * BKV, std::false_type{}, FM_LOOP);
 
   // ---- finalize: lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j] for each query sub-tile
-  float inv[QT];
+  float inv[QT], l_fin[QT];
   bool bad = false;
 #pragma unroll
   for (int qs = 0; qs < QT; ++qs) {
@@ -494,9 +494,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
     }
     bad = bad || !(l_tot < 1.2676506e30f) || !(l_tot > 0.f);
     inv[qs] = oscale / l_tot;
+    l_fin[qs] = l_tot;
   }
   if constexpr (NOMAX) {
     if (__syncthreads_or(bad ? 1 : 0)) return false;       // (every wave is also done with the LDS images)
+  }
+  if constexpr (!TWO) {
+    if (p.lse != nullptr) {      // training: log2 of the softmax denominator (m_off: raw-score maximum in the fma form, else the log2-domain offset)
+#pragma unroll
+      for (int qs = 0; qs < QT; ++qs)
+        if (q_ok[qs] && g == 0)
+          p.lse[((int64_t)grp * p.heads + head) * p.q_len + q_idx[qs]] =
+              __builtin_amdgcn_logf(l_fin[qs]) + (OFS == OFS_FMA ? m_off[qs] * p.scale_log2 : m_off[qs]);
+    }
   }
   if constexpr (TWO && !SET1) {
     if (p.K2 != nullptr) {                                 // first key set of two: keep the normalised result in registers
@@ -1320,10 +1330,10 @@ extern "C" int a3d_tune_flash(int variant) {
 }
 #endif
 
-extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
-                                   const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
-                                   int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
-                                   float scale, float out_scale, int accumulate) {
+static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                           const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                           int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                           float scale, float out_scale, int accumulate, float* lse) {
   if (!Q || !K || !V || !O || groups <= 0 || heads <= 0 || q_len <= 0 || kv_len <= 0) return A3D_EINVAL;
   if (!map_ok(qmap, head_dim) || !map_ok(kmap, head_dim) || !map_ok(omap, head_dim)) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15u) return A3D_EINVAL;
@@ -1334,7 +1344,9 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
   p.qm = *qmap; p.km = *kmap; p.om = *omap;
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len;
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate & 1; p.causal = (accumulate >> 1) & 1;
+  p.lse = lse;
   if (p.causal && head_dim != 64 && head_dim != 160) return A3D_EUNSUPPORTED;     // offered on the raw-score (fma) kernels only
+  const bool no_lse = lse == nullptr;      // the log-sum-exp output exists in the LDS-DMA kernels and in the plain kernel only
   const int bkv = head_dim == 160 ? 32 : 64;
   const bool aligned = (kmap->seg_len % bkv == 0) || (kv_len <= kmap->seg_len);
   hipStream_t s = (hipStream_t)stream;
@@ -1369,7 +1381,7 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
       }
       // interleaved kernel (default for the long aligned shapes): 8 waves x 64 queries; A/B variants 7 = 4 waves x 64, 13 = 4 x 128,
       // 15 = 8 x 32; 16 = the ping-pong kernel instead
-      if (g_flash_variant != 5 && g_flash_variant != 16 && aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512) {
+      if (no_lse && g_flash_variant != 5 && g_flash_variant != 16 && aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 512) {
         int rc = 0;
         if (g_flash_variant == 7) rc = launch_il<2, 4>(groups, s, p);
         else if (g_flash_variant == 13) rc = launch_il<4, 4>(groups, s, p);
@@ -1378,7 +1390,7 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
         if (rc != A3D_OK) return rc;
         break;
       }
-      if (g_flash_variant != 5 && aligned && kv_len % 64 == 0 && kv_len >= 128 && q_len >= 512) {
+      if (no_lse && g_flash_variant != 5 && aligned && kv_len % 64 == 0 && kv_len >= 128 && q_len >= 512) {
         const int q_tiles = (int)((q_len + 511) / 512);
         const dim3 grid((unsigned)(heads * q_tiles), (unsigned)groups);
         switch (g_flash_variant) {
@@ -1422,6 +1434,24 @@ extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const 
     default: return A3D_EUNSUPPORTED;
   }
   return a3d_launch_status();
+}
+
+extern "C" int A3D_FN(a3d_flash_attn)(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                                   const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                                   int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                                   float scale, float out_scale, int accumulate) {
+  return flash_attn_impl(stream, Q, K, V, O, qmap, kmap, omap, groups, heads, head_dim, q_len, kv_len, scale, out_scale, accumulate, nullptr);
+}
+
+// Training forward: the same attention, and per query the log2 of its softmax denominator (lse2 [groups][heads][q_len] floats) —
+// what a3d_flash_attn_bwd's statistics pass would recompute.  The row sum comes out of the kernel's own accumulators, so this costs one
+// float store per query and head.
+extern "C" int A3D_FN(a3d_flash_attn_lse)(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                                       const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                                       int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                                       float scale, float out_scale, int accumulate, float* lse2) {
+  if (!lse2) return A3D_EINVAL;
+  return flash_attn_impl(stream, Q, K, V, O, qmap, kmap, omap, groups, heads, head_dim, q_len, kv_len, scale, out_scale, accumulate, lse2);
 }
 
 // Two key sets in one launch: O = out_scale * softmax(Q K^T * scale) V + out_scale2 * softmax(Q K2^T * scale) V2 (+ previous O if

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
   // row sums (O^T row 40): 32x32 layout: register 4 of the second row tile, half 0 (query l31); 16x16 layout: register 0 of row
   // tile 2 in lanes 32..47 (query i16 of block nb).  Returns 1 / sum scaled for the store; `bad` = sum unusable (max-free pass).
   constexpr int NINV = PV16 ? 2 * QT : QT;
+  float l_row[NINV];
   auto row_sums = [&](float (&inv)[NINV]) __attribute__((always_inline)) -> bool {
     bool bad = false;
 #pragma unroll
@@ -319,8 +320,22 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
       else l_tot = __shfl(oacc[i][1][4], l31);
       bad = bad || !(l_tot < DM_L_BAD) || !(l_tot > 0.f);
       inv[i] = p.out_scale / l_tot;
+      l_row[i] = l_tot;
     }
     return bad;
+  };
+  // training: log2 of the softmax denominator per query = offset + log2(row sum); the offset of query l31 of sub-tile qs is what the
+  // lanes of half G_PAD carry (negated, 16 bits) in contraction slot 40 of their Q fragment
+  auto store_lse = [&]() __attribute__((always_inline)) {
+    if (p.lse == nullptr) return;
+#pragma unroll
+    for (int i = 0; i < NINV; ++i) {
+      const int qs = PV16 ? i / 2 : i, ql = PV16 ? 16 * (i % 2) + i16 : l31;
+      const float noff = lo16((uint32_t)__shfl((int)qf[qs][KS_PAD][0], 32 * G_PAD + ql));
+      const int q_idx = qt * BQ + wid * 32 * QT + 32 * qs + ql;
+      if (q_idx < p.q_len && (PV16 ? q4 == 0 : g == 0))
+        p.lse[((int64_t)grp * p.heads + head) * p.q_len + q_idx] = __builtin_amdgcn_logf(l_row[i]) - noff;
+    }
   };
   auto store4 = [&](uint16_t* dst, float v0, float v1, float v2, float v3) __attribute__((always_inline)) {
     if (p.accumulate) {
@@ -508,6 +523,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
     const bool bad = row_sums(inv);
     if (__syncthreads_or(bad ? 1 : 0)) return false;          // (also: every wave is done with the LDS images)
     store_out(inv);
+    store_lse();
     return true;
   };
 
@@ -585,6 +601,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
     float inv[NINV];
     row_sums(inv);
     store_out(inv);
+    store_lse();
   };
 
   __syncthreads();        // constant region written

@@ -215,6 +215,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
       if (__syncthreads_or(bad ? 1 : 0)) return false;          // (also: every wave is done with the LDS images)
     }
     const float inv = p.out_scale / l_tot;
+    if (p.lse != nullptr && q_idx < p.q_len && g == 0)      // training: log2 of the softmax denominator (minit = -offset in every lane)
+      p.lse[((int64_t)grp * p.heads + head) * p.q_len + q_idx] = __builtin_amdgcn_logf(l_tot) - minit[0];
     if (q_idx < p.q_len) {      // lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j]
       uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
 #pragma unroll

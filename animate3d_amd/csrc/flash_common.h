@@ -15,6 +15,9 @@ struct AttnParams {
   // second key set (a3d_flash_attn2: text tokens + IP-Adapter image tokens in one launch): O = out_scale * attn(Q, K, V) +
   // out_scale2 * attn(Q, K2, V2), each with its own softmax.  K2 == nullptr: single key set.
   const uint16_t* K2; const uint16_t* V2; a3d_rowmap km2; int kv_len2; float out_scale2;
+  // training (a3d_flash_attn_lse): per query log2 sum_k 2^(s_qk * scale * log2 e), [groups][heads][q_len] floats, as the backward's
+  // statistics pass would compute it (attn_bwd.hip); nullptr: not wanted
+  float* lse;
 };
 
 namespace {

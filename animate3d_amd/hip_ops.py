@@ -73,6 +73,9 @@ _SIGNATURES = {
     "a3d_flash_attn_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                         ctypes.POINTER(_RowMapC), c_int, c_int, c_int, c_i64, c_i64, c_int, c_f32, c_f32, c_int]),
+    "a3d_flash_attn_lse_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
+                                        c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int, c_vp]),
+    "a3d_attn_delta_bf16": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), c_vp, c_int, c_int, c_int, c_i64]),
     "a3d_temporal_attn_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
     "a3d_layer_norm_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_int]),
     "a3d_group_norm_bwd_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int]),
@@ -165,6 +168,8 @@ class HipOps:
     what a model cast with ``.half()`` gets, as the reference's 4D-SDS caller does, animatemv_guidance.py:339-346).  Both use
     fp32 accumulation, statistics and softmax; an fp16 model keeps 11 significant bits where bf16 keeps 8."""
 
+    has_attn_lse = True      # flash_attn(with_lse=True) / flash_attn_bwd(o=..., lse=...): see autograd_ops._FlashAttn
+
     def __init__(self, device: Optional[torch.device] = None, act_dtype: torch.dtype = torch.bfloat16):
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a visible MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
@@ -255,13 +260,23 @@ class HipOps:
 
     # ---- attention
     def flash_attn(self, q, k, v, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
-                   out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False):
+                   out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False, with_lse: bool = False,
+                   accumulation_target: bool = False):
+        """``accumulation_target`` is a hint for the autograd op set (autograd_ops.AutogradOps.flash_attn), ignored here.  ``with_lse``: returns (o, lse2) with lse2 [groups, heads, q_len] fp32 = log2 of every query's softmax denominator (training:
+        ``flash_attn_bwd(stats=...)`` then skips its statistics pass)."""
         q, k, v = self._act(q, "attn.q"), self._act(k, "attn.k"), self._act(v, "attn.v")
         C = q.shape[1]
         D = C // heads
         assert k.stride(0) == v.stride(0)
         o = out if out is not None else self.empty(q.shape[0], C)
         qm, km, om = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(o.stride(0))
+        if with_lse:
+            lse = torch.empty((groups, heads, q_len), dtype=torch.float32, device=self.device)
+            rc = self.lib.a3d_flash_attn_lse_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
+                                                  groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale,
+                                                  (1 if accumulate else 0) | (2 if causal else 0), _p(lse))
+            _check(rc, f"a3d_flash_attn_lse_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
+            return o, lse
         rc = self.lib.a3d_flash_attn_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
                                           groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, (1 if accumulate else 0) | (2 if causal else 0))
         _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
@@ -437,10 +452,11 @@ class HipOps:
 
     # ---- training path: backward kernels (reference: torch autograd behind train.py:576-590) and the optimiser step
     def flash_attn_bwd(self, q, k, v, do, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
-                       q_per_kv: int = 1, do_scale: float = 1.0, need_dq: bool = True, need_dkv: bool = True):
+                       q_per_kv: int = 1, do_scale: float = 1.0, need_dq: bool = True, need_dkv: bool = True, o=None, lse=None):
         """Gradients of ``flash_attn`` (same maps): ``do`` = gradient of the output buffer (rows as q), scaled by ``do_scale`` (= the
         forward's out_scale).  Returns (dq [q rows, C] | None, dk, dv [k rows, C] | None); rows of dk / dv that the K/V map never
-        reads (e.g. frames > 0 in the first-frame branch) are zero."""
+        reads (e.g. frames > 0 in the first-frame branch) are zero.  ``o`` / ``lse`` (the un-accumulated output and the log-sum-exp of
+        ``flash_attn(with_lse=True)``): the statistics pass is replaced by one elementwise kernel (delta = rowsum(dO * O) per head)."""
         q, k, v, do = self._act(q, "attn_bwd.q"), self._act(k, "attn_bwd.k"), self._act(v, "attn_bwd.v"), self._act(do, "attn_bwd.do")
         C = q.shape[1]
         D = C // heads
@@ -449,12 +465,23 @@ class HipOps:
         dq = (self.empty(q.shape[0], C) if q.shape[0] == groups * q_len else torch.zeros((q.shape[0], C), dtype=self.act_dtype, device=self.device)) if need_dq else None
         dk = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
         dv = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
-        stats = torch.empty((2, groups * heads * q_len), dtype=torch.float32, device=self.device)
         qm, km, dom = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(do.stride(0))
         dqm, dkm = qmap.c(C), kmap.c(C)
-        rc = self.lib.a3d_flash_attn_bwd_bf16(self._stream(), _p(q), _p(k), _p(v), _p(do), _p(dq), _p(dk), _p(dv), _p(stats[0]), _p(stats[1]),
+        flags = 0
+        if lse is not None:
+            assert o is not None and lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == groups * heads * q_len
+            o = self._act(o, "attn_bwd.o")
+            lse2, delta = lse, torch.empty(groups * heads * q_len, dtype=torch.float32, device=self.device)
+            om = qmap.c(o.stride(0))
+            rc = self.lib.a3d_attn_delta_bf16(self._stream(), _p(do), _p(o), ctypes.byref(dom), ctypes.byref(om), _p(delta), groups, heads, D, q_len)
+            _check(rc, f"a3d_attn_delta_bf16 groups={groups} heads={heads} D={D} q_len={q_len}")
+            flags = 2
+        else:
+            stats = torch.empty((2, groups * heads * q_len), dtype=torch.float32, device=self.device)
+            lse2, delta = stats[0], stats[1]
+        rc = self.lib.a3d_flash_attn_bwd_bf16(self._stream(), _p(q), _p(k), _p(v), _p(do), _p(dq), _p(dk), _p(dv), _p(lse2), _p(delta),
                                               ctypes.byref(qm), ctypes.byref(km), ctypes.byref(dom), ctypes.byref(dqm), ctypes.byref(dkm),
-                                              groups, heads, D, q_len, kv_len, q_per_kv, float(D) ** -0.5, do_scale, 0)
+                                              groups, heads, D, q_len, kv_len, q_per_kv, float(D) ** -0.5, do_scale, flags)
         _check(rc, f"a3d_flash_attn_bwd_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len} q_per_kv={q_per_kv}")
         return dq, dk, dv
 

@@ -172,12 +172,8 @@ def add_noise(x: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor, alp
     return a.sqrt().reshape(shape) * x + (1.0 - a).sqrt().reshape(shape) * noise
 
 
-def training_step(unet, optimizer: FlatAdamW, latents: torch.Tensor, text_embeds: torch.Tensor, cameras: torch.Tensor,
-                  image_embeds: Optional[torch.Tensor], *, alphas_cumprod: torch.Tensor, num_views: int, i2v_cond_time_zero: bool = False,
-                  generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None,
-                  timesteps: Optional[torch.Tensor] = None, group=None) -> Dict[str, float]:
-    """One optimisation step, train.py:538-596.  ``latents`` [b, n, c, f, h, w] (scaled VAE latents), ``text_embeds`` [b, 77, 768],
-    ``cameras`` [(b n), 16], ``image_embeds`` [(b n), 1024] or None.  ``unet.enable_training()`` must have been called."""
+def _sample_batch(latents: torch.Tensor, text_embeds: torch.Tensor, alphas_cumprod: torch.Tensor, generator, noise, timesteps):
+    """train.py:540-569: noise on every frame but the first, one timestep per batch element, text states repeated per view."""
     b, n, c, f, h, w = latents.shape
     dev = latents.device
     first, rest = latents[:, :, :, 0:1], latents[:, :, :, 1:]                               # :540-543 first frame stays clean
@@ -190,12 +186,28 @@ def training_step(unet, optimizer: FlatAdamW, latents: torch.Tensor, text_embeds
     noisy = noisy.reshape(b * n, c, f, h, w)
     ehs = text_embeds[:, None].expand(b, n, *text_embeds.shape[1:]).reshape(b * n, *text_embeds.shape[1:])      # :565-566
     t = timesteps[:, None].expand(b, n).reshape(b * n)                                          # :568-569
+    return noisy, t, ehs, noise
+
+
+def _loss(unet, noisy, t, ehs, cameras, image_embeds, noise, shape, num_views: int, i2v_cond_time_zero: bool) -> torch.Tensor:
+    """train.py:572-577: UNet prediction, MSE against the noise on the noisy frames."""
+    b, n, c, f, h, w = shape
     added = None if image_embeds is None else {"image_embeds": image_embeds}
-    optimizer.zero_grad()
     pred = unet(noisy, t, encoder_hidden_states=ehs, camera=cameras, num_views=num_views, added_cond_kwargs=added,
                 i2v_cond_time_zero=i2v_cond_time_zero).sample                                   # :572-573
     pred = pred.reshape(b, n, c, f, h, w)[:, :, :, 1:]
-    loss = F.mse_loss(pred.float(), noise.float(), reduction="mean")                          # :576-577
+    return F.mse_loss(pred.float(), noise.float(), reduction="mean")                          # :576-577
+
+
+def training_step(unet, optimizer: FlatAdamW, latents: torch.Tensor, text_embeds: torch.Tensor, cameras: torch.Tensor,
+                  image_embeds: Optional[torch.Tensor], *, alphas_cumprod: torch.Tensor, num_views: int, i2v_cond_time_zero: bool = False,
+                  generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None,
+                  timesteps: Optional[torch.Tensor] = None, group=None) -> Dict[str, float]:
+    """One optimisation step, train.py:538-596.  ``latents`` [b, n, c, f, h, w] (scaled VAE latents), ``text_embeds`` [b, 77, 768],
+    ``cameras`` [(b n), 16], ``image_embeds`` [(b n), 1024] or None.  ``unet.enable_training()`` must have been called."""
+    noisy, t, ehs, noise = _sample_batch(latents, text_embeds, alphas_cumprod, generator, noise, timesteps)
+    optimizer.zero_grad()
+    loss = _loss(unet, noisy, t, ehs, cameras, image_embeds, noise, latents.shape, num_views, i2v_cond_time_zero)
     optimizer.scale(loss).backward()
     world = optimizer.all_reduce_grads(group)
     info = optimizer.step(world)

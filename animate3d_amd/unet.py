@@ -457,6 +457,8 @@ class MVUNetMotionModel(nn.Module):
             # merge weights: python floats for inference; under _pack_train the trainable mix_factor stays a tensor (its
             # gradient comes out of the to_out GEMMs' backward)
             ct, cs, ci = pr.blend_coefficients_t() if self._pack_grad else pr.blend_coefficients()
+            if self._pack_grad:
+                self._coef_tensors.extend(c for c in (ct, cs, ci) if torch.is_tensor(c))
             ns = SimpleNamespace(
                 heads=a.heads, spatial=pr.use_spatial_attn, image=pr.use_image_attn,
                 spatial_pe=pr.use_spatial_attn and pr.use_spatial_encoding, camera_pe=pr.use_spatial_attn and pr.use_camera_encoding,
@@ -677,7 +679,7 @@ class MVUNetMotionModel(nn.Module):
             ca = fused(q2, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), B2, pk.heads,
                        L, T, nt, out_scale2=pk.ip_scale[0])
         if ca is None:
-            ca = ops.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), B2, pk.heads, L, T)
+            ca = ops.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), B2, pk.heads, L, T, accumulation_target=bool(ip_rows))
             for ipr, w, scale, nt in zip(ip_rows, pk.kv_ip, pk.ip_scale, pk.ip_tokens):
                 kvi = ops.gemm(ipr, w)
                 ops.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), B2, pk.heads, L, nt,
@@ -877,6 +879,7 @@ class MVUNetMotionModel(nn.Module):
             if trainable(mod):
                 raise NotImplementedError(f"{name} is not trainable on this path (the reference trains 'motion_modules.' and 'i2v.' only)")
         self._pack_grad = True
+        self._coef_tensors = []
         try:
             def block(blk, pf):
                 out = SimpleNamespace(**vars(pf))
@@ -893,6 +896,8 @@ class MVUNetMotionModel(nn.Module):
             P.up = [block(b, q) for b, q in zip(self.up_blocks, Pf.up)]
         finally:
             self._pack_grad = False
+        if self._train_ops is not None:
+            self._train_ops.prefetch_scalars(self._coef_tensors)      # every trainable merge weight in one device -> host transfer
         return P
 
     # ------------------------------------------------------------------ forward

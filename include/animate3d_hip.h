@@ -224,13 +224,26 @@ int a3d_cfg_ddim_step_f32(a3d_stream_t stream, const float* eps_pair, const floa
  * video in the first-frame branch; groups % q_per_kv == 0).  dO is the gradient of the attention output scaled by `do_scale`
  * (the forward's out_scale).  lse2 / delta: fp32 scratch [groups * heads * q_len] each (log2-sum-exp and sum_k P dP per query
  * row, recomputed here: the forward keeps nothing).  dQ may be NULL (no query gradient wanted) or dK == dV == NULL (keys / values
- * of frozen text / image tokens); accumulate != 0 adds into dQ / dK / dV.  head_dim 40 / 64 / 80 / 160. */
+ * of frozen text / image tokens); bit 0 of accumulate adds into dQ / dK / dV, bit 1: see a3d_flash_attn_lse below.  head_dim 40 / 64 / 80 / 160. */
 int a3d_flash_attn_bwd_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* dO,
                             void* dQ, void* dK, void* dV, float* lse2, float* delta,
                             const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* domap,
                             const a3d_rowmap* dqmap, const a3d_rowmap* dkmap,
                             int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int q_per_kv,
                             float scale, float do_scale, int accumulate);
+
+/* The statistics of the backward without its statistics pass (a third of the attention backward's time at head_dim 40), for callers that
+ * keep the forward's output: a3d_flash_attn_lse is a3d_flash_attn that also returns lse2 [groups][heads][q_len] (log2 of the softmax
+ * denominator per query, out of the kernel's own row sums: one float store per query and head; xformers keeps the same tensor for its
+ * backward); a3d_attn_delta computes delta[g][h][q] = sum_d dO[q][h, d] * O[q][h, d] (dO rows through `domap`, O rows through `omap`,
+ * O = that forward's un-accumulated output).  a3d_flash_attn_bwd with bit 1 of `accumulate` set then reads lse2 / delta instead of
+ * recomputing them. */
+int a3d_flash_attn_lse_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                            const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                            int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                            float scale, float out_scale, int accumulate, float* lse2);
+int a3d_attn_delta_bf16(a3d_stream_t stream, const void* dO, const void* O, const a3d_rowmap* domap, const a3d_rowmap* omap,
+                        float* delta, int groups, int heads, int head_dim, int64_t q_len);
 
 /* Temporal attention backward (attention_processor.py:630-636 under autograd): rows ((v*F + f)*L + l); Q / K / V share the row
  * stride ldqkv, dQ / dK / dV share ldd (e.g. the three column ranges of one [rows, 3C] gradient buffer).  frames <= 32. */
@@ -348,6 +361,12 @@ int a3d_flash_attn_bwd_f16(a3d_stream_t stream, const void* Q, const void* K, co
                             const a3d_rowmap* dqmap, const a3d_rowmap* dkmap,
                             int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int q_per_kv,
                             float scale, float do_scale, int accumulate);
+int a3d_flash_attn_lse_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                           const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                           int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                           float scale, float out_scale, int accumulate, float* lse2);
+int a3d_attn_delta_f16(a3d_stream_t stream, const void* dO, const void* O, const a3d_rowmap* domap, const a3d_rowmap* omap,
+                       float* delta, int groups, int heads, int head_dim, int64_t q_len);
 int a3d_temporal_attn_bwd_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, int64_t ldqkv,
                                const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t ldd,
                                int videos, int frames, int64_t L, int heads, int head_dim, float scale);

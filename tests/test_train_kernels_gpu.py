@@ -68,6 +68,56 @@ def test_flash_attn_bwd_multiview_and_first_frame(ops, ref, C, n, F, L):
     assert float(got[1][fr != 0].abs().max()) == 0.0 and float(got[2][fr != 0].abs().max()) == 0.0
 
 
+def _lse_reference(q, k, qmap, kmap, groups, heads, q_len, kv_len):
+    """log2 sum_k 2^(q.k * scale * log2 e) per (group, head, query), fp32, through the row maps."""
+    C = q.shape[1]
+    D = C // heads
+    out = torch.empty(groups, heads, q_len, device=q.device)
+    for g in range(groups):
+        rows = lambda m, n: (g // m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (torch.arange(n, device=q.device) // m.seg_len) * m.seg_stride + torch.arange(n, device=q.device) % m.seg_len
+        qr, kr = rows(qmap, q_len), rows(kmap, kv_len)
+        qh = q[qr].float().reshape(q_len, heads, D).permute(1, 0, 2)
+        kh = k[kr].float().reshape(kv_len, heads, D).permute(1, 0, 2)
+        s = qh @ kh.transpose(1, 2) * (D ** -0.5)
+        out[g] = torch.logsumexp(s, dim=-1) / math.log(2.0)
+    return out
+
+
+@pytest.mark.parametrize("C,n,F,L", [(320, 4, 2, 256), (320, 2, 2, 96), (640, 4, 2, 256), (640, 2, 3, 40), (1280, 3, 2, 16), (1280, 2, 2, 64)])
+def test_flash_attn_log_sum_exp_feeds_the_backward(ops, ref, C, n, F, L):
+    """a3d_flash_attn_lse (every kernel that serves the training shapes: the LDS-DMA kernels at head_dim 40 / 80 from 256 / 512 keys,
+    the plain kernel elsewhere) returns the log2 softmax denominator per query; with it and a3d_attn_delta (rowsum(dO * O) per head)
+    a3d_flash_attn_bwd skips its statistics pass: same gradients as the recomputing path, multi-view and first-frame maps."""
+    dt, b, heads = ops.act_dtype, 2, 8
+    rows = b * n * F * L
+    kvq = rnd(rows, 3 * C, seed=1, dtype=dt)
+    q, k, v = kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C]
+    do = rnd(rows, C, seed=2, dtype=dt)
+    qm = RowMap(gdiv=F, ga=n * F * L, gb=L, seg_len=L, seg_stride=F * L)
+    k0 = RowMap(gdiv=F, ga=n * F * L, gb=0, seg_len=L, seg_stride=F * L)
+    S, G = n * L, b * F
+    for name, km, share in (("multi-view", qm, 1), ("first-frame", k0, F)):
+        o_plain = ops.flash_attn(q, k, v, qm, km, G, heads, S, S)
+        o, lse = ops.flash_attn(q, k, v, qm, km, G, heads, S, S, with_lse=True)
+        assert torch.equal(o, o_plain)
+        want_lse = _lse_reference(q, k, qm, km, G, heads, S, S)
+        err = float((lse - want_lse).abs().max())
+        print(f"[parity] lse {name} D={C // heads} S={S}: max abs {err:.3e} log2 units")
+        assert err <= (2e-2 if dt == torch.bfloat16 else 4e-3)          # the row sum adds P rounded to 16 bits; Q is pre-scaled in 16 bits at head_dim 40
+        slow = ops.flash_attn_bwd(q, k, v, do, qm, km, G, heads, S, S, q_per_kv=share)
+        fast = ops.flash_attn_bwd(q, k, v, do, qm, km, G, heads, S, S, q_per_kv=share, o=o, lse=lse)
+        want = ref.flash_attn_bwd(q, k, v, do, qm, km, G, heads, S, S)
+        for a, bb, w, t in zip(fast, slow, want, "qkv"):
+            check(f"flash_attn_bwd with forward statistics {name} d{t} D={C // heads}", a, w, ATTN_TOL[dt])
+            check(f"  ... against the recomputing path d{t}", a, bb, ATTN_TOL[dt])
+    # out_scale: O carries it, delta = rowsum(dO * O) needs no correction
+    o, lse = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, out_scale=0.6, with_lse=True)
+    fast = ops.flash_attn_bwd(q, k, v, do, qm, qm, G, heads, S, S, do_scale=0.6, o=o, lse=lse)
+    want = ref.flash_attn_bwd(q, k, v, do, qm, qm, G, heads, S, S, do_scale=0.6)
+    for a, w, t in zip(fast, want, "qkv"):
+        check(f"flash_attn_bwd with forward statistics, out_scale 0.6, d{t}", a, w, ATTN_TOL[dt])
+
+
 @pytest.mark.parametrize("C,T,L", [(320, 77, 50), (640, 16, 50), (1280, 77, 50), (320, 77, 600)])
 def test_flash_attn_bwd_cross_attention_query_only(ops, ref, C, T, L):
     """attention_processor.py:233-270: text / IP tokens are frozen inputs, only dQ is wanted; the IP branch's out_scale scales dO."""

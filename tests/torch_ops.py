@@ -84,7 +84,8 @@ class TorchRefOps:
             y = y + residual.float()
         return self._o(y), Ho, Wo
 
-    def flash_attn(self, q, k, v, qmap, kmap, groups, heads, q_len, kv_len, *, out=None, out_scale=1.0, accumulate=False, causal=False):
+    def flash_attn(self, q, k, v, qmap, kmap, groups, heads, q_len, kv_len, *, out=None, out_scale=1.0, accumulate=False, causal=False,
+                   accumulation_target=False):
         C = q.shape[1]
         D = C // heads
         qi = rowmap_indices(qmap, groups, q_len).to(q.device)
