@@ -255,19 +255,24 @@ class MVUNetMotionModel(nn.Module):
         self.load_state_dict(sd, strict=False)
 
     def save_motion_modules(self, save_directory: str, is_main_process: bool = True, safe_serialization: bool = True, **unused) -> None:
-        """unet_motion_mv_model.py:404-438: write the motion modules as a diffusers MotionAdapter directory
-        (``config.json`` + ``diffusion_pytorch_model.safetensors`` / ``.bin``) that ``MotionAdapter.from_pretrained`` reads back."""
+        """unet_motion_mv_model.py:404-438: write the motion modules in the layout of a diffusers MotionAdapter directory
+        (``config.json`` + ``diffusion_pytorch_model.safetensors`` / ``.bin``): the diffusers layers of every motion module under the
+        adapter's key names plus the sinusoidal ``pos_embed.pe`` buffers a stock ``MotionAdapter`` registers for its transformer blocks
+        (this model computes them on the fly).  Round-tripped here through ``load_motion_modules``; loading the directory with
+        ``MotionAdapter.from_pretrained`` could not be exercised offline (diffusers is not installed in this image).  The processors'
+        own parameters (``to_*_sp``, ``alpha_blender`` ...) are not part of an adapter: they travel in the UNet checkpoint."""
         if not is_main_process:
             return
         import json
         cfg = self.config
         os.makedirs(save_directory, exist_ok=True)
-        # MotionAdapter holds the diffusers layers of the motion modules; the processors' parameters travel in the UNet checkpoint
         sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if self._MOTION_KEY.match(k) and ".processor." not in k}
-        meta = {"_class_name": "MotionAdapter", "block_out_channels": list(cfg.block_out_channels),
+        for k in [k for k in sd if k.endswith(".transformer_blocks.0.attn1.to_q.weight")]:      # one buffer per temporal transformer block
+            sd[k[:-len("attn1.to_q.weight")] + "pos_embed.pe"] = sinusoidal_pos_1d(sd[k].shape[0], cfg.motion_max_seq_length).contiguous()
+        meta = {"_class_name": "MotionAdapter", "_diffusers_version": "0.27.2", "block_out_channels": list(cfg.block_out_channels),
                 "motion_layers_per_block": cfg.layers_per_block, "motion_norm_num_groups": cfg.norm_num_groups,
                 "motion_num_attention_heads": cfg.motion_num_attention_heads, "motion_max_seq_length": cfg.motion_max_seq_length,
-                "use_motion_mid_block": True}
+                "use_motion_mid_block": True, "conv_in_channels": None}
         with open(os.path.join(save_directory, "config.json"), "w") as f:
             json.dump(meta, f, indent=2)
         if safe_serialization:
