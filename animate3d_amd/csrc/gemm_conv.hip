@@ -25,6 +25,7 @@ extern int g_gemm_reserved_cus;
 extern int g_gemm_stagger;
 extern int g_gemm_ring;
 #else
+extern int g_wgrad_dma;       // wgrad.hip
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
                               // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
 int g_conv_chunk_major = 0;  // experiment builds (-DA3D_EXP_CHUNK_MAJOR) only: a3d_tune_gemm(6) tap-major K walk (= the shipped order), (7)
@@ -796,6 +797,7 @@ extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
   if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
   if (bk >= 8 && bk <= 10) { g_gemm_ring = bk - 8; return A3D_OK; }
+  if (bk == 11 || bk == 12) { g_wgrad_dma = bk - 11; return A3D_OK; }
 #ifdef A3D_EXP_CHUNK_MAJOR
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
 #endif

@@ -272,6 +272,25 @@ def bench_flash16(_ops):
     ops.lib.a3d_tune_flash(0)
 
 
+def bench_wgrad(ops):
+    """Weight gradient dW = dY^T X at the train.yaml shapes (4 views x 16 frames x 32x32 latent): round-2 kernel (a3d_tune_gemm(11)) vs the
+    LDS-DMA kernel (12, default)."""
+    print("== wgrad: median ms / TFLOP/s;  round-2 (register staging, v_perm transposition) | LDS-DMA + ds_read_b64_tr_b16")
+    for (M, N, K) in [(65536, 320, 320), (65536, 2560, 320), (65536, 320, 1280), (16384, 640, 640), (16384, 5120, 640), (16384, 640, 2560),
+                      (4096, 1280, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (1024, 1280, 1280)]:
+        dy, x = rnd(M, N), rnd(M, K)
+        fl = 2.0 * M * N * K
+        outs, ref = [], None
+        for mode in (11, 12, 11, 12):
+            ops.lib.a3d_tune_gemm(mode)
+            y = ops.wgrad(dy, x)
+            ref = y if ref is None else ref
+            med, mn = timeit(lambda: ops.wgrad(dy, x), reps=9, warm=2)
+            outs.append(f"{med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
+        ops.lib.a3d_tune_gemm(12)
+        print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(outs))
+
+
 def bench_fill(ops):
     print("== persistent kernel on partially filled grids: median ms for 128x128 classic | persistent (a3d_tune_gemm(300 + 40): min fill 40 %)")
     def ab(fn):
@@ -399,7 +418,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "flash16": bench_flash16,
+         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "wgrad": bench_wgrad, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
