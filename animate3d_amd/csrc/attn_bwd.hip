@@ -14,8 +14,9 @@
 // STATS / DQ, keys in DKV) and holds their two B operands in registers; the ROW side (keys, resp. queries) streams through LDS in
 // tiles of BR rows.  Both score-shaped products of a tile use v_mfma_f32_32x32x16: A = row-side images [row][d] read with the
 // forward's row permutation (kperm), so that the 16 results of a lane are two runs of 8 consecutive rows and P / dS, packed to
-// 16 bits, ARE the B operand of the gradient products (contraction over rows) without any cross-lane movement; their A operand
-// is a transposed image [d][row] of the row-side tensor, written while staging (4 rows x 8 dims per thread, v_perm_b32).
+// 16 bits, ARE the B operand of the gradient products (contraction over rows) without any cross-lane movement; their A operand,
+// the row-side tensor with the row index as contraction, is read from the SAME natural image by ds_read_b64_tr_b16 (round 2 staged a
+// second, transposed image per tensor: every row tile was loaded from global twice and transposed with v_perm_b32 + 8-byte LDS writes).
 // The loads of the next row tile are issued into registers before the current tile's MFMAs and written to LDS after them; a wave owns
 // one or two 32-column sub-tiles (CT) that share every row-side LDS fragment.
 #include "common.h"
@@ -64,21 +65,17 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   constexpr int KS = DK / 16;
   constexpr int MT = (D + 31) / 32;        // 32-row tiles of the transposed gradients
   constexpr int NROW = DK + 8;             // natural image row stride (elements): odd number of 16-B slots
-  constexpr int TROW = BR + 8;             // transposed image row stride
   constexpr int DCH = D / 8;               // 16-byte chunks per row
-  constexpr int N_ELEMS = BR * NROW, T_ELEMS = MT * 32 * TROW;
-  constexpr int NT = (MODE == MODE_STATS) ? 0 : (MODE == MODE_DQ ? 1 : 2);
+  constexpr int N_ELEMS = BR * NROW;
   constexpr int NCH = BR * DCH, NPT = (NCH + 255) / 256;            // natural staging: 16-byte chunks, per thread
-  constexpr int TIT = (BR / 4) * DCH, TPT = (TIT + 255) / 256;      // transposed staging: 4-row x 8-dim items, per thread
   constexpr int WCOLS = 32 * CT;           // columns per wave
-  static_assert((NROW / 8) % 2 == 1 && (TROW / 8) % 2 == 1, "LDS row strides must be an odd number of 16-B slots");
+  static_assert((NROW / 8) % 2 == 1, "the LDS row stride must be an odd number of 16-B slots");
 
-  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * N_ELEMS + (NT > 0 ? NT : 1) * T_ELEMS];
+  // + 64 elements: the transposing reads of the last d block run up to 24 columns past a row's end (results never stored)
+  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * N_ELEMS + 64];
   __shared__ __attribute__((aligned(16))) float rstat[2][BR];
   uint16_t* const N1 = smem;
   uint16_t* const N2 = smem + N_ELEMS;
-  uint16_t* const T1 = smem + 2 * N_ELEMS;
-  uint16_t* const T2 = T1 + (NT > 1 ? T_ELEMS : 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
@@ -147,7 +144,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   for (int c = 0; c < CT; ++c) { m_run[c] = -INFINITY; l_run[c] = 0.f; t_run[c] = 0.f; }
 
   const int nrow_off = kperm(l31) * NROW + 8 * g;
-  const int trow_off = l31 * TROW + 8 * g;
+  // transposing reads: lane (16-lane group q4 = lane >> 4, i16) addresses row 8 g + (i16 >> 2) (+ 4 for the second read), columns 16 (q4 & 1) + 4 (i16 & 3) .. + 3
+  const int tr_off = (8 * g + ((lane & 15) >> 2)) * NROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   // ---- row-tile staging through registers: the loads of tile t+1 are issued before tile t's MFMAs, the LDS writes after them
   const uint16_t* const src_a = ((MODE == MODE_DKV) ? p.Q : p.K) + hoff;      // row-side tensors: (Q, dO) in DKV, (K, V) otherwise
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   const int64_t ld_b = (MODE == MODE_DKV) ? p.dom.ld : p.km.ld;
   const int ntiles = (rlen + BR - 1) / BR;
   const int total_tiles = ntiles * ((MODE == MODE_DKV) ? p.q_per_kv : 1);
-  u32x4_t n1[NPT], n2[NPT], t1r[TPT][4], t2r[MODE == MODE_DKV ? TPT : 1][4];
+  u32x4_t n1[NPT], n2[NPT];
   float stat_r = 0.f;
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int64_t grp_r = (MODE == MODE_DKV) ? grp_c + t / ntiles : grp_c;      // group the row maps see
@@ -184,41 +182,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
         n2[i] = *reinterpret_cast<const u32x4_t*>(src_b + row_b * ld_b + ch * 8);
       }
     }
-    if constexpr (MODE != MODE_STATS) {
-#pragma unroll
-      for (int i = 0; i < TPT; ++i) {
-        const int it = tid + 256 * i;
-        if (TIT % 256 == 0 || it < TIT) {
-          const int rq = it / DCH, ch = it % DCH;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            int64_t row_a, row_b;
-            rows_of(r0 + 4 * rq + j, row_a, row_b);
-            t1r[i][j] = *reinterpret_cast<const u32x4_t*>(src_a + row_a * ld_a + ch * 8);
-            if constexpr (MODE == MODE_DKV) t2r[i][j] = *reinterpret_cast<const u32x4_t*>(src_b + row_b * ld_b + ch * 8);
-          }
-        }
-      }
-    }
     if constexpr (MODE == MODE_DKV) {
       if (tid < 2 * BR) {
         int s = r0 + (tid % BR); if (s >= rlen) s = rlen - 1;
         const int64_t si = (grp_r * p.heads + head) * (int64_t)p.q_len + s;
         stat_r = (tid < BR) ? p.lse2[si] : p.delta[si];
       }
-    }
-  };
-  // transposed staging of 4 rows x 8 dims: word j of a row holds dims 2j (lo) and 2j+1 (hi)
-  auto store_t = [&](uint16_t* T, int ch, int rq, const u32x4_t (&w)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u32x2_t even, odd;
-      even[0] = __builtin_amdgcn_perm(w[1][j], w[0][j], 0x05040100u);
-      even[1] = __builtin_amdgcn_perm(w[3][j], w[2][j], 0x05040100u);
-      odd[0] = __builtin_amdgcn_perm(w[1][j], w[0][j], 0x07060302u);
-      odd[1] = __builtin_amdgcn_perm(w[3][j], w[2][j], 0x07060302u);
-      *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j) * TROW + rq * 4) = even;
-      *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j + 1) * TROW + rq * 4) = odd;
     }
   };
   auto store_tile = [&]() __attribute__((always_inline)) {
@@ -229,16 +198,6 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
         const int r = c / DCH, ch = c % DCH;
         *reinterpret_cast<u32x4_t*>(N1 + r * NROW + ch * 8) = n1[i];
         *reinterpret_cast<u32x4_t*>(N2 + r * NROW + ch * 8) = n2[i];
-      }
-    }
-    if constexpr (MODE != MODE_STATS) {
-#pragma unroll
-      for (int i = 0; i < TPT; ++i) {
-        const int it = tid + 256 * i;
-        if (TIT % 256 == 0 || it < TIT) {
-          store_t(T1, it % DCH, it / DCH, t1r[i]);
-          if constexpr (MODE == MODE_DKV) store_t(T2, it % DCH, it / DCH, t2r[i]);
-        }
       }
     }
     if constexpr (MODE == MODE_DKV) {
@@ -332,11 +291,16 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const u32x4_t f1 = *reinterpret_cast<const u32x4_t*>(T1 + 32 * mt * TROW + trow_off + 32 * u + 16 * h);
+            // A = X^T [d = 32 mt + l31][rows 32 u + 16 h + 8 g .. + 7] straight from the natural image: two transposing reads of 4 rows each
+            const uint16_t* const tsrc = N1 + (32 * u + 16 * h) * NROW + 32 * mt + tr_off;
+            const u32x2_t f1a = lds_tr16_b64(tsrc), f1b = lds_tr16_b64(tsrc + 4 * NROW);
+            const u32x4_t f1 = {f1a[0], f1a[1], f1b[0], f1b[1]};
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc1[c][mt] = mfma32(f1, dsf[c][h], acc1[c][mt]);        // dQ^T += K^T dS^T   /   dK^T += Q^T dS
             if constexpr (MODE == MODE_DKV) {
-              const u32x4_t f2 = *reinterpret_cast<const u32x4_t*>(T2 + 32 * mt * TROW + trow_off + 32 * u + 16 * h);
+              const uint16_t* const tsrc2 = N2 + (32 * u + 16 * h) * NROW + 32 * mt + tr_off;
+              const u32x2_t f2a = lds_tr16_b64(tsrc2), f2b = lds_tr16_b64(tsrc2 + 4 * NROW);
+              const u32x4_t f2 = {f2a[0], f2a[1], f2b[0], f2b[1]};
 #pragma unroll
               for (int c = 0; c < CT; ++c) acc2[c][mt] = mfma32(f2, pf[c][h], acc2[c][mt]);       // dV^T += dO^T P
             }

@@ -77,6 +77,13 @@ A3D_DEV f32x4_t mfma16(const u32x4_t& a, const u32x4_t& b, const f32x4_t& c) {
 #endif
 }
 // row index inside a 32x32 MFMA result for register r of a lane in half g = lane>>5
+// ds_read_b64_tr_b16: within a 16-lane group, lanes 4 j .. 4 j + 3 address row j (8 bytes = 4 columns each); lane i receives column i of
+// the four rows — the transposing LDS read behind every contraction-over-rows MFMA operand
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+A3D_DEV u32x2_t lds_tr16_b64(const uint16_t* ptr) {
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)ptr));
+}
+
 A3D_DEV int mfma_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
 // bijective XCD-aware remap of a 1-D grid: block b runs on XCD b % 8; give every XCD a

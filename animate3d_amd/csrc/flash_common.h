@@ -44,10 +44,6 @@ A3D_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::
 template <int N, typename F>
 A3D_DEV void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
-typedef short v4i16_t __attribute__((ext_vector_type(4)));
-A3D_DEV u32x2_t lds_tr16_b64(const uint16_t* ptr) {
-  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)ptr));
-}
 A3D_DEV float vmax3(float a, float b, float c) {      // no NaN canonicalisation of the MFMA results (fmaxf adds a v_max per input)
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

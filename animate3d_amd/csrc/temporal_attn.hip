@@ -191,10 +191,6 @@ A3D_DEV f32x4_t mfma16k16(const u32x2_t& a, const u32x2_t& b, const f32x4_t& c) 
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
 #endif
 }
-typedef short v4i16_t __attribute__((ext_vector_type(4)));
-A3D_DEV u32x2_t ta_lds_tr16_b64(const uint16_t* ptr) {
-  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)ptr));
-}
 
 // Matrix-core version (round 3): the same staging (every token byte read from HBM once), then per (pixel, head) S^T = K·Q^T and
 // O^T = V^T·P^T on v_mfma_f32_16x16x16 — 6 MFMAs per head at 16 frames / head_dim 40 instead of ~1 000 v_dot2 / v_fma per thread, which
@@ -326,7 +322,7 @@ __global__ __launch_bounds__(NSL * FP) void temporal_attn_mfma_kernel(const TAPa
 #pragma unroll
       for (int jb = 0; jb < FB; ++jb) {
         const int fj = 16 * jb + 4 * k4 + (i16 >> 2) < F ? 16 * jb + 4 * k4 + (i16 >> 2) : F - 1;      // masked keys carry P = 0
-        vfr[jb] = ta_lds_tr16_b64(Vs + (size_t)fj * ROWB + hc + 16 * db + 4 * (i16 & 3));
+        vfr[jb] = lds_tr16_b64(Vs + (size_t)fj * ROWB + hc + 16 * db + 4 * (i16 & 3));
       }
 #pragma unroll
       for (int ib = 0; ib < FB; ++ib) {

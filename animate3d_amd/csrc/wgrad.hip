@@ -14,7 +14,6 @@
 // staging (4 rows x 8 columns per thread, v_perm_b32 + 8-byte LDS writes — the forward attention's V^T path), double-buffered in
 // LDS with register prefetch of the next 32 rows; one barrier per step.  4 waves = 2 x 2, each 64 x 64 of the tile.
 #include "gemm_common.h"      // LDS-DMA helpers (glds16_v, lds_addr), the zero page
-#include "flash_common.h"     // lds_tr16_b64
 
 #ifdef A3D_STORAGE_F16
 extern int g_wgrad_dma;
