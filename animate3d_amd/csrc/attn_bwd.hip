@@ -72,10 +72,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   static_assert((NROW / 8) % 2 == 1, "the LDS row stride must be an odd number of 16-B slots");
 
   // + 64 elements: the transposing reads of the last d block run up to 24 columns past a row's end (results never stored)
-  __shared__ __attribute__((aligned(16))) uint16_t smem[2 * N_ELEMS + 64];
-  __shared__ __attribute__((aligned(16))) float rstat[2][BR];
-  uint16_t* const N1 = smem;
-  uint16_t* const N2 = smem + N_ELEMS;
+  // Two buffers of [natural image of tensor a | of tensor b]: tile t+1 is written while tile t is being read, one barrier per tile.
+  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * N_ELEMS + 64];
+  __shared__ __attribute__((aligned(16))) float rstat_all[2][2][BR];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
 
   // zero the contraction padding of the natural images once (staging never writes it)
   if constexpr (DK > D) {
-    for (int i = tid; i < 2 * BR * (DK - D); i += 256) {
+    for (int i = tid; i < 4 * BR * (DK - D); i += 256) {
       const int b = i / (BR * (DK - D)), rem = i % (BR * (DK - D));
       smem[b * N_ELEMS + (rem / (DK - D)) * NROW + D + rem % (DK - D)] = 0;
     }
@@ -190,26 +189,31 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
       }
     }
   };
-  auto store_tile = [&]() __attribute__((always_inline)) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    uint16_t* const S1 = smem + buf * 2 * N_ELEMS;
+    uint16_t* const S2 = S1 + N_ELEMS;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int c = tid + 256 * i;
       if (NCH % 256 == 0 || c < NCH) {
         const int r = c / DCH, ch = c % DCH;
-        *reinterpret_cast<u32x4_t*>(N1 + r * NROW + ch * 8) = n1[i];
-        *reinterpret_cast<u32x4_t*>(N2 + r * NROW + ch * 8) = n2[i];
+        *reinterpret_cast<u32x4_t*>(S1 + r * NROW + ch * 8) = n1[i];
+        *reinterpret_cast<u32x4_t*>(S2 + r * NROW + ch * 8) = n2[i];
       }
     }
     if constexpr (MODE == MODE_DKV) {
-      if (tid < 2 * BR) rstat[tid / BR][tid % BR] = stat_r;
+      if (tid < 2 * BR) rstat_all[buf][tid / BR][tid % BR] = stat_r;
     }
   };
 
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
   for (int t = 0; t < total_tiles; ++t) {
     const int r0 = (t % ntiles) * BR;
+    const uint16_t* const N1 = smem + (t & 1) * 2 * N_ELEMS;
+    const uint16_t* const N2 = N1 + N_ELEMS;
+    const float (*const rstat)[BR] = rstat_all[t & 1];
     if (t + 1 < total_tiles) load_tile(t + 1);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -307,11 +311,15 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
           }
       }
     }
-    __syncthreads();                     // every wave is done reading this tile's images
-    if (t + 1 < total_tiles) {
-      store_tile();
-      __syncthreads();
-    }
+#ifdef A3D_EXP_BWD_SINGLEBUF      // A/B build (python -m animate3d_amd.build --experiment A3D_EXP_BWD_SINGLEBUF): round 2's flow, two barriers per tile
+    __syncthreads();
+    if (t + 1 < total_tiles) store_tile((t + 1) & 1);
+    __syncthreads();
+#else
+    // tile t+1 goes into the other buffer: its last readers (tile t-1) passed the barrier of the previous iteration
+    if (t + 1 < total_tiles) store_tile((t + 1) & 1);
+    __syncthreads();
+#endif
   }
 
   // ---- results: lane holds column l31 of each sub-tile; register r = 4*qd + j of tile mt is dim d = 32*mt + 8*qd + 4*g + j

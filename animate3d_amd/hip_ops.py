@@ -479,11 +479,39 @@ class HipOps:
         else:
             stats = torch.empty((2, groups * heads * q_len), dtype=torch.float32, device=self.device)
             lse2, delta = stats[0], stats[1]
-        rc = self.lib.a3d_flash_attn_bwd_bf16(self._stream(), _p(q), _p(k), _p(v), _p(do), _p(dq), _p(dk), _p(dv), _p(lse2), _p(delta),
-                                              ctypes.byref(qm), ctypes.byref(km), ctypes.byref(dom), ctypes.byref(dqm), ctypes.byref(dkm),
-                                              groups, heads, D, q_len, kv_len, q_per_kv, float(D) ** -0.5, do_scale, flags)
-        _check(rc, f"a3d_flash_attn_bwd_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len} q_per_kv={q_per_kv}")
+        def run(dq_, dk_, dv_, dkm_, share, fl):
+            rc = self.lib.a3d_flash_attn_bwd_bf16(self._stream(), _p(q), _p(k), _p(v), _p(do), _p(dq_), _p(dk_), _p(dv_), _p(lse2), _p(delta),
+                                                  ctypes.byref(qm), ctypes.byref(km), ctypes.byref(dom), ctypes.byref(dqm), ctypes.byref(dkm_),
+                                                  groups, heads, D, q_len, kv_len, share, float(D) ** -0.5, do_scale, fl)
+            _check(rc, f"a3d_flash_attn_bwd_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len} q_per_kv={share}")
+
+        # Shared keys (first-frame branches: the q_per_kv = F query groups of a video read frame 0's K / V): the kernel sums their dK | dV
+        # inside one workgroup per key tile, i.e. groups / q_per_kv x key tiles x heads workgroups — 16 .. 256 at the training shapes,
+        # a fraction of the chip (2.5 - 3.8 x the time of the same attention with private keys at head_dim 80 / 160).  When that grid
+        # cannot fill the CUs, every query group writes its own partial dK | dV (full-width grid, no sharing) and one reduction over
+        # the q_per_kv partials follows (torch.sum accumulates in fp32).
+        wgs_shared = (groups // q_per_kv) * heads * ((kv_len + 127) // 128)
+        if need_dkv and q_per_kv > 1 and wgs_shared < 512:
+            run(dq, None, None, dkm, q_per_kv, flags) if need_dq else None
+            pk = self.empty(groups * kv_len, C)
+            pv = self.empty(groups * kv_len, C)
+            run(None, pk, pv, RowMap(1, kv_len, 0, kv_len, 0).c(C), 1, flags | (2 if need_dq else 0))       # (the first call left the statistics in lse2 / delta)
+            idx = self._shared_kv_rows(kmap, groups, q_per_kv, kv_len)
+            dk.index_copy_(0, idx, pk.view(groups // q_per_kv, q_per_kv, kv_len, C).sum(dim=1).view(-1, C))
+            dv.index_copy_(0, idx, pv.view(groups // q_per_kv, q_per_kv, kv_len, C).sum(dim=1).view(-1, C))
+            return dq, dk, dv
+        run(dq, dk, dv, dkm, q_per_kv, flags)
         return dq, dk, dv
+
+    def _shared_kv_rows(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int) -> torch.Tensor:
+        """Rows of the K / V tensor that the first query group of every sharing set reads, in (set, key) order (cached per map)."""
+        key = (kmap.gdiv, kmap.ga, kmap.gb, kmap.seg_len, kmap.seg_stride, groups, q_per_kv, kv_len)
+        cache = self.__dict__.setdefault("_kv_row_cache", {})
+        if key not in cache:
+            g = torch.arange(0, groups, q_per_kv, device=self.device).view(-1, 1)
+            s = torch.arange(kv_len, device=self.device).view(1, -1)
+            cache[key] = ((g // kmap.gdiv) * kmap.ga + (g % kmap.gdiv) * kmap.gb + (s // kmap.seg_len) * kmap.seg_stride + s % kmap.seg_len).reshape(-1)
+        return cache[key]
 
     def temporal_attn_bwd(self, q, k, v, do, videos: int, frames: int, L: int, heads: int):
         """Returns one [rows, 3C] buffer = [dq | dk | dv]."""

@@ -291,6 +291,28 @@ def bench_wgrad(ops):
         print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(outs))
 
 
+def bench_attnbwd(ops):
+    """Attention backward at the train.yaml level-0 / level-1 shapes (4 views x 16 frames x 32x32 latent): dQ + dK|dV with the forward's
+    statistics (a3d_attn_delta + the two gradient passes) and with the statistics pass; multi-view and first-frame maps."""
+    print("== attention backward: median ms (with forward statistics | recomputing them)")
+    for (D, n, F, L, b) in ((40, 4, 16, 1024, 1), (80, 4, 16, 256, 1), (160, 4, 16, 64, 1)):
+        heads, C = 8, 8 * D
+        rows = b * n * F * L
+        kvq = rnd(rows, 3 * C)
+        q, k, v = kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C]
+        do = rnd(rows, C)
+        qm = RowMap(F, n * F * L, L, L, F * L)
+        k0 = RowMap(F, n * F * L, 0, L, F * L)
+        S, G = n * L, b * F
+        for name, km, share in (("multi-view", qm, 1), ("first-frame", k0, F)):
+            o, lse = ops.flash_attn(q, k, v, qm, km, G, heads, S, S, with_lse=True)
+            fast, _ = timeit(lambda: ops.flash_attn_bwd(q, k, v, do, qm, km, G, heads, S, S, q_per_kv=share, o=o, lse=lse), reps=9, warm=2)
+            slow, _ = timeit(lambda: ops.flash_attn_bwd(q, k, v, do, qm, km, G, heads, S, S, q_per_kv=share), reps=9, warm=2)
+            fwd, _ = timeit(lambda: ops.flash_attn(q, k, v, qm, km, G, heads, S, S), reps=9, warm=2)
+            fl = 4.0 * G * S * S * C
+            print(f"D={D:3d} S={S:5d} {name:11s}: {fast:7.3f} ms ({2.5 * fl / fast / 1e9:6.1f} TF/s) | {slow:7.3f} ms   forward {fwd:6.3f} ms ({fl / fwd / 1e9:6.1f} TF/s)")
+
+
 def bench_fill(ops):
     print("== persistent kernel on partially filled grids: median ms for 128x128 classic | persistent (a3d_tune_gemm(300 + 40): min fill 40 %)")
     def ab(fn):
@@ -418,7 +440,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "wgrad": bench_wgrad, "flash16": bench_flash16,
+         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
