@@ -439,3 +439,37 @@ def test_staged_training_refreezing_a_module_drops_its_stale_frozen_pack():
         y_eval = model(**inp).sample
     assert not torch.allclose(y_train, y0)                # the new weights are seen ...
     torch.testing.assert_close(y_train.detach(), y_eval, rtol=1e-5, atol=1e-6)      # ... exactly as the re-packing inference path sees them
+
+
+def test_trainable_merge_weights_are_read_back_once_per_forward(monkeypatch):
+    """The kernels take the AlphaBlender weight by value, so a trainable ``mix_factor`` has to be read back from the device; one
+    ``float(tensor)`` per merge GEMM would be a host synchronisation in the middle of the forward (~130 per training step at the real
+    depth).  ``AutogradOps.prefetch_scalars`` reads all of them in one transfer while the step's weights are packed: no merge GEMM may fall
+    back to its own read-back, and the values must be the ones the gradient check of the oracle test sees (same forward result)."""
+    from animate3d_amd import autograd_ops as A
+    n, Fr, hw = 2, 2, (8, 8)
+    ocfg, ref, model = _pair(n, Fr, hw)
+    inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=3, cfg_doubled=False)
+    model.enable_training()
+    aops = model._autograd_ops()
+    fallbacks, batches = [], []
+    real_prefetch = A.AutogradOps.prefetch_scalars
+
+    def counting_prefetch(self, tensors):
+        batches.append(len([t for t in tensors if torch.is_tensor(t)]))
+        return real_prefetch(self, tensors)
+
+    def counting_scalar(self, t):
+        hit = self._host_scalars.get(id(t))
+        if hit is None or hit[0] is not t:
+            fallbacks.append(t)
+        return float(t.detach())
+
+    monkeypatch.setattr(A.AutogradOps, "prefetch_scalars", counting_prefetch)
+    monkeypatch.setattr(A.AutogradOps, "_scalar", counting_scalar)
+    y = model(**inp).sample
+    assert batches and batches[0] > 0 and len(batches) == 1            # one batched read-back for the whole forward
+    assert not fallbacks                                                # every tensor-valued merge weight was in it
+    want = ref(**inp).sample
+    assert float((y.detach() - want).abs().max()) < 2e-3 * float(want.abs().max())
+    assert all(abs(v - float(t.detach())) == 0.0 for t, v in aops._host_scalars.values())
