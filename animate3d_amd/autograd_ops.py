@@ -146,11 +146,15 @@ class _FlashAttn(torch.autograd.Function):
             if aops.keep_lse and may_keep_out:
                 o, lse = aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out_scale=out_scale, with_lse=True)
                 ctx.save_for_backward(q, k, v, o, lse)
+                o._a3d_kept_for_backward = True
                 return o
             ctx.save_for_backward(q, k, v)
             return aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out_scale=out_scale)
         # accumulated into a caller's buffer (the IP-Adapter image tokens on top of the text attention): that buffer is not this
         # attention's output, the backward recomputes the statistics
+        if getattr(out_in, "_a3d_kept_for_backward", False):
+            raise RuntimeError("flash_attn(out=..., accumulate=True) adds into the result of a flash_attn call that kept that result for its "
+                               "backward (delta = rowsum(dO * O)): pass accumulation_target=True to the call that produced the buffer")
         ctx.save_for_backward(q, k, v)
         aops.base.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len, out=out_in, out_scale=out_scale, accumulate=True)
         ctx.mark_dirty(out_in)

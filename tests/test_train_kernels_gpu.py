@@ -326,13 +326,16 @@ def test_autograd_ops_attention_and_norm_compositions(ops, ref):
     qc = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
 
     def cross(o, q2, kvt, kvi):
-        ca = o.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), V * F, heads, L, T)
+        ca = o.flash_attn(q2, kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), V * F, heads, L, T, accumulation_target=True)
         o.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), V * F, heads, L, nt, out=ca, out_scale=0.7, accumulate=True)
         return ca
 
     q2, kvt, kvi = rnd(rows, C, seed=3, dtype=dt), rnd(V * T, 2 * C, seed=4, dtype=dt), rnd(V * nt, 2 * C, seed=5, dtype=dt)
     dy = rnd(rows, C, seed=6)
     got = _grads(lambda q: cross(a, q, kvt, kvi), [q2], dy)
+    with pytest.raises(RuntimeError, match="accumulation_target"):      # without the hint the first call keeps its output for the backward: refused loudly
+        first = a.flash_attn(q2.clone().requires_grad_(True), kvt[:, :C], kvt[:, C:], qc, RowMap(F, T, 0, T, 0), V * F, heads, L, T)
+        a.flash_attn(q2, kvi[:, :C], kvi[:, C:], qc, RowMap(F, nt, 0, nt, 0), V * F, heads, L, nt, out=first, out_scale=0.7, accumulate=True)
     want = _grads(lambda q: cross(r, q, kvt.float(), kvi.float()), [q2.float()], dy)
     check("autograd text + IP cross-attention dq", got[0], want[0], tol)
 
