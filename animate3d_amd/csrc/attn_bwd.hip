@@ -375,6 +375,8 @@ int launch(hipStream_t s, const BwdParams& p, int groups_y) {
   constexpr int BR = 32 * NU;
   const bool aligned = (MODE == MODE_DKV) ? (p.qm.seg_len % BR == 0 && p.dom.seg_len % BR == 0) : (p.km.seg_len % BR == 0);
   // workgroups per CU the register budget is set for: two wherever the kernel fits 256 registers without spilling
+  // (measured, round 3: three workgroups per CU for the 168-register dQ pass and 128-row tiles at head_dim 40 change nothing: 2.33-2.44 ms
+  // per level-0 backward in every variant, profiles/README.md)
   constexpr int OCC = (CT == 1 && (D <= 64 || (D == 80 && MODE != MODE_DKV))) ? 2 : 1;
   if (aligned) attn_bwd_kernel<D, MODE, NU, CT, true, OCC><<<grid, dim3(256), 0, s>>>(p);
   else attn_bwd_kernel<D, MODE, NU, CT, false, OCC><<<grid, dim3(256), 0, s>>>(p);
