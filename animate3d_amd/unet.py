@@ -847,8 +847,11 @@ class MVUNetMotionModel(nn.Module):
         return self._train_ops
 
     def enable_gradient_checkpointing(self):
-        """train.py:381-382.  Accepted for call compatibility and a no-op: the backward keeps its activations (38 GB at the train.yaml
-        shape, of 288 GB per MI355X) — recomputation would only cost time here."""
+        """train.py:381-382 (diffusers wraps every ResNet / Transformer2D / motion module in ``torch.utils.checkpoint``).  Here one
+        checkpoint spans a whole layer (ResNet + Transformer2D + motion module): a grad-enabled forward keeps only the layer boundaries and
+        recomputes the inside of a layer when the backward reaches it — the HIP kernels run again through the same autograd functions, so
+        the gradients are bit-identical to the un-checkpointed ones.  The train.yaml shape needs 38 GB without it (of 288 GB per MI355X),
+        so the reference's default costs one extra forward here for nothing; larger batches / resolutions are where it pays."""
         self._gradient_checkpointing = True
 
     def disable_gradient_checkpointing(self):
@@ -1031,12 +1034,28 @@ class MVUNetMotionModel(nn.Module):
         h_, w_ = H, W
         skips = [x]
         sizes = [(H, W)]                  # feature-map size per level: the forced upsample sizes of :690-698, 831-837
+        ckpt = bool(getattr(self, "_gradient_checkpointing", False)) and torch.is_grad_enabled() and self._active_ops is not None
+
+        def layer(x_in, rp, tp, mp, hh, ww):
+            """ResNet (+ Transformer2D) + motion module of one layer; under gradient checkpointing only its input and output are kept."""
+            aops = self._active_ops
+            def run(xx):
+                prev, self._active_ops = self._active_ops, aops      # the recomputation runs inside backward(), after forward() has returned
+                try:
+                    xx = self._resnet(xx, B2, hh, ww, rp, semb, rb_rows)
+                    if tp is not None:
+                        xx = self._t2d(xx, V, n, F, hh, ww, tp, text_rows, ip_rows, T)
+                    return self._motion(xx, V, n, F, hh, ww, mp)
+                finally:
+                    self._active_ops = prev
+            if ckpt:
+                from torch.utils.checkpoint import checkpoint
+                return checkpoint(run, x_in, use_reentrant=False, preserve_rng_state=False)
+            return run(x_in)
+
         for pk in P.down:
             for j, rp in enumerate(pk.resnets):
-                x = self._resnet(x, B2, h_, w_, rp, semb, rb_rows)
-                if pk.t2d is not None:
-                    x = self._t2d(x, V, n, F, h_, w_, pk.t2d[j], text_rows, ip_rows, T)
-                x = self._motion(x, V, n, F, h_, w_, pk.motion[j])
+                x = layer(x, rp, pk.t2d[j] if pk.t2d is not None else None, pk.motion[j], h_, w_)
                 skips.append(x)
             if pk.down is not None:
                 x, h_, w_ = ops.conv3x3(x, B2, h_, w_, pk.down[0], pk.down[1], stride=2)
@@ -1059,9 +1078,7 @@ class MVUNetMotionModel(nn.Module):
                 geo += [sizes[bi]] * len(pkd.resnets) + ([sizes[bi + 1]] if pkd.down is not None else [])
             skips = [plus(s_, r_, *g_) for s_, r_, g_ in zip(skips, down_block_additional_residuals, geo)]
         pk = P.mid
-        x = self._resnet(x, B2, h_, w_, pk.resnets[0], semb, rb_rows)
-        x = self._t2d(x, V, n, F, h_, w_, pk.t2d[0], text_rows, ip_rows, T)
-        x = self._motion(x, V, n, F, h_, w_, pk.motion[0])
+        x = layer(x, pk.resnets[0], pk.t2d[0], pk.motion[0], h_, w_)
         x = self._resnet(x, B2, h_, w_, pk.resnets[1], semb, rb_rows)
         if mid_block_additional_residual is not None:
             x = plus(x, mid_block_additional_residual, h_, w_)
@@ -1069,10 +1086,7 @@ class MVUNetMotionModel(nn.Module):
         for blk, pk in zip(self.up_blocks, P.up):
             for j, rp in enumerate(pk.resnets):
                 x = ops.concat(x, skips.pop())
-                x = self._resnet(x, B2, h_, w_, rp, semb, rb_rows)
-                if pk.t2d is not None:
-                    x = self._t2d(x, V, n, F, h_, w_, pk.t2d[j], text_rows, ip_rows, T)
-                x = self._motion(x, V, n, F, h_, w_, pk.motion[j])
+                x = layer(x, rp, pk.t2d[j] if pk.t2d is not None else None, pk.motion[j], h_, w_)
             if pk.up is not None:
                 # the reference passes the next skip's size whenever a latent side is not a multiple of 2^(levels-1);
                 # when it is, that size is the plain 2x, so always naming it is the same arithmetic

@@ -473,3 +473,38 @@ def test_trainable_merge_weights_are_read_back_once_per_forward(monkeypatch):
     want = ref(**inp).sample
     assert float((y.detach() - want).abs().max()) < 2e-3 * float(want.abs().max())
     assert all(abs(v - float(t.detach())) == 0.0 for t, v in aops._host_scalars.values())
+
+
+def test_gradient_checkpointing_recomputes_layers_and_changes_no_gradient():
+    """train.py:381-382 ``unet.enable_gradient_checkpointing()``: one checkpoint per layer (ResNet + Transformer2D + motion module).  The
+    recomputation runs the same ops through the same autograd functions, so loss and every parameter gradient must equal the
+    un-checkpointed ones bit for bit, while the saved-tensor count of the graph drops (only layer boundaries are kept)."""
+    n, Fr, hw = 2, 2, (8, 8)
+    ocfg, ref, model = _pair(n, Fr, hw)
+    inp = O.synthetic_inputs(ocfg, n, n, Fr, hw, seed=3, cfg_doubled=False)
+    target = torch.randn(n, 4, Fr, *hw, generator=torch.Generator().manual_seed(1))
+    from animate3d_amd.train import select_trainable
+    select_trainable(model)
+    model.enable_training()
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        packed = []
+        with torch.autograd.graph.saved_tensors_hooks(lambda t: (packed.append(t.numel()), t)[1], lambda t: t):
+            loss = F.mse_loss(model(**inp).sample, target)
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad}, sum(packed)
+
+    loss0, g0, kept0 = run()
+    model.enable_gradient_checkpointing()
+    loss1, g1, kept1 = run()
+    model.disable_gradient_checkpointing()
+    assert loss0 == loss1 and g0.keys() == g1.keys() and len(g0) > 50
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    print(f"[parity] elements saved for the backward: {kept0} without, {kept1} with gradient checkpointing")
+    assert kept1 < 0.5 * kept0
+    with torch.no_grad():                                   # the inference path is untouched
+        model.enable_gradient_checkpointing()
+        assert torch.isfinite(model(**inp).sample).all()

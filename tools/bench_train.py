@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--checkpoint", action="store_true", help="unet.enable_gradient_checkpointing() (train.py:381-382): one checkpoint per layer")
     args = ap.parse_args()
     from animate3d_amd.config import UNetConfig
     from animate3d_amd.denoise import ddim_schedule
@@ -32,6 +33,8 @@ def main():
     params = select_trainable(model)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     model.enable_training(compute_dtype=dt)
+    if args.checkpoint:
+        model.enable_gradient_checkpointing()
     opt = FlatAdamW(params, model.ops, lr=1e-4, loss_scale=None if dt == torch.bfloat16 else 65536.0)
     g = torch.Generator(device="cuda").manual_seed(0)
     latents = torch.randn(1, n, 4, Fr, lat, lat, generator=g, device="cuda") * 0.5
@@ -62,7 +65,7 @@ def main():
     ms_fwd = (time.perf_counter() - t0) / args.steps * 1e3
     f_fwd = step_flops(cfg, n, n, Fr, lat, lat)["total"]
     print(json.dumps({"metric": "training steps/s (train.yaml shape, 1 GPU)", "value": 1e3 / ms, "ms_per_step": ms, "forward_only_ms": ms_fwd,
-                      "dtype": args.dtype, "trainable_params": opt.numel, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                      "dtype": args.dtype, "gradient_checkpointing": bool(args.checkpoint), "trainable_params": opt.numel, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
                       "forward_tflop": f_fwd / 1e12, "approx_step_tflops": 3.0 * f_fwd / (ms * 1e-3) / 1e12,
                       "loss": info["loss"], "grad_norm": info["grad_norm"], "skipped": info["skipped"],
                       "config": {"workload": f"1 x {n} views x {Fr} frames x {lat}x{lat} latent, no CFG; motion_modules + i2v trainable"}}))
