@@ -176,6 +176,7 @@ class HipOps:
         if act_dtype not in (torch.bfloat16, torch.float16):
             raise ValueError(f"storage type {act_dtype} is not supported (bfloat16 or float16)")
         self.raw_lib = load_library()
+        self._kv_row_cache = {}      # _shared_kv_rows
         self.act_dtype = act_dtype
         self.lib = _Entry(self.raw_lib, act_dtype == torch.float16)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -492,7 +493,8 @@ class HipOps:
         # the q_per_kv partials follows (torch.sum accumulates in fp32).
         wgs_shared = (groups // q_per_kv) * heads * ((kv_len + 127) // 128)
         if need_dkv and q_per_kv > 1 and wgs_shared < 512:
-            run(dq, None, None, dkm, q_per_kv, flags) if need_dq else None
+            if need_dq:
+                run(dq, None, None, dkm, q_per_kv, flags)
             pk = self.empty(groups * kv_len, C)
             pv = self.empty(groups * kv_len, C)
             run(None, pk, pv, RowMap(1, kv_len, 0, kv_len, 0).c(C), 1, flags | (2 if need_dq else 0))       # (the first call left the statistics in lse2 / delta)
@@ -506,7 +508,7 @@ class HipOps:
     def _shared_kv_rows(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int) -> torch.Tensor:
         """Rows of the K / V tensor that the first query group of every sharing set reads, in (set, key) order (cached per map)."""
         key = (kmap.gdiv, kmap.ga, kmap.gb, kmap.seg_len, kmap.seg_stride, groups, q_per_kv, kv_len)
-        cache = self.__dict__.setdefault("_kv_row_cache", {})
+        cache = self._kv_row_cache
         if key not in cache:
             g = torch.arange(0, groups, q_per_kv, device=self.device).view(-1, 1)
             s = torch.arange(kv_len, device=self.device).view(1, -1)
