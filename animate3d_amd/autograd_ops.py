@@ -30,6 +30,84 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.contiguous()
 
 
+class _GradSink:
+    """fp32 gradient of a packed kernel weight, handed from the GEMM backward that computed it (``a3d_wgrad`` produces fp32) to ``PackW.backward``
+    next to the 16-bit placeholder autograd carries between the two: no fp32 -> 16-bit -> fp32 round trip of every weight gradient."""
+    __slots__ = ("grad32",)
+
+    def __init__(self):
+        self.grad32 = None
+
+    def put(self, g: torch.Tensor) -> None:
+        self.grad32 = g if self.grad32 is None else self.grad32 + g
+
+
+_PLACEHOLDERS = {}
+
+
+def _placeholder(w: torch.Tensor) -> torch.Tensor:
+    """A zero of w's dtype expanded to its shape (no memory, no kernel): keeps autograd's edge to PackW alive while the real gradient travels in the sink."""
+    key = (w.dtype, w.device)
+    z = _PLACEHOLDERS.get(key)
+    if z is None:
+        z = _PLACEHOLDERS[key] = torch.zeros((), dtype=w.dtype, device=w.device)
+    return z.expand(w.shape)
+
+
+class PackW(torch.autograd.Function):
+    """Trainable fp32 master weights -> the 16-bit kernel operand of one GEMM: rows concatenated (fused Q|K|V projections), optionally
+    GEGLU-interleaved, cast to the storage type.  The per-step price of fp32 master weights behind 16-bit kernels (unet._pack_train);
+    backward splits the operand's gradient back over the masters — in fp32, taken from the sink when the consuming GEMM left it there."""
+
+    @staticmethod
+    def forward(ctx, dtype, interleave, sink, *masters):
+        ctx.interleave, ctx.sink = interleave, sink
+        ctx.rows = [m.shape[0] for m in masters]
+        w = masters[0] if len(masters) == 1 else torch.cat(masters, 0)
+        if interleave:
+            w = _interleave32(w)
+        return w.to(dtype).contiguous()
+
+    @staticmethod
+    def backward(ctx, dw):
+        g, ctx.sink.grad32 = ctx.sink.grad32, None
+        if g is None:
+            g = dw.float()
+        if ctx.interleave:
+            g = _deinterleave32(g)
+        outs, r = [], 0
+        for i, n in enumerate(ctx.rows):
+            outs.append(g[r:r + n] if ctx.needs_input_grad[3 + i] else None)
+            r += n
+        return (None, None, None, *outs)
+
+
+def _interleave32(w):          # hip_ops.HipOps.interleave_geglu: [h rows | gate rows] -> blocks of 32 rows alternating
+    n = w.shape[0] // 2
+    return torch.stack([w[:n].reshape(n // 32, 32, *w.shape[1:]), w[n:].reshape(n // 32, 32, *w.shape[1:])], dim=1).reshape(w.shape)
+
+
+def _deinterleave32(w):
+    n = w.shape[0] // 2
+    blk = w.reshape(n // 32, 2, 32, *w.shape[1:])
+    return torch.cat([blk[:, 0].reshape(n, *w.shape[1:]), blk[:, 1].reshape(n, *w.shape[1:])], 0)
+
+
+def pack_weight(dtype, masters, interleave: bool = False) -> torch.Tensor:
+    sink = _GradSink()
+    w = PackW.apply(dtype, interleave, sink, *masters)
+    w._a3d_sink = sink
+    return w
+
+
+def _weight_grad(ctx_sink, w, dw32: torch.Tensor) -> torch.Tensor:
+    """What a GEMM backward returns for its weight operand: through the sink (fp32, no cast) when the operand came from ``pack_weight``."""
+    if ctx_sink is not None:
+        ctx_sink.put(dw32)
+        return _placeholder(w)
+    return dw32.to(w.dtype)
+
+
 class _Gemm(torch.autograd.Function):
     """Y = alpha (X W^T + bias + rowbias) + beta R;  ``alpha_t``: optional 0-dim tensor the float ``alpha`` was read from (the
     AlphaBlender merge weight of attention_processor.py:700-713, a trainable scalar)."""
@@ -39,6 +117,7 @@ class _Gemm(torch.autograd.Function):
         base = aops.base
         ctx.aops, ctx.alpha, ctx.beta = aops, alpha, beta
         ctx.has_rowbias = rowbias is not None
+        ctx.w_sink = getattr(w, "_a3d_sink", None)
         ctx.save_for_backward(x, w, bias)
         return base.gemm(x, w, bias, residual=residual, alpha=alpha, beta=beta, rowbias=rowbias, rb_div=rb_div)
 
@@ -63,11 +142,11 @@ class _Gemm(torch.autograd.Function):
             if db_u is not None:
                 dalpha = dalpha + (bias.float() * db_u).sum()
             if need[2]:
-                dw = (dw_u * ctx.alpha).to(w.dtype)
+                dw = _weight_grad(ctx.w_sink, w, dw_u * ctx.alpha)
             if need[3]:
                 db = db_u * ctx.alpha
         elif need[2]:
-            dw = base.wgrad(dy, x, ctx.alpha).to(w.dtype)
+            dw = _weight_grad(ctx.w_sink, w, base.wgrad(dy, x, ctx.alpha))
             if need[3]:
                 db = base.colsum(dy, ctx.alpha)
         elif need[3]:
@@ -81,6 +160,7 @@ class _GemmGeglu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, aops, x, w_il, b_il):
         ctx.aops = aops
+        ctx.w_sink = getattr(w_il, "_a3d_sink", None)
         ctx.save_for_backward(x, w_il, b_il)
         return aops.base.gemm_geglu(x, w_il, b_il)
 
@@ -92,7 +172,7 @@ class _GemmGeglu(torch.autograd.Function):
         proj = base.gemm(x, w_il, b_il)                     # recomputed: the forward keeps only its input
         dp = base.geglu_bwd(proj, _c(dy))
         dx = base.gemm(dp, aops.transposed_weight(w_il)) if need[1] else None
-        dw = base.wgrad(dp, x).to(w_il.dtype) if need[2] else None
+        dw = _weight_grad(ctx.w_sink, w_il, base.wgrad(dp, x)) if need[2] else None
         db = base.colsum(dp) if need[3] else None
         return None, dx, dw, db
 

@@ -391,7 +391,20 @@ class MVUNetMotionModel(nn.Module):
         return t if (self._pack_grad and t.requires_grad) else t.detach()
 
     def _w(self, t: torch.Tensor) -> torch.Tensor:        # kernel weight: act dtype, contiguous
+        if self._pack_grad and t.requires_grad and t.is_leaf:
+            return self._wcat([t])
         return self._d(t).to(self.ops.act_dtype).contiguous()
+
+    def _wcat(self, ws, interleave: bool = False) -> torch.Tensor:
+        """Kernel weight of a fused projection: the rows of ``ws`` concatenated (GEGLU: interleaved in blocks of 32), act dtype.  Under
+        ``_pack_train`` a trainable member makes it one ``autograd_ops.PackW`` node whose fp32 gradient comes straight from the GEMM backward."""
+        if self._pack_grad and any(w.requires_grad for w in ws):
+            from .autograd_ops import pack_weight
+            return pack_weight(self.ops.act_dtype, list(ws), interleave)
+        w = ws[0].detach() if len(ws) == 1 else torch.cat([w.detach() for w in ws], 0)
+        if interleave:
+            w = self.ops.interleave_geglu(w)
+        return w.to(self.ops.act_dtype).contiguous()
 
     def _f(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:   # bias / affine: fp32
         return None if t is None else self._d(t).float().contiguous()
@@ -412,7 +425,7 @@ class MVUNetMotionModel(nn.Module):
     def _pack_ff(self, tb):
         return SimpleNamespace(n3=(self._f(tb.norm3.weight), self._f(tb.norm3.bias)),
                                # GEGLU projection rows interleaved (h | gate in blocks of 32) for the fused GEMM epilogue
-                               ff1=(self._w(self.ops.interleave_geglu(self._d(tb.ff.net[0].proj.weight))),
+                               ff1=(self._wcat([tb.ff.net[0].proj.weight], interleave=True),
                                     self._f(self.ops.interleave_geglu(self._d(tb.ff.net[0].proj.bias)))),
                                ff2=(self._w(tb.ff.net[2].weight), self._f(tb.ff.net[2].bias)))
 
@@ -433,13 +446,13 @@ class MVUNetMotionModel(nn.Module):
             norm=(self._f(t.norm.weight), self._f(t.norm.bias)),
             pin=(self._conv_w(t.proj_in), self._f(t.proj_in.bias)),
             n1=(self._f(tb.norm1.weight), self._f(tb.norm1.bias)),
-            qkv=self._w(torch.cat([self._d(w) for w in qkv], 0)),
+            qkv=self._wcat(qkv),
             oi2v=(self._w(p1.to_out_i2v.weight), self._f(p1.to_out_i2v.bias)) if i2v else None,
             o1=(self._w(a1.to_out[0].weight), self._f(a1.to_out[0].bias)),
             n2=(self._f(tb.norm2.weight), self._f(tb.norm2.bias)),
             q2=self._w(a2.to_q.weight),
-            kv_text=self._w(torch.cat([self._d(a2.to_k.weight), self._d(a2.to_v.weight)], 0)),
-            kv_ip=[self._w(torch.cat([self._d(k.weight), self._d(v.weight)], 0)) for k, v in zip(p2.to_k_ip, p2.to_v_ip)],
+            kv_text=self._wcat([a2.to_k.weight, a2.to_v.weight]),
+            kv_ip=[self._wcat([k.weight, v.weight]) for k, v in zip(p2.to_k_ip, p2.to_v_ip)],
             ip_scale=list(p2.scale), ip_tokens=list(p2.num_tokens),
             o2=(self._w(a2.to_out[0].weight), self._f(a2.to_out[0].bias)),
             pout=(self._conv_w(t.proj_out), self._f(t.proj_out.bias)))
@@ -468,17 +481,17 @@ class MVUNetMotionModel(nn.Module):
                 heads=a.heads, spatial=pr.use_spatial_attn, image=pr.use_image_attn,
                 spatial_pe=pr.use_spatial_attn and pr.use_spatial_encoding, camera_pe=pr.use_spatial_attn and pr.use_camera_encoding,
                 n=(self._f(ln.weight), self._f(ln.bias)),
-                qkv=self._w(torch.cat([self._d(a.to_q.weight), self._d(a.to_k.weight), self._d(a.to_v.weight)], 0)),
+                qkv=self._wcat([a.to_q.weight, a.to_k.weight, a.to_v.weight]),
                 o=(self._w(a.to_out[0].weight), self._f(a.to_out[0].bias)),
                 pe_t=self._w(pe), coef=(ct, cs, ci), proc=pr,
                 # diffusers' BasicTransformerBlock.pos_embed stays on unless the spatial branch carries an encoding
                 # (inference.py:176-178): the temporal PE then sits on the LayerNorm output that EVERY branch reads
                 block_pe=not proc_pe)
             if pr.use_spatial_attn:
-                ns.qkv_sp = self._w(torch.cat([self._d(pr.to_k_sp.weight), self._d(pr.to_v_sp.weight), self._d(pr.to_q_sp.weight)], 0))   # [K; V; Q]
+                ns.qkv_sp = self._wcat([pr.to_k_sp.weight, pr.to_v_sp.weight, pr.to_q_sp.weight])   # [K; V; Q]
                 ns.osp = (self._w(pr.to_out_sp.weight), self._f(pr.to_out_sp.bias))
             if pr.use_image_attn:
-                ns.qkv_img = self._w(torch.cat([self._d(pr.to_k_i2v.weight), self._d(pr.to_v_i2v.weight), self._d(pr.to_q_i2v.weight)], 0))
+                ns.qkv_img = self._wcat([pr.to_k_i2v.weight, pr.to_v_i2v.weight, pr.to_q_i2v.weight])
                 ns.oimg = (self._w(pr.to_out_i2v.weight), self._f(pr.to_out_i2v.bias))
             attns.append(ns)
         out = SimpleNamespace(norm=(self._f(m.norm.weight), self._f(m.norm.bias)),
