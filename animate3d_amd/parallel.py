@@ -85,6 +85,7 @@ class ShardPlan:
         and frame groups (``dist.new_group`` is collective over the world — call it explicitly, e.g. through
         ``shard_unet(unet, shape=(b, n, F))``, if the first forward must not carry that hidden collective)."""
         cfg, views, frames = self.choose_layout(self.world, b, n, F, self.layout_request)
+        self.release_reservation()           # a forward that died between *_start and *_finish must not leave CUs reserved
         self.cfg_shards, self.view_shards, self.frame_shards = cfg, views, frames
         r = self.rank
         self.frame_rank, self.view_rank, self.cfg_rank = r % frames, (r // frames) % views, r // (frames * views)
@@ -131,8 +132,14 @@ class ShardPlan:
         if self.cu_knob is not None and self.reserve_cus > 0 and (before == 0) != (self._in_flight == 0):
             self.cu_knob(200 + (self.reserve_cus if self._in_flight else 0))
 
+    def release_reservation(self):
+        """Drop any CU reservation and forget collectives in flight (start of every configure(); error paths)."""
+        self._in_flight = 0
+        if self.cu_knob is not None:
+            self.cu_knob(200)
+
     # ---- view axis
-    def all_gather_views_start(self, kv: torch.Tensor):
+    def all_gather_views_start(self, kv: torch.Tensor, b_local: int = 1):
         """Launch the all-gather of this rank's tokens (or projected K|V) ``[(b_l n_l f) l, width]`` over the view group and
         return a handle; the collective runs on the backend's own stream (RCCL), so kernels issued on the compute stream
         before ``all_gather_views_finish`` overlap with it (the Q projection, the temporal branch of a motion module)."""
@@ -140,26 +147,36 @@ class ShardPlan:
         rows, width = kv.shape
         kv = kv.contiguous()
         out = torch.empty((S * rows, width), dtype=kv.dtype, device=kv.device)
-        work = dist.all_gather_into_tensor(out, kv, group=self.view_group, async_op=True)
+        # one collective per local batch entry, each straight into its final place: rank s's rows of batch entry j land at
+        # out[j][s] of the [b_l, S, per_b, width] view = unsharded (b_l N f) l order, so no re-ordering copy follows the gather
+        # (b_local = 1: the single gather already is in that order)
+        per_b = rows // b_local
+        works = []
+        try:
+            for j in range(b_local):
+                works.append(dist.all_gather_into_tensor(out[j * S * per_b:(j + 1) * S * per_b], kv[j * per_b:(j + 1) * per_b],
+                                                         group=self.view_group, async_op=True))
+        except Exception:
+            for w_ in works:
+                w_.wait()
+            raise
         self._count((S - 1) * rows * width * kv.element_size())
         self._overlap(+1)
-        return work, out, kv
+        return works, out, kv
 
     def all_gather_views_finish(self, handle, b_local: int) -> torch.Tensor:
         """Wait (the compute stream waits, not the host) and return the view group's ``[(b_l N f) l, width]`` tokens in
         unsharded row order."""
-        work, out, kv = handle
-        work.wait()
-        self._overlap(-1)
-        S = self.view_shards
-        rows, width = kv.shape
-        if b_local == 1:
-            return out                               # [S, n_l F L, width] is already (N f) l order
-        per_b = rows // b_local
-        return out.view(S, b_local, per_b, width).permute(1, 0, 2, 3).reshape(S * rows, width)
+        works, out, kv = handle
+        try:
+            for w_ in works:
+                w_.wait()
+        finally:
+            self._overlap(-1)
+        return out
 
     def all_gather_views(self, kv: torch.Tensor, b_local: int) -> torch.Tensor:
-        return self.all_gather_views_finish(self.all_gather_views_start(kv), b_local)
+        return self.all_gather_views_finish(self.all_gather_views_start(kv, b_local), b_local)
 
     # ---- frame axis
     def all_gather_frames_start(self, kv: torch.Tensor):
@@ -176,8 +193,10 @@ class ShardPlan:
 
     def all_gather_frames_finish(self, handle) -> torch.Tensor:
         work, out, _ = handle
-        work.wait()
-        self._overlap(-1)
+        try:
+            work.wait()
+        finally:
+            self._overlap(-1)
         return out
 
     def broadcast_frame0(self, x0: Optional[torch.Tensor], shape, dtype, device) -> torch.Tensor:

@@ -646,13 +646,13 @@ class MVUNetMotionModel(nn.Module):
         if par.gather_tokens:
             # gather the (normalised) INPUT tokens [rows_local, C] and project K|V for all N views locally: half the
             # bytes on xGMI for S x the (cheap, HBM-bound) K|V projection
-            pending = par.all_gather_views_start(x)
+            pending = par.all_gather_views_start(x, b)
             qq = ops.gemm(x, w_kvq[2 * C:])                   # overlaps the gather
             extra = overlap() if overlap is not None else None
             kv_all = ops.gemm(par.all_gather_views_finish(pending, b), w_kvq[:2 * C])
         else:
             kv = ops.gemm(x, w_kvq[:2 * C])                   # [rows_local, 2C], contiguous
-            pending = par.all_gather_views_start(kv)          # RCCL stream
+            pending = par.all_gather_views_start(kv, b)       # RCCL stream
             qq = ops.gemm(x, w_kvq[2 * C:])                   # [rows_local, C or 2C], overlaps the gather
             extra = overlap() if overlap is not None else None
             kv_all = par.all_gather_views_finish(pending, b)  # [b * N*F*L, 2C] in unsharded (b n f) l order

@@ -169,3 +169,22 @@ def test_collectives_run_under_the_rccl_backend():
     p.join(timeout=120)
     assert status == "ok", status
     assert backend == "nccl" and p.exitcode == 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form the driver uses for N = 1, extended to N > 1): bench.py re-executes itself
+    under torch.distributed.run, rank 0 prints the one JSON line incl. the `communication` object.  A3D_BENCH_SHARE_GPU=1 puts both ranks
+    on this box's single GPU (collectives over gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(A3D_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--latent", "16",
+                        "--frames", "4", "--no-cpu-baseline", "--no-groups"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["communication"]["layout"] == {"cfg": 2, "views": 1, "frames": 1}
+    assert rec["metric"].startswith("UNet denoise-steps/sec")
