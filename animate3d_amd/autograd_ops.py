@@ -71,8 +71,13 @@ class PackW(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dw):
         g, ctx.sink.grad32 = ctx.sink.grad32, None
+        # a consumer of a SLICE / view of the packed operand (unet._mv_attention: w_kvq[:2 * C] for the first-frame K|V) has no sink and
+        # returns a real gradient through autograd; it arrives here summed with the sink consumers' stride-0 zero placeholders
+        real = dw is not None and not (dw.dim() > 0 and all(s_ == 0 for s_ in dw.stride()))
         if g is None:
             g = dw.float()
+        elif real:
+            g = g + dw.float()
         if ctx.interleave:
             g = _deinterleave32(g)
         outs, r = [], 0

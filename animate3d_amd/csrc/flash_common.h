@@ -39,10 +39,6 @@ A3D_DEV int kperm(int i) {
 
 A3D_DEV float round16(float x) { return lo16(pack16(x, 0.f)); }
 
-template <int N, typename F, int... I>
-A3D_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-A3D_DEV void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
 A3D_DEV float vmax3(float a, float b, float c) {      // no NaN canonicalisation of the MFMA results (fmaxf adds a v_max per input)
   float r;

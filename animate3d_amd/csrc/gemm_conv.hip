@@ -24,6 +24,7 @@ extern int g_gemm_bk;
 extern int g_gemm_reserved_cus;
 extern int g_gemm_stagger;
 extern int g_gemm_ring;
+extern int g_gemm_pp;
 #else
 extern int g_wgrad_dma;       // wgrad.hip
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
@@ -38,6 +39,7 @@ int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measure
 int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
 int g_gemm_ring = 0;           // a3d_tune_gemm(8): two-stage persistent kernel (default), (9) / (10): four-stage ring kernel of gemm_ring.hip with
                                // back-to-back / MFMA-interleaved DMA issue (round-3 experiment: 5-15 % slower at full occupancy, profiles/README.md)
+int g_gemm_pp = 0;             // a3d_tune_gemm(13): lockstep persistent kernel, (14) / (15) / (16): ping-pong main loop of gemm_pp.hip, variants 1 / 2 / 3
 int g_gemm_stagger = 0;        // a3d_tune_gemm(500 + u): start-time stagger of the persistent workgroups (A/B experiment: de-phase the epilogue store bursts)
 int g_gemm_reserved_cus = 0;   // a3d_tune_gemm(200 + k): the persistent grid leaves k CUs free (set by the sharded path while an RCCL
                                // all-gather is in flight: its kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
@@ -452,11 +454,18 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
   int64_t ld_m0 = 0, ld_n0 = 0;         // origin of the tile being loaded
   int ld_par = 0;                       // bias-area parity of the tile being loaded
   int ik0 = 0, itap = 0, ici0 = 0;      // K position of the next K-tile to request (running state: no divisions in the loop)
+  // scalar DMA bases of this wave's first X / W piece for the K-tile requested next (+ 128 bytes per K-tile; piece i is i * 8 rows on):
+  // recomputing (row0 + 8 pc) * ld + k0 per piece was ~20 dependent SALU instructions per piece in front of every K-tile's MFMAs
+  uint64_t xk = 0, wk0 = 0, rbk = 0;
+  const uint32_t sx8 = (uint32_t)(p.ldx * 16), sw8 = (uint32_t)(p.ldw * 16);
   auto setup_tile = [&](int64_t tt) {
     const int64_t tile_n = tt % p.tiles_n, tile_m = tt / p.tiles_n;
     ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
     ik0 = 0; itap = 0; ici0 = 0;
     ld_par ^= 1;
+    if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx);
+    wk0 = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw);
+    if (EPI == EPI_LINEAR && p.rowbias) rbk = (uint64_t)(uintptr_t)(p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0);
     if constexpr (CONV != 0) {
       amask[0] = 0; amask[1] = 0;
 #pragma unroll
@@ -500,6 +509,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
     int wk = ik0;                       // K column of the weight rows of this K-tile
 #else
     const int wk = ik0;
+    (void)wk;
 #endif
     if (ik0 == 0) {
       // per-tile epilogue vectors ride along with the first K-tile: bias (fp32, BN floats) and the tile's rowbias row
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
         if (NB == 5 && wid == 1) { if (lane < 16) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0 + 256, bdst + 1024u); }
       }
       if (EPI == EPI_LINEAR && p.rowbias && wid == 2) {
-        if (lane < PC::BN / 8) glds16_s((uint32_t)lane * 16u, p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0, bdst + 1280u);
+        if (lane < PC::BN / 8) glds16_s((uint32_t)lane * 16u, (const void*)(uintptr_t)rbk, bdst + 1280u);
       }
     }
     if constexpr (CONV != 0) {
@@ -542,15 +552,21 @@ __global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int pc = wid * 4 + i;
-        glds16_s(vx0 ^ (uint32_t)((i & 1) << 6), p.X + (ld_m0 + pc * 8) * p.ldx + ik0, dst + (uint32_t)pc * 1024u);
+        glds16_s(vx0 ^ (uint32_t)((i & 1) << 6), (const void*)(uintptr_t)(xk + (uint64_t)(uint32_t)(i * sx8)), dst + (uint32_t)pc * 1024u);
       }
     }
+#ifdef A3D_EXP_CHUNK_MAJOR
+    const uint64_t wkk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw + wk);
+#else
+    const uint64_t wkk = wk0;
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int pc = wid * NB + i;
-      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), p.W + (ld_n0 + pc * 8) * p.ldw + wk, dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
+      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), (const void*)(uintptr_t)(wkk + (uint64_t)(uint32_t)(i * sw8)), dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
     }
     ik0 += 64;
+    xk += 128; wk0 += 128;
   };
 
   f32x16_t acc[NB][2];   // [tn][tm]
@@ -670,6 +686,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   p.vm_counted = g_gemm_vm_counted;
   p.stagger = g_gemm_stagger;
   p.ring_spread = g_gemm_ring == 2;
+  if (g_gemm_pp) return A3D_FN(a3d_launch_gemm_pp)(g_gemm_pp, CONV, EPI, nb, stream, p, cus);
   if (g_gemm_ring) return A3D_FN(a3d_launch_gemm_ring)(CONV, EPI, nb, stream, p, cus);
   if constexpr (EPI == EPI_GEGLU) {
     return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
@@ -798,6 +815,7 @@ extern "C" int a3d_tune_gemm(int bk) {
   if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
   if (bk >= 8 && bk <= 10) { g_gemm_ring = bk - 8; return A3D_OK; }
   if (bk == 11 || bk == 12) { g_wgrad_dma = bk - 11; return A3D_OK; }
+  if (bk >= 13 && bk <= 16) { g_gemm_pp = bk - 13; return A3D_OK; }
 #ifdef A3D_EXP_CHUNK_MAJOR
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
 #endif

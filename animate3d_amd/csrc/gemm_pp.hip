@@ -1,0 +1,346 @@
+// Persistent GEMM / implicit-GEMM 3x3 convolution with a PING-PONG main loop (round 4).
+//
+// Same tile, LDS images, LDS-DMA pieces and epilogue as gemm_persist_kernel (gemm_conv.hip): one 512-thread workgroup per CU owns
+// 256 x (NB*64) output tiles, 8 waves as 4(M) x 2(N), K-tiles of 64 go global -> LDS by global_load_lds_dwordx4 into two stages.
+// What is different is WHEN a wave does what.  gemm_persist_kernel runs all eight waves in lockstep: wait for the DMA, barrier,
+// nine DMA issues per wave, fragment reads, 40 MFMAs — the matrix pipe idles while every wave queues its DMA requests and
+// waits for its first fragments, and at full occupancy that serial part is as long as the MFMA part (K-tile period 2.4 us
+// against 1.07 us of matrix work; profiles/README.md).  Here the waves form two groups (waves 0-3 / 4-7 = one wave per SIMD
+// each) that run ONE BARRIER APART: while group A issues the MFMAs of a k-phase, group B issues its fragment reads and its share
+// of the next K-tile's DMA, then they swap (the 8-phase / ping-pong schedule of the CDNA4 guide, "256^2 8-phase template",
+// on this kernel's 256 x 320 tile and 32x32x16 MFMA).  Per phase and group:
+//
+//     L section:  ds_read_b128 fragments of this phase | LDS-DMA pieces of the next K-tile | s_waitcnt lgkmcnt(0)
+//     s_barrier (B1)
+//     M section:  s_setprio 1 | PH x 10 (NB = 5) MFMAs | s_setprio 0
+//     s_barrier (B2)
+//
+// Group 1 executes one extra barrier in front of every tile, so its L section coincides with group 0's M section and vice
+// versa; group 0 executes one extra barrier behind the tile's last phase, so both groups run the epilogue together.
+// Hazards (P(i) = i-th barrier instance of the workgroup; group 0's phase j has B1 = P(2j+1), B2 = P(2j+2); group 1's one later):
+//   * fragment reads complete (lgkmcnt(0)) before the reading wave's B1, so after the barrier that follows the last phase of a
+//     K-tile for BOTH groups its stage may be refilled: the next-but-one K-tile's DMA starts in the first L section of the next K-tile;
+//   * a wave's DMA pieces are retired by its own s_waitcnt vmcnt(0) in front of the last barrier instance before the first read
+//     of that stage: group 0 waits at the end of the last M section of the K-tile (before B2), group 1 at the end of its last L
+//     section (before B1) — the same barrier instance;
+//   * the epilogue's LDS transposition buffers alias the stage consumed last; every wave is out of the epilogue before group 0
+//     passes B1 of the next tile's first phase, so the first K-tile of a tile issues its DMA one phase later than the others.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int PBM = 256;
+template <int NB> struct PPCfg {
+  static constexpr int BN = NB * 64;
+  static constexpr int XBYTES = PBM * 128;
+  static constexpr int WBYTES = BN * 128;
+  static constexpr int EPI_BYTES = 8 * 32 * 68 * 4;
+  static constexpr int STAGE = (XBYTES + WBYTES) > EPI_BYTES ? (XBYTES + WBYTES) : EPI_BYTES;
+  static constexpr int BIAS_OFF = 2 * STAGE;
+  static constexpr int BIAS_STRIDE = 2048;
+  static constexpr int SMEM = 2 * STAGE + 2 * BIAS_STRIDE;
+};
+
+A3D_DEV void pp_barrier() {
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// PH: k-steps (16 of K) per phase, 1 or 2.  SCHED: how the 4 + NB DMA pieces a wave issues per K-tile are spread over the phases
+// (0: three per phase, 1: five then the rest).
+template <int CONV, int EPI, int NB, bool RES, int PH, int SCHED>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
+  using PC = PPCfg<NB>;
+  constexpr int NPH = 4 / PH;                 // phases per K-tile
+  constexpr int NP = 4 + NB;                  // DMA pieces per wave and K-tile: X 0..3, W 0..NB-1
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  char* const smem_b = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int grp = wid >> 2;                            // ping-pong group
+  const int l31 = lane & 31, g = lane >> 5;
+  const int lr = lane >> 3, pos = lane & 7;
+  const uint32_t lds0 = lds_addr(smem);
+
+  const int64_t ntiles = p.tiles_m * p.tiles_n;
+  const int64_t G = gridDim.x;
+  int64_t t = xcd_remap(blockIdx.x, G);
+  if (t >= ntiles) return;
+  const int nk = (int)(p.K / 64);
+
+  const uint32_t koff0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
+  const uint32_t xrd = (uint32_t)(wm * 64 + l31) * 128u;
+  const int wblk = (NB == 5) ? wn * 4 : wn * NB;
+  const int wblk_last = (NB == 5) ? 8 + wn : wn * NB + NB - 1;
+  const uint32_t wrd = (uint32_t)PC::XBYTES + (uint32_t)(wblk * 32 + l31) * 128u;
+  const uint32_t wrd_last = (uint32_t)PC::XBYTES + (uint32_t)(wblk_last * 32 + l31) * 128u;
+
+  const uint32_t vx0 = (uint32_t)(lr * p.ldx * 2 + ((pos ^ (lr >> 1)) << 4));
+  const uint32_t vw0 = (uint32_t)(lr * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4));
+  uint32_t aoff[CONV ? 4 : 1];
+  uint32_t amask[CONV ? 2 : 1];
+  const int64_t cbias = CONV ? ((int64_t)p.Wd + 1) * p.Cin : 0;
+  int64_t ld_m0 = 0, ld_n0 = 0;
+  int ld_par = 0;
+  int ik0 = 0, itap = 0, ici0 = 0;
+  // Scalar DMA bases of this wave's first X / W piece for the K-tile requested next, advanced by 128 bytes per K-tile; the other
+  // pieces are a 32-bit offset away (i * 8 rows).  (Recomputing (row0 + 8 pc) * ld + k0 per piece cost ~20 dependent SALU
+  // instructions per piece — 180 per wave and K-tile — in front of the first MFMA of every K-tile.)
+  uint64_t xk = 0, wk = 0, rbk = 0;
+  const uint32_t sx8 = (uint32_t)(p.ldx * 16), sw8 = (uint32_t)(p.ldw * 16);      // bytes between two pieces (8 rows)
+  auto setup_tile = [&](int64_t tt) {
+    const int64_t tile_n = tt % p.tiles_n, tile_m = tt / p.tiles_n;
+    ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
+    ik0 = 0; itap = 0; ici0 = 0;
+    ld_par ^= 1;
+    if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx);
+    wk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw);
+    if (EPI == EPI_LINEAR && p.rowbias) rbk = (uint64_t)(uintptr_t)(p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0);
+    if constexpr (CONV != 0) {
+      amask[0] = 0; amask[1] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (wid * 4 + i) * 8 + lr;
+        const int slot = pos ^ ((r >> 1) & 7);
+        const int64_t m = ld_m0 + r;
+        const int hw = p.Ho * p.Wo;
+        const int b = (int)(m / hw);
+        const int rem = (int)(m - (int64_t)b * hw);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        uint32_t mask = 0;
+        if constexpr (CONV == 2) {
+          const int sy0 = (oy - 1) >> 1, sx0 = (ox - 1) >> 1;
+          aoff[i] = (uint32_t)(((((int64_t)b * p.H + sy0) * p.Wd + sx0) * p.Cin + cbias) * 2 + slot * 16);
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int yy = oy + tp / 3 - 1, xx = ox + tp % 3 - 1;
+            if (yy >= 0 && yy < p.He && xx >= 0 && xx < p.We) mask |= 1u << tp;
+          }
+          amask[i >> 1] |= (mask << (9 * (i & 1))) | ((uint32_t)(~oy & 1) << (18 + 2 * (i & 1))) | ((uint32_t)(~ox & 1) << (19 + 2 * (i & 1)));
+        } else {
+          const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+          aoff[i] = (uint32_t)(((((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + cbias) * 2 + slot * 16);
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int yy = y0 + tp / 3, xx = x0 + tp % 3;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1u << tp;
+          }
+          amask[i >> 1] |= mask << (9 * (i & 1));
+        }
+      }
+    }
+  };
+  // DMA pieces [A, B) of the K-tile at the running position (ik0 / itap / ici0) into stage buf; the position moves on with the last piece
+  auto issue_pieces = [&](int buf, auto a_c, auto b_c) __attribute__((always_inline)) {
+    constexpr int A = decltype(a_c)::value, B = decltype(b_c)::value;
+    if constexpr (A >= B) return;
+    const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
+    if constexpr (A == 0) {
+      if (ik0 == 0) {
+        const uint32_t bdst = lds0 + (uint32_t)PC::BIAS_OFF + (uint32_t)ld_par * PC::BIAS_STRIDE;
+        if (p.bias) {
+          if (wid == 0) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0, bdst);
+          if (NB == 5 && wid == 1) { if (lane < 16) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0 + 256, bdst + 1024u); }
+        }
+        if (EPI == EPI_LINEAR && p.rowbias && wid == 2) {
+          if (lane < PC::BN / 8) glds16_s((uint32_t)lane * 16u, (const void*)(uintptr_t)rbk, bdst + 1280u);
+        }
+      }
+    }
+    if constexpr (CONV != 0) {
+      const int ky = itap / 3, kx = itap - ky * 3;
+      const uint16_t* xb = CONV == 2 ? p.X + (ici0 - cbias) : p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
+      const uint32_t rowb = (uint32_t)(p.Wd * p.Cin * 2), colb = (uint32_t)(p.Cin * 2);
+      const uint32_t yE = (uint32_t)((ky + 1) >> 1) * rowb, yO = (uint32_t)(ky >> 1) * rowb;
+      const uint32_t xE = (uint32_t)((kx + 1) >> 1) * colb, xO = (uint32_t)(kx >> 1) * colb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < A || i >= B) continue;
+        const uint32_t d = dst + (uint32_t)(wid * 4 + i) * 1024u;
+        const uint32_t mk = amask[i >> 1];
+        uint32_t vo = aoff[i];
+        if constexpr (CONV == 2) vo += (((mk >> (18 + 2 * (i & 1))) & 1u) ? yE : yO) + (((mk >> (19 + 2 * (i & 1))) & 1u) ? xE : xO);
+        if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
+        else glds16_s(0u, g_zero_page, d);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < A || i >= B) continue;
+        const int pc = wid * 4 + i;
+        glds16_s(vx0 ^ (uint32_t)((i & 1) << 6), (const void*)(uintptr_t)(xk + (uint64_t)(uint32_t)(i * sx8)), dst + (uint32_t)pc * 1024u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (4 + i < A || 4 + i >= B) continue;
+      const int pc = wid * NB + i;
+      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), (const void*)(uintptr_t)(wk + (uint64_t)(uint32_t)(i * sw8)), dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
+    }
+    if constexpr (B == NP) {
+      if constexpr (CONV != 0) {
+        ici0 += 64;
+        if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
+      }
+      ik0 += 64;
+      xk += 128; wk += 128;
+    }
+  };
+  // DMA share of phase PHASE (template) of a K-tile; `late` = first K-tile of a tile (everything one phase later)
+  auto issue_phase = [&](int buf, auto ph_c, bool late) __attribute__((always_inline)) {
+    constexpr int ph = decltype(ph_c)::value;
+    using I = std::integral_constant<int, 0>;
+    auto rng = [&](auto s_c) __attribute__((always_inline)) {       // pieces of schedule slot s
+      constexpr int s = decltype(s_c)::value;
+      if constexpr (NPH == 4 && SCHED == 0) {
+        constexpr int a = s == 0 ? 0 : (s == 1 ? 3 : 6), b = s == 0 ? 3 : (s == 1 ? 6 : NP);
+        issue_pieces(buf, std::integral_constant<int, a>{}, std::integral_constant<int, b>{});
+      } else if constexpr (NPH == 4) {
+        if constexpr (s == 0) issue_pieces(buf, I{}, std::integral_constant<int, 5>{});
+        if constexpr (s == 1) issue_pieces(buf, std::integral_constant<int, 5>{}, std::integral_constant<int, NP>{});
+      } else {
+        if constexpr (s == 0) issue_pieces(buf, I{}, std::integral_constant<int, NP>{});
+      }
+    };
+    if constexpr (NPH == 4) {
+      if (!late) {
+        if constexpr (ph < 3) rng(std::integral_constant<int, ph>{});
+      } else {
+        // first K-tile of a tile: nothing in phase 0 (epilogue buffers), then five pieces, then the rest
+        if constexpr (ph == 1) issue_pieces(buf, I{}, std::integral_constant<int, 5>{});
+        if constexpr (ph == 2) issue_pieces(buf, std::integral_constant<int, 5>{}, std::integral_constant<int, NP>{});
+      }
+    } else {
+      // two phases per K-tile: everything in phase 0 (first K-tile of a tile: group 0's phase 0 precedes the end of the other
+      // waves' epilogues, so it takes phase 1 there)
+      if constexpr (ph == 0) { if (!late) rng(I{}); }
+      if constexpr (ph == 1) { if (late) rng(I{}); }
+    }
+  };
+
+  f32x16_t acc[NB][2];
+  u32x4_t fx[PH][2], fw[PH][NB];
+  auto load_frags = [&](int buf, int ks0) __attribute__((always_inline)) {
+    const char* xs = smem_b + buf * PC::STAGE + xrd;
+    const char* ws = smem_b + buf * PC::STAGE + wrd;
+    const char* wl = smem_b + buf * PC::STAGE + wrd_last;
+#pragma unroll
+    for (int s = 0; s < PH; ++s) {
+      const uint32_t ko = koff0 ^ (uint32_t)((ks0 + s) << 5);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) fx[s][tm] = *reinterpret_cast<const u32x4_t*>(xs + tm * 4096 + ko);
+#pragma unroll
+      for (int tn = 0; tn < NB - 1; ++tn) fw[s][tn] = *reinterpret_cast<const u32x4_t*>(ws + tn * 4096 + ko);
+      fw[s][NB - 1] = *reinterpret_cast<const u32x4_t*>(wl + ko);
+    }
+  };
+  auto mfma_phase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < PH; ++s)
+#pragma unroll
+      for (int tn = 0; tn < NB; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[s][tn], fx[s][tm], acc[tn][tm]);
+  };
+
+  // prologue: the first K-tile of the first tile, complete for everybody
+  setup_tile(t);
+  issue_pieces(0, std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  pp_barrier();
+  int buf = 0;
+  for (;;) {
+    const int64_t tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
+    const int64_t tnext = t + G;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int cur_par = ld_par;
+    if (grp) pp_barrier();                         // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool last = kt + 1 >= nk;
+      const bool more = !last || tnext < ntiles;   // a K-tile follows this one (this tile's next or the next tile's first)
+      const bool late = kt == 0;
+      static_for<NPH>([&](auto ph_c) __attribute__((always_inline)) {
+        constexpr int ph = decltype(ph_c)::value;
+        // ---- L section
+        load_frags(buf, ph * PH);
+        if (more) {
+          if constexpr (ph == 0 || (NPH == 4 && ph == 1) || (NPH == 2 && ph == 1)) {
+            // the next tile's first K-tile: set the tile up right before its first piece is issued
+            const bool first_piece_here = (NPH == 4) ? (late ? ph == 1 : ph == 0) : (late ? ph == 1 : ph == 0);
+            if (last && first_piece_here) setup_tile(tnext);
+          }
+          issue_phase(buf ^ 1, ph_c, late);
+          if constexpr (ph == NPH - 1) { if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_barrier();                              // B1
+        // ---- M section
+        __builtin_amdgcn_s_setprio(1);
+        mfma_phase();
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ph == NPH - 1) { if (more && !grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        pp_barrier();                              // B2
+      });
+      buf ^= 1;
+    }
+    if (!grp) pp_barrier();                        // group 0 waits for group 1's last phase: both run the epilogue together
+
+    persist_epilogue<EPI, NB, RES>(p, acc, reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * 68),
+                                   reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE),
+                                   reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280),
+                                   m0, n0, wm, wblk, wblk_last, lane);
+    if (tnext >= ntiles) break;
+    t = tnext;
+  }
+}
+
+template <int CONV, int EPI, int NB, bool RES, int PH, int SCHED>
+int launch_pp(hipStream_t stream, const GemmParams& p, int cus) {
+  using PC = PPCfg<NB>;
+  static uint64_t attr_done = 0;
+  if (int rc = a3d_once_per_device(attr_done, [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, PH, SCHED>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
+  const int64_t ntiles = p.tiles_m * p.tiles_n;
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  gemm_pp_kernel<CONV, EPI, NB, RES, PH, SCHED><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
+  return a3d_launch_status();
+}
+
+template <int CONV, int PH, int SCHED>
+int launch_pp_conv(int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
+  if (epi == EPI_GEGLU) {
+    if constexpr (CONV == 0) { if (nb == 4) return launch_pp<0, EPI_GEGLU, 4, false, PH, SCHED>(stream, p, cus); }
+    return A3D_EUNSUPPORTED;
+  }
+  if (nb == 5) return p.R ? launch_pp<CONV, EPI_LINEAR, 5, true, PH, SCHED>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 5, false, PH, SCHED>(stream, p, cus);
+  if (nb == 4) return p.R ? launch_pp<CONV, EPI_LINEAR, 4, true, PH, SCHED>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 4, false, PH, SCHED>(stream, p, cus);
+  return A3D_EUNSUPPORTED;
+}
+
+template <int PH, int SCHED>
+int launch_pp_var(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
+  if (conv == 0) return launch_pp_conv<0, PH, SCHED>(epi, nb, stream, p, cus);
+  if (conv == 1) return launch_pp_conv<1, PH, SCHED>(epi, nb, stream, p, cus);
+  return launch_pp_conv<2, PH, SCHED>(epi, nb, stream, p, cus);
+}
+
+}  // namespace
+
+// var: 1 = one k-step per phase, three DMA pieces per phase; 2 = one k-step per phase, five pieces then the rest; 3 = two k-steps per phase
+int A3D_FN(a3d_launch_gemm_pp)(int var, int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
+  switch (var) {
+    case 1: return launch_pp_var<1, 0>(conv, epi, nb, stream, p, cus);
+    case 2: return launch_pp_var<1, 1>(conv, epi, nb, stream, p, cus);
+    case 3: return launch_pp_var<2, 0>(conv, epi, nb, stream, p, cus);
+    default: return A3D_EINVAL;
+  }
+}

@@ -892,6 +892,8 @@ class MVUNetMotionModel(nn.Module):
             self._packed_frozen_sig = sig
             self._packed = None                    # (_pack stored it as the inference pack; that one is rebuilt on demand)
             self._mark_persistent(self._packed_frozen)
+            if getattr(self, "_train_ops", None) is not None:
+                self._train_ops._persistent.clear()    # (weight, derived dgrad operand) pairs of the previous frozen pack: several GB per switch
         Pf = self._packed_frozen
         trainable = lambda m: m is not None and any(p.requires_grad for p in m.parameters())
         for name, mod in (("time_embedding", self.time_embedding), ("camera_embedding", getattr(self, "camera_embedding", None)),

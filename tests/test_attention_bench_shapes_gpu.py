@@ -1,0 +1,98 @@
+"""Kernel-level parity at the launch shapes of the benchmark (BASELINE config 2): the level-0 attention launch
+(8 heads x 16 384 queries x 16 384 keys per group, head_dim 40: flash_attn_dm_kernel) and the level-1 launch (4 096 x 4 096,
+head_dim 80: flash_attn_dm80_kernel), two groups each, through the multi-view and the first-frame row maps, in both storage
+types, against a chunked fp32 softmax attention on the same 16-bit inputs.
+
+What the small-shape kernel tests (tests/test_hip_kernels_gpu.py, <= 1 024 keys) and the end-to-end golden (nearly flat softmax:
+score sd ~ 0.3) cannot see: q, k ~ N(0, 1) give scores with sd ~ 1 over 256 key tiles, so a mis-indexed far tile, a ring-buffer
+wrap error after many tiles or a wrong key stride of the fp16 sample would move the result by far more than the bar; spikes
+are planted around the ring wrap points of the LDS tile rings (8 x 64 keys at head_dim 40, 5 x 64 at head_dim 80), in the
+last tile and in the last key.  Replaces xformers.ops.memory_efficient_attention at attention_processor.py:405, 416, 656.
+Bars: bf16 storage 4e-3, fp16 storage 1.5e-3 (relative L2)."""
+import pytest
+import torch
+
+from animate3d_amd.hip_ops import RowMap
+from tests.torch_ops import rowmap_indices
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops(dtype):
+    from animate3d_amd.hip_ops import HipOps
+    return HipOps(act_dtype=dtype)
+
+
+def chunked_attention_fp32(q, k, v, qm, km, groups, heads, q_len, kv_len, qchunk=2048):
+    """softmax(Q K^T / sqrt(D)) V per (group, head) in fp32, query chunks of ``qchunk`` (a [heads, qchunk, kv_len] score block)."""
+    C = q.shape[1]
+    D = C // heads
+    out = torch.zeros(q.shape[0], C, dtype=torch.float32, device=q.device)
+    qi_all = rowmap_indices(qm, groups, q_len).to(q.device)
+    ki_all = rowmap_indices(km, groups, kv_len).to(q.device)
+    for g in range(groups):
+        qi, ki = qi_all[g], ki_all[g]
+        kg = k.float()[ki].reshape(kv_len, heads, D).transpose(0, 1)            # [heads, kv, D]
+        vg = v.float()[ki].reshape(kv_len, heads, D).transpose(0, 1)
+        for q0 in range(0, q_len, qchunk):
+            rows = qi[q0:q0 + qchunk]
+            qg = q.float()[rows].reshape(-1, heads, D).transpose(0, 1)          # [heads, qc, D]
+            p = torch.softmax(qg @ kg.transpose(1, 2) * (D ** -0.5), dim=-1)
+            out[rows] = (p @ vg).transpose(0, 1).reshape(-1, C)
+    return out
+
+
+def _case(dtype, D, n, F, L, ring_keys, spikes_gain):
+    heads = 8
+    C = heads * D
+    S = n * L
+    g = torch.Generator(device="cuda").manual_seed(1000 + D)
+    qkv = torch.randn(n * F * L, 3 * C, generator=g, device="cuda").to(dtype)
+    q, k, v = qkv[:, :C].contiguous(), qkv[:, C:2 * C].contiguous(), qkv[:, 2 * C:].contiguous()
+    qm = RowMap(F, n * F * L, L, L, F * L)          # multi-view group (b, f): n segments of L rows, F * L apart
+    k0 = RowMap(F, n * F * L, 0, L, F * L)          # first-frame keys: frame 0 of the same video for every f
+    # spikes: key s of group 0 / of the first-frame set = gain x a query of group 0 and of group 1 (so both groups, and in the
+    # first-frame map every frame, see it); positions: around the ring wrap, the last tile's first key, the very last key
+    pos = [ring_keys - 1, ring_keys, S - 64, S - 1]
+    ki = rowmap_indices(qm, F, S).to("cuda")
+    for t, s in enumerate(pos):
+        gain = spikes_gain[t] if isinstance(spikes_gain, (tuple, list)) else spikes_gain + 0.25 * t
+        for grp in range(min(F, 2)):
+            k[ki[grp, s]] = (q[ki[grp, 97 + 613 * t]].float() * gain).to(dtype)
+    return heads, S, q, k, v, qm, k0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-3), (torch.float16, 1.5e-3)])
+@pytest.mark.parametrize("gain", [1.5, 22.0])
+def test_level0_launch_shape_head_dim_40(dtype, tol, gain):
+    """16 384 x 16 384 per group, 8 heads, head_dim 40, two groups.  gain 1.5: every spike is ~14 log2 units above the bulk (inside the
+    max-free window of both storage types).  gain 22: the spike in the LAST tile is ~200 log2 units up (bf16: row sums beyond the
+    2^100 bar -> the workgroup discards 255 tiles of work and takes the exact re-run at the full key count; fp16: P overflows ->
+    re-run), the other three stay moderate."""
+    ops = _ops(dtype)
+    heads, S, q, k, v, qm, k0 = _case(dtype, 40, 4, 2, 4096, 512, gain if gain < 10 else (1.5, 1.75, gain, 2.0))
+    for km, name in ((qm, "multi-view"), (k0, "first-frame")):
+        got = ops.flash_attn(q, k, v, qm, km, 2, heads, S, S).float()
+        want = chunked_attention_fp32(q, k, v, qm, km, 2, heads, S, S)
+        err = ((got - want).norm() / want.norm()).item()
+        worst = ((got - want).norm(dim=1) / (want.norm(dim=1) + 1e-6)).max().item()
+        print(f"[parity] level-0 launch shape {name} {dtype} gain {gain}: rel L2 {err:.3e}, worst row {worst:.3e}")
+        assert torch.isfinite(got).all() and err <= (tol if gain < 10 else 1e-2), (name, err)      # huge scores: the 16-bit pre-scaled Q moves near-ties
+        assert worst <= 0.25, (name, worst)          # no single query row may be wrong (a lost tile moves a row by O(1))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-3), (torch.float16, 1.5e-3)])
+@pytest.mark.parametrize("gain", [1.0, 15.0])
+def test_level1_launch_shape_head_dim_80(dtype, tol, gain):
+    """4 096 x 4 096 per group, 8 heads, head_dim 80, two groups (ring of 5 x 64 keys: spikes at keys 319 / 320, 4 032 and 4 095; gain 15
+    = ~190 log2 units in the last tile: forces the exact re-run)."""
+    ops = _ops(dtype)
+    heads, S, q, k, v, qm, k0 = _case(dtype, 80, 4, 2, 1024, 320, gain if gain < 10 else (1.0, 1.25, gain, 1.5))
+    for km, name in ((qm, "multi-view"), (k0, "first-frame")):
+        got = ops.flash_attn(q, k, v, qm, km, 2, heads, S, S).float()
+        want = chunked_attention_fp32(q, k, v, qm, km, 2, heads, S, S)
+        err = ((got - want).norm() / want.norm()).item()
+        worst = ((got - want).norm(dim=1) / (want.norm(dim=1) + 1e-6)).max().item()
+        print(f"[parity] level-1 launch shape {name} {dtype} gain {gain}: rel L2 {err:.3e}, worst row {worst:.3e}")
+        assert torch.isfinite(got).all() and err <= (tol if gain < 10 else 1e-2), (name, err)
+        assert worst <= 0.25, (name, worst)

@@ -508,3 +508,35 @@ def test_gradient_checkpointing_recomputes_layers_and_changes_no_gradient():
     with torch.no_grad():                                   # the inference path is untouched
         model.enable_gradient_checkpointing()
         assert torch.isfinite(model(**inp).sample).all()
+
+
+def test_packed_weight_with_a_sink_consumer_and_a_sliced_consumer_keeps_both_gradients():
+    """PackW: the GEMM on the full packed operand leaves its fp32 weight gradient in the sink and returns a stride-0 placeholder; a GEMM on
+    a SLICE of the same operand (unet._mv_attention's first-frame K|V projection under frame sharding: ``w_kvq[:2 * C]``) has no sink and
+    returns a real gradient through autograd.  Both must reach the master parameters."""
+    from animate3d_amd import autograd_ops as A
+    torch.manual_seed(0)
+    m1 = torch.randn(6, 8, requires_grad=True)
+    m2 = torch.randn(4, 8, requires_grad=True)
+    w = A.pack_weight(torch.float32, [m1, m2])
+    x = torch.randn(5, 8)
+
+    class SinkGemm(torch.autograd.Function):          # what autograd_ops' GEMM does for a packed operand
+        @staticmethod
+        def forward(ctx, x_, w_, sink):
+            ctx.save_for_backward(x_, w_)
+            ctx.sink = sink
+            return x_ @ w_.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x_, w_ = ctx.saved_tensors
+            return None, A._weight_grad(ctx.sink, w_, dy.t() @ x_), None
+
+    y_full = SinkGemm.apply(x, w, w._a3d_sink)
+    y_slice = x @ w[:6].t()                           # plain consumer of a view: no sink
+    (y_full.sum() * 2.0 + y_slice.sum() * 3.0).backward()
+    w_ref = torch.cat([m1.detach(), m2.detach()], 0).requires_grad_(True)
+    ((x @ w_ref.t()).sum() * 2.0 + (x @ w_ref[:6].t()).sum() * 3.0).backward()
+    assert torch.allclose(m1.grad, w_ref.grad[:6], atol=1e-6) and torch.allclose(m2.grad, w_ref.grad[6:], atol=1e-6)
+    assert w._a3d_sink.grad32 is None

@@ -265,6 +265,55 @@ def bench_gemmcal(ops):
         print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(outs), flush=True)
 
 
+def bench_pp(ops, modes=(13, 14, 15, 16)):
+    """Lockstep persistent kernel (a3d_tune_gemm(13)) vs the ping-pong main loop of gemm_pp.hip (14: one k-step per phase, DMA 3+3+3;
+    15: one k-step per phase, DMA 5+4; 16: two k-steps per phase), interleaved rounds in one process, outputs compared bit for bit."""
+    print("== ping-pong GEMM A/B: median ms / TFLOP/s per mode " + str(modes) + "  [+res = with residual]")
+
+    def run(tag, fl, fn):
+        outs, ref = [], None
+        for rnd_ in range(2):
+            for m in modes:
+                ops.lib.a3d_tune_gemm(m)
+                y = fn()
+                y = y[0] if isinstance(y, tuple) else y
+                if rnd_ == 0:
+                    ref = y.clone() if ref is None else ref
+                    ok = torch.equal(y, ref)
+                med, mn = timeit(fn, reps=9, warm=2)
+                if rnd_ == 0:
+                    outs.append([m, med, mn, ok])
+                else:
+                    o = outs[modes.index(m)]
+                    o[1] = min(o[1], med); o[2] = min(o[2], mn)
+        ops.lib.a3d_tune_gemm(13)
+        print(f"{tag}: " + " | ".join(f"[{m}] {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if ok else ' MISMATCH'}" for m, med, mn, ok in outs), flush=True)
+
+    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (8192, 5120, 8192)]:
+        x = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF); w = (torch.rand(N, K, device="cuda") * 2 - 1).to(BF)
+        run(f"uniform M={M:6d} N={N:5d} K={K:5d}     ", 2.0 * M * N * K, lambda: ops.gemm(x, w))
+    shapes = [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (524288, 320, 1280),
+              (131072, 640, 640), (131072, 1920, 640), (131072, 640, 2560), (32768, 1280, 1280), (32768, 3840, 1280), (32768, 1280, 5120)]
+    for (M, N, K) in shapes:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N)
+        run(f"M={M:7d} N={N:5d} K={K:5d}     ", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias))
+        if N <= 1280:
+            run(f"M={M:7d} N={N:5d} K={K:5d} +res", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias, residual=res))
+    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
+        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
+        bias = torch.randn(N2, device="cuda")
+        run(f"geglu M={M:7d} N2={N2:5d} K={K:5d}", 2.0 * M * N2 * K, lambda: ops.gemm_geglu(x, w, bias))
+    for (B, H, W, Cin, Cout, st, up) in [(128, 64, 64, 320, 320, 1, False), (128, 32, 32, 640, 640, 1, False), (128, 16, 16, 1280, 1280, 1, False),
+                                         (128, 16, 16, 2560, 1280, 1, False), (128, 64, 64, 320, 320, 2, False), (128, 32, 32, 640, 640, 1, True)]:
+        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
+        bias = torch.randn(Cout, device="cuda")
+        He, We = (2 * H, 2 * W) if up else (H, W)
+        Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
+        run(f"conv B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}", 2.0 * B * Ho * Wo * 9 * Cin * Cout, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up))
+
+
 def bench_flash16(_ops):
     """fp16 storage: LDS-DMA kernels with the sampled max-free pass (default) against the round-2 kernels, BASELINE config-2 launch shapes."""
     ops = HipOps(act_dtype=torch.float16)
@@ -457,7 +506,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "pp": bench_pp, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
