@@ -17,6 +17,8 @@ struct GemmParams {
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
   int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
   int ring_spread;      // ring kernel: DMA pieces interleaved with the MFMAs (a3d_tune_gemm(10)) instead of issued back to back (9)
+  int abl;              // -DA3D_ABLATIONS builds only (timing experiments, results wrong): bit 0 = every tile stores to output rows 0..255
+                        // (writes stay in L2), bit 1 = no output stores
   int stagger;          // persistent kernel (experiment, a3d_tune_gemm(500 + u)): CUs start (blockIdx / 8) % 4 * u * ~0.5 us apart
 #ifdef A3D_EXP_CHUNK_MAJOR
   int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
@@ -150,6 +152,105 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
     }
   };
   if constexpr (RES) load_res(0, 0);
+  // Epilogues without a residual (and the fused GEGLU) apply bias / rowbias / alpha (GEGLU: the whole h * gelu(gate)) in the MFMA
+  // layout — a lane holds 4 consecutive columns of one row per register quad, the per-column vectors are broadcast LDS reads —
+  // and send ROUNDED 16-bit values through the transposition buffer: a quarter (GEGLU) / half of the fp32 staging traffic, whose
+  // ds_write_b128 rate (~80 B/clk per CU) made the transposition the longest part of a K = 320 tile's epilogue.  Arithmetic and
+  // rounding per element are exactly those of the fp32-staged path below (kept for residual epilogues: one rounding after the add).
+  if constexpr (EPI == EPI_GEGLU || !RES) {
+    constexpr int RS = (EPI == EPI_GEGLU) ? 80 : 144;        // bytes per staged row: 32 / 64 values + 16 (keeps 16-byte alignment)
+    char* const stg16 = reinterpret_cast<char*>(stg);
+#pragma unroll
+    for (int pi = 0; pi < 2 * NP; ++pi) {
+      const int tm = pi / NP, ps = pi % NP;
+      const int ncol = pass_cols(ps);
+      const int64_t mbase = m0 + wm * 64 + tm * 32;
+      const int64_t nbase = n0 + pass_col0(ps);
+      if constexpr (EPI == EPI_GEGLU) {
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {                      // register quads 2 q2, 2 q2 + 1: columns 16 q2 + 4 g + {0..3} and + 8
+          float hv[8], gv[8], bh[8], bg[8], y[8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c0 = 8 * (2 * q2 + h) + 4 * g;
+            const float4 b0 = p.bias ? *reinterpret_cast<const float4*>(bias_lds + pass_col0(ps) + c0) : float4{0.f, 0.f, 0.f, 0.f};
+            const float4 b1 = p.bias ? *reinterpret_cast<const float4*>(bias_lds + pass_col0(ps) + 32 + c0) : float4{0.f, 0.f, 0.f, 0.f};
+            bh[4 * h] = b0.x; bh[4 * h + 1] = b0.y; bh[4 * h + 2] = b0.z; bh[4 * h + 3] = b0.w;
+            bg[4 * h] = b1.x; bg[4 * h + 1] = b1.y; bg[4 * h + 2] = b1.z; bg[4 * h + 3] = b1.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[4 * h + j] = acc[2 * ps][tm][4 * (2 * q2 + h) + j]; gv[4 * h + j] = acc[2 * ps + 1][tm][4 * (2 * q2 + h) + j]; }
+          }
+          geglu8(hv, gv, bh, bg, y);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            u32x2_t o;
+            o[0] = pack16(y[4 * h], y[4 * h + 1]);
+            o[1] = pack16(y[4 * h + 2], y[4 * h + 3]);
+            *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + (8 * (2 * q2 + h) + 4 * g) * 2) = o;
+          }
+        }
+        wave_lds_fence();
+        const int cc = lane & 3;
+        const int64_t oc = nbase / 2 + 8 * cc;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = 16 * j + (lane >> 2);
+          const int64_t m = mbase + row;
+          const u32x4_t o = *reinterpret_cast<const u32x4_t*>(stg16 + row * RS + cc * 16);
+#ifdef A3D_ABLATIONS
+          if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
+          *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + oc) = o;
+#else
+          *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
+#endif
+        }
+      } else {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const int tn = 2 * ps + tl;
+          if (tn < NB) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int c0 = tl * 32 + 8 * q + 4 * g;           // column within the pass
+              float v[4] = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+              if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias_lds + pass_col0(ps) + c0);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+              }
+              if (p.rowbias) {
+                const u32x2_t tb = *reinterpret_cast<const u32x2_t*>(rowbias_lds + pass_col0(ps) + c0);
+                v[0] += lo16(tb[0]); v[1] += hi16(tb[0]); v[2] += lo16(tb[1]); v[3] += hi16(tb[1]);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = epi_scale(v[e], p.alpha);
+              u32x2_t o;
+              o[0] = pack16(v[0], v[1]);
+              o[1] = pack16(v[2], v[3]);
+              *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + c0 * 2) = o;
+            }
+          }
+        }
+        wave_lds_fence();
+        const int lpr = ncol / 8;
+        const int cc = lane & (lpr - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j * (64 / lpr) >= 32) continue;
+          const int row = (64 / lpr) * j + lane / lpr;
+          const int64_t m = mbase + row;
+          const u32x4_t o = *reinterpret_cast<const u32x4_t*>(stg16 + row * RS + cc * 16);
+#ifdef A3D_ABLATIONS
+          if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
+          *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + nbase + 8 * cc) = o;
+#else
+          *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + nbase + 8 * cc) = o;
+#endif
+        }
+      }
+      wave_lds_fence();
+    }
+    return;
+  }
 #pragma unroll
   for (int pi = 0; pi < 2 * NP; ++pi) {
     const int tm = pi / NP, ps = pi % NP;
@@ -196,7 +297,12 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
         u32x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack16(y[2 * e], y[2 * e + 1]);
+#ifdef A3D_ABLATIONS
+        if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
+        *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + oc) = o;
+#else
         *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + oc) = o;
+#endif
       }
     } else {
       const int lpr = ncol / 8;                                // lanes per row: 8 (64 columns) or 4 (32 columns)
@@ -232,7 +338,12 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
         u32x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack16(v[2 * e], v[2 * e + 1]);
+#ifdef A3D_ABLATIONS
+        if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
+        *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + n) = o;
+#else
         *reinterpret_cast<u32x4_t*>(p.Y + m * p.ldy + n) = o;
+#endif
       }
     }
     wave_lds_fence();
@@ -241,6 +352,8 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
 
 // gemm_ring.hip: the four-stage ring variant of the persistent kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller
 // (try_launch_persist) has filled tiles_m / tiles_n / vm_counted and checked the shape
+// gemm_duo.hip: two 256-thread workgroups per CU on 128-row tiles (short-K dense GEMMs); tiles_m counts 128-row tiles
+__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_duo)(int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
 // gemm_pp.hip: the ping-pong main loop on the same tile / epilogue (var 1..3: phase length and DMA spread)
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_pp)(int var, int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_ring)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);

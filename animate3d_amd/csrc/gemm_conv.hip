@@ -25,6 +25,8 @@ extern int g_gemm_reserved_cus;
 extern int g_gemm_stagger;
 extern int g_gemm_ring;
 extern int g_gemm_pp;
+extern int g_gemm_abl;
+extern int g_gemm_duo;
 #else
 extern int g_wgrad_dma;       // wgrad.hip
 int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
@@ -40,6 +42,8 @@ int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 /
 int g_gemm_ring = 0;           // a3d_tune_gemm(8): two-stage persistent kernel (default), (9) / (10): four-stage ring kernel of gemm_ring.hip with
                                // back-to-back / MFMA-interleaved DMA issue (round-3 experiment: 5-15 % slower at full occupancy, profiles/README.md)
 int g_gemm_pp = 0;             // a3d_tune_gemm(13): lockstep persistent kernel, (14) / (15) / (16): ping-pong main loop of gemm_pp.hip, variants 1 / 2 / 3
+int g_gemm_duo = 0;            // a3d_tune_gemm(17): off, (18): two-workgroups-per-CU kernel (gemm_duo.hip) for dense K <= g_gemm_duo_maxk
+int g_gemm_abl = 0;            // -DA3D_ABLATIONS builds: a3d_tune_gemm(700 + bits), see GemmParams::abl
 int g_gemm_stagger = 0;        // a3d_tune_gemm(500 + u): start-time stagger of the persistent workgroups (A/B experiment: de-phase the epilogue store bursts)
 int g_gemm_reserved_cus = 0;   // a3d_tune_gemm(200 + k): the persistent grid leaves k CUs free (set by the sharded path while an RCCL
                                // all-gather is in flight: its kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
@@ -682,9 +686,17 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   const int64_t ntiles = tiles_m * tiles_n;
   const int64_t rounds = (ntiles + cus - 1) / cus;
   if (ntiles * 100 < rounds * cus * g_gemm_min_fill) return -1000;                  // average fill of the rounds (per cent)
-  p.tiles_m = tiles_m; p.tiles_n = tiles_n;
   p.vm_counted = g_gemm_vm_counted;
+  if constexpr (CONV == 0) {
+    if (g_gemm_duo && p.K <= 1024 && p.M % 128 == 0 && p.K % 32 == 0) {
+      p.tiles_m = p.M / 128; p.tiles_n = tiles_n;
+      p.abl = g_gemm_abl;
+      return A3D_FN(a3d_launch_gemm_duo)(EPI, nb, stream, p, cus);
+    }
+  }
+  p.tiles_m = tiles_m; p.tiles_n = tiles_n;
   p.stagger = g_gemm_stagger;
+  p.abl = g_gemm_abl;
   p.ring_spread = g_gemm_ring == 2;
   if (g_gemm_pp) return A3D_FN(a3d_launch_gemm_pp)(g_gemm_pp, CONV, EPI, nb, stream, p, cus);
   if (g_gemm_ring) return A3D_FN(a3d_launch_gemm_ring)(CONV, EPI, nb, stream, p, cus);
@@ -816,6 +828,10 @@ extern "C" int a3d_tune_gemm(int bk) {
   if (bk >= 8 && bk <= 10) { g_gemm_ring = bk - 8; return A3D_OK; }
   if (bk == 11 || bk == 12) { g_wgrad_dma = bk - 11; return A3D_OK; }
   if (bk >= 13 && bk <= 16) { g_gemm_pp = bk - 13; return A3D_OK; }
+  if (bk == 17 || bk == 18) { g_gemm_duo = bk - 17; return A3D_OK; }
+#ifdef A3D_ABLATIONS
+  if (bk >= 700 && bk <= 703) { g_gemm_abl = bk - 700; return A3D_OK; }
+#endif
 #ifdef A3D_EXP_CHUNK_MAJOR
   if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
 #endif

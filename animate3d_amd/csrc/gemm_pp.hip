@@ -161,8 +161,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         const uint32_t mk = amask[i >> 1];
         uint32_t vo = aoff[i];
         if constexpr (CONV == 2) vo += (((mk >> (18 + 2 * (i & 1))) & 1u) ? yE : yO) + (((mk >> (19 + 2 * (i & 1))) & 1u) ? xE : xO);
-        if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
-        else glds16_s(0u, g_zero_page, d);
+        // one DMA instruction per piece with per-lane 64-bit sources: in-image taps read X, the others the zero page (the two exec-masked
+        // instructions of the lockstep kernel cost two branches per piece in the L section)
+        const uint64_t src = ((mk >> (itap + 9 * (i & 1))) & 1u) ? (uint64_t)(uintptr_t)xb + vo : (uint64_t)(uintptr_t)g_zero_page;
+        glds16_v((const void*)(uintptr_t)src, d);
       }
     } else {
 #pragma unroll

@@ -46,7 +46,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         flops = 4.0 * G * S * S * C
         ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in ((0, 19, 16, 5, 0, 19) if D == 40 else ((17, 8, 42, 43, 17, 8, 42) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
+        for var in ((0, 5, 21, 0, 5, 21) if D == 40 else ((17, 8, 42, 43, 17, 8, 42) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
             if ops.lib.a3d_tune_flash(var) != 0:      # ablation variants exist only in -DA3D_ABLATIONS builds
                 continue
             out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
@@ -56,7 +56,7 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         ops.lib.a3d_tune_flash(0)
 
 
-def bench_flashdm(ops, variants=(19, 21, 25, 29, 33, 32, 19, 21, 25, 29, 33), scales=(1.0, 0.0, 3.0)):
+def bench_flashdm(ops, variants=(5, 21, 25, 29, 33, 32, 5, 21, 25, 29, 33), scales=(1.0, 0.0, 3.0)):
     """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel
     (a3d_tune_flash(20 + flags)) against the interleaved kernel (0), interleaved rounds in one process; err vs the interleaved
     kernel's output.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
@@ -78,28 +78,6 @@ def bench_flashdm(ops, variants=(19, 21, 25, 29, 33, 32, 19, 21, 25, 29, 33), sc
             med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5)
             print(f"level-0 D=40 scale={sc} var={var:2d}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err vs var 0 = {err:.2e}", flush=True)
         ops.lib.a3d_tune_flash(0)
-
-
-def bench_il_abl(ops):
-    """Timing ablations of the interleaved D = 40 attention kernel (-DA3D_ABLATIONS build; results wrong by construction)."""
-    D, n, F, L, b = 40, 4, 16, 4096, 2
-    heads, C = 8, 8 * D
-    qkv = rnd(b * n * F * L, 3 * C)
-    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    qm = RowMap(F, n * F * L, L, L, F * L)
-    S, G = n * L, b * F
-    flops = 4.0 * G * S * S * C
-    names = {0: "full", 1: "no exp", 2: "no max/vote", 4: "no staging", 8: "no barrier", 12: "no staging, no barrier", 16: "no QK mfma", 32: "no PV mfma",
-             48: "no mfma", 64: "no frag reads", 76: "no frag reads/staging/barrier", 129: "no exp, no cvt", 131: "no exp/cvt/max",
-             207: "mfma only (no exp/cvt/max/staging/barrier/frag reads)", 124: "no mfma/frag/staging/barrier: exp+cvt+max only"}
-    names = {0: "full", 256: "tile request in the odd step", 512: "barrier without vmcnt wait", 768: "both", 4: "no staging", 8: "no barrier"}
-    for base, tag in ((1000, "8 waves"), (1000, "8 waves (second pass)")):
-        for a, nm in names.items():
-            if ops.lib.a3d_tune_flash(base + a) != 0:
-                continue
-            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=4)
-            print(f"il {tag} ABL={a:3d} {nm:58s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s-equivalent")
-    ops.lib.a3d_tune_flash(0)
 
 
 def bench_gemm(ops):
@@ -314,11 +292,84 @@ def bench_pp(ops, modes=(13, 14, 15, 16)):
         run(f"conv B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}", 2.0 * B * Ho * Wo * 9 * Cin * Cout, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up))
 
 
+def bench_epiabl(ops):
+    """What the epilogue of the small-K persistent GEMMs waits for (-DA3D_ABLATIONS build, results wrong by construction): normal | every tile
+    stores to output rows 0..255 (the writes never leave L2) | no output stores at all; lockstep (13) and ping-pong (14) main loops."""
+    print("== epilogue ablations: median ms for  normal | stores stay in L2 | no stores")
+    shapes = [(524288, 320, 320, False), (524288, 320, 320, True), (524288, 960, 320, False), (524288, 1280, 320, False), (131072, 1920, 640, False),
+              (131072, 640, 640, True), (32768, 1280, 1280, True)]
+    for mode in (13, 14):
+        ops.lib.a3d_tune_gemm(mode)
+        for (M, N, K, r) in shapes:
+            x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+            bias = torch.randn(N, device="cuda")
+            res = rnd(M, N) if r else None
+            out = []
+            for a in (0, 1, 2):
+                if ops.lib.a3d_tune_gemm(700 + a) != 0:
+                    out.append("   n/a")
+                    continue
+                med, _ = timeit(lambda: ops.gemm(x, w, bias, residual=res), reps=9, warm=2)
+                out.append(f"{med:7.3f}")
+            ops.lib.a3d_tune_gemm(700)
+            print(f"mode {mode} M={M:7d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + " | ".join(out) + f"   (MFMA-only bound at 1250 TF/s: {2.0 * M * N * K / 1250e9:6.3f} ms; HBM bytes / 6 TB/s: {2.0 * (M * K + (2 if r else 1) * M * N) / 6e9:6.3f} ms)", flush=True)
+        x, w = rnd(524288, 320), rnd(2560, 320, scale=320 ** -0.5)
+        bias = torch.randn(2560, device="cuda")
+        out = []
+        for a in (0, 1, 2):
+            if ops.lib.a3d_tune_gemm(700 + a) != 0:
+                continue
+            med, _ = timeit(lambda: ops.gemm_geglu(x, w, bias), reps=9, warm=2)
+            out.append(f"{med:7.3f}")
+        ops.lib.a3d_tune_gemm(700)
+        print(f"mode {mode} geglu M=524288 N2=2560 K=320: " + " | ".join(out), flush=True)
+    ops.lib.a3d_tune_gemm(13)
+
+
+def bench_duo(ops):
+    """Short-K dense GEMMs: lockstep persistent kernel (13 + 17) | ping-pong (14 + 17) | two workgroups per CU on 128-row tiles (gemm_duo.hip, 18);
+    interleaved rounds, outputs compared bit for bit with the lockstep kernel's."""
+    print("== short-K GEMM A/B: median ms / TFLOP/s   lockstep | ping-pong | duo")
+    MODES = ((13, 17), (14, 17), (13, 18))
+
+    def run(tag, fl, fn):
+        outs, ref = [None] * len(MODES), None
+        for rnd_ in range(2):
+            for i, m in enumerate(MODES):
+                for k_ in m:
+                    ops.lib.a3d_tune_gemm(k_)
+                y = fn()
+                if rnd_ == 0:
+                    ref = y.clone() if ref is None else ref
+                    ok = torch.equal(y, ref)
+                    err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
+                med, mn = timeit(fn, reps=9, warm=2)
+                outs[i] = [med, ok, err] if rnd_ == 0 else [min(outs[i][0], med), outs[i][1], outs[i][2]]
+        ops.lib.a3d_tune_gemm(13); ops.lib.a3d_tune_gemm(17)
+        print(f"{tag}: " + " | ".join(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if ok else f' MISMATCH {err:.2e}'}" for med, ok, err in outs), flush=True)
+
+    for (M, N, K) in [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (131072, 640, 640), (131072, 1920, 640), (131072, 2560, 640),
+                      (32768, 1280, 640), (4096, 320, 320), (524288, 320, 64)]:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N)
+        run(f"M={M:7d} N={N:5d} K={K:5d}     ", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias))
+        if N <= 1280:
+            run(f"M={M:7d} N={N:5d} K={K:5d} +res", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias, residual=res))
+    rb = rnd(128, 320)
+    x, w = rnd(524288, 320), rnd(320, 320, scale=320 ** -0.5)
+    run("M= 524288 N=  320 K=  320 +rowbias", 2.0 * 524288 * 320 * 320, lambda: ops.gemm(x, w, None, rowbias=rb, rb_div=4096, alpha=0.7))
+    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640)]:
+        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
+        bias = torch.randn(N2, device="cuda")
+        run(f"geglu M={M:7d} N2={N2:5d} K={K:5d}", 2.0 * M * N2 * K, lambda: ops.gemm_geglu(x, w, bias))
+
+
 def bench_flash16(_ops):
     """fp16 storage: LDS-DMA kernels with the sampled max-free pass (default) against the round-2 kernels, BASELINE config-2 launch shapes."""
     ops = HipOps(act_dtype=torch.float16)
     print("== fp16 storage flash attention: default (LDS-DMA, sampled max-free) vs round-2 kernels; median ms / TFLOP/s; err = rel L2 vs round-2 kernel")
-    for (D, n, F, L, b, old) in ((40, 4, 16, 4096, 2, 19), (80, 4, 16, 1024, 2, 8)):
+    for (D, n, F, L, b, old) in ((40, 4, 16, 4096, 2, 5), (80, 4, 16, 1024, 2, 8)):
         heads, C = 8, 8 * D
         rows = b * n * F * L
         for scale in (1.0, 2.0):
@@ -506,7 +557,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "il_abl": bench_il_abl, "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "pp": bench_pp, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "pp": bench_pp, "duo": bench_duo, "epiabl": bench_epiabl, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
