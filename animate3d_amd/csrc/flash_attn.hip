@@ -36,12 +36,6 @@
 #include "common.h"
 #include "flash_common.h"
 
-// tuning knobs shared by the bf16 and the fp16 build of this file (defined once, in the bf16 object)
-#ifdef A3D_STORAGE_F16
-extern int g_flash_variant;
-#else
-int g_flash_variant = 0;   // a3d_tune_flash(): 0 = default dispatch, 5 = plain kernel only, 20 + flags = flash_attn_dm_kernel flag set, 8 / 17 / 40 .. 43 = head_dim 80 choices
-#endif
 
 namespace {
 
@@ -79,8 +73,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
-  const int head = blockIdx.x % p.heads;
-  const int qt = blockIdx.x / p.heads;
+  // Default order: head fastest, so with 8 heads block b runs on XCD b % 8 = head and all query tiles of a (group, head) share one
+  // L2 copy of its K/V.  When K/V are a handful of tokens (cross attention: 77 text + 4 image tokens) the traffic is Q in and O out, and
+  // a token row's 8 head slices (80 .. 320 B of one 640 .. 2560-B row) read / written from 8 different XCDs cost every 128-B line
+  // twice; then the order is query-tile-major per XCD: block b -> XCD x = b % 8, slot s = b / 8, head = s % heads, tile = 8 (s / heads) + x.
+  int head = blockIdx.x % p.heads;
+  int qt = blockIdx.x / p.heads;
+  if (p.q_tiles_per_xcd_order) {
+    const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    head = sl % p.heads;
+    qt = (sl / p.heads) * 8 + x;
+  }
   const int64_t grp = blockIdx.y;
   const int64_t hoff = (int64_t)head * D;
 
@@ -569,34 +572,26 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
 
 
 template <int D, int BKV, int QT, int OFS, int VAR = 0, int NM = 0>
-void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
+void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p0) {
+  AttnParams p = p0;
   const int q_tiles = (p.q_len + 128 * QT - 1) / (128 * QT);
+  p.q_tiles_per_xcd_order = (p.kv_len <= 128 && q_tiles % 8 == 0) ? 1 : 0;
   const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
   if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true, VAR, NM><<<grid, dim3(256), 0, s>>>(p);
   else flash_attn_kernel<D, BKV, QT, OFS, false, 0><<<grid, dim3(256), 0, s>>>(p);
 }
 
 template <int D, int BKV, int OFS>
-void launch_two(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
+void launch_two(bool aligned, int groups, hipStream_t s, const AttnParams& p0) {
+  AttnParams p = p0;
   const int q_tiles = (p.q_len + 127) / 128;
+  p.q_tiles_per_xcd_order = (p.kv_len <= 128 && p.kv_len2 <= 128 && q_tiles % 8 == 0) ? 1 : 0;
   const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
   if (aligned) flash_attn_kernel<D, BKV, 1, OFS, true, 0, 0, true><<<grid, dim3(256), 0, s>>>(p);
   else flash_attn_kernel<D, BKV, 1, OFS, false, 0, 0, true><<<grid, dim3(256), 0, s>>>(p);
 }
 
 }  // namespace
-
-extern int g_a3d_ta_pix;      // temporal_attn.hip
-
-#ifndef A3D_STORAGE_F16
-extern "C" int a3d_tune_flash(int variant) {
-  if (variant == 11 || variant == 12 || variant == 14) { g_a3d_ta_pix = variant - 10; return A3D_OK; }
-  if (variant == 8 || variant == 17 || (variant >= 20 && variant <= 43)) { g_flash_variant = variant; return A3D_OK; }     // head dim 80: force two / one query sub-tile per wave
-  if (variant != 0 && variant != 5) return A3D_EINVAL;
-  g_flash_variant = variant;
-  return A3D_OK;
-}
-#endif
 
 static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                            const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
@@ -611,7 +606,9 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
   p.Q = (const uint16_t*)Q; p.K = (const uint16_t*)K; p.V = (const uint16_t*)V; p.O = (uint16_t*)O;
   p.qm = *qmap; p.km = *kmap; p.om = *omap;
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len;
+  if (accumulate & ~(A3D_ATTN_ACCUMULATE | A3D_ATTN_CAUSAL | A3D_ATTN_EXACT | A3D_ATTN_PLAIN)) return A3D_EINVAL;
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate & 1; p.causal = (accumulate >> 1) & 1;
+  const bool exact = (accumulate & A3D_ATTN_EXACT) != 0, plain = (accumulate & A3D_ATTN_PLAIN) != 0;
   p.lse = lse;
   if (p.causal && head_dim != 64 && head_dim != 160) return A3D_EUNSUPPORTED;     // offered on the raw-score (fma) kernels only
   const int bkv = head_dim == 160 ? 32 : 64;
@@ -620,41 +617,24 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
   switch (head_dim) {
     case 40:
       if (q_len <= 128) { launch<40, 64, 1, OFS_PAD>(aligned, groups, s, p); break; }
-      // LDS-DMA staged kernel (flash_attn_dm.hip).  bf16 storage: the default for the long aligned shapes (flags 5: max-free first
-      // pass + P·V through the 16x16x32 MFMA); a3d_tune_flash(20 + flags) forces a flag set, 5 the plain kernel below.
-      // fp16 storage runs the same flag set with a sampled offset and fp16's narrower window (flash_attn_dm.hip, DM_BIAS).
-      {
-        const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 256;      // (a workgroup covers 512 queries)
-        int dm_flags = (g_flash_variant >= 20 && g_flash_variant <= 35) ? g_flash_variant - 20 : -1;
-        if (g_flash_variant == 0) dm_flags = 5;
-        if (long_aligned && dm_flags >= 0) {
-          if (int rc = A3D_FN(a3d_launch_flash_dm)(dm_flags, groups, s, p)) return rc;
-          break;
-        }
+      // LDS-DMA staged kernel (flash_attn_dm.hip): the default for the long aligned shapes in both storage types (max-free first
+      // pass + P·V through the 16x16x32 MFMA; fp16 storage with a sampled offset and fp16's narrower window, DM_BIAS there);
+      // A3D_ATTN_EXACT runs its exact pass only, A3D_ATTN_PLAIN the generic kernel below.
+      if (!plain && aligned && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 256) {      // (a workgroup covers 512 queries)
+        if (int rc = A3D_FN(a3d_launch_flash_dm)(exact ? 4 : 5, groups, s, p)) return rc;
+        break;
       }
       launch<40, 64, 2, OFS_PAD, 0>(aligned, groups, s, p);
       break;
     case 80:
-      // long sequences (level 1 of the 512-px configurations): two query sub-tiles per wave, 32-key tiles — every K / V^T
-      // fragment read feeds two MFMAs, which relieves the LDS port that bounds the one-sub-tile kernel (+4-8 %,
-      // profiles/r2_microbench_flash80_ab.log); short ones keep one sub-tile per wave (more workgroups).  a3d_tune_flash(8 | 17) forces either.
-      // LDS-DMA staged kernel (flash_attn_dm80.hip): the default from 512 tokens (both storage types); a3d_tune_flash(42) forces it (43: its exact pass only),
-      // 8 / 17 force the kernels below
-      {
-        const bool long_aligned = aligned && kv_len % 64 == 0 && kv_len >= 256;
-        int dm_flags = g_flash_variant == 42 ? 1 : (g_flash_variant == 43 ? 0 : -1);
-        if (g_flash_variant == 0 && kv_len >= 512 && q_len >= 256) dm_flags = 1;
-        if (long_aligned && dm_flags >= 0) {
-          if (int rc = A3D_FN(a3d_launch_flash_dm80)(dm_flags, groups, s, p)) return rc;
-          break;
-        }
+      // LDS-DMA staged kernel (flash_attn_dm80.hip): the default from 512 keys (both storage types).  Otherwise: long sequences take
+      // two query sub-tiles per wave and 32-key tiles — every K / V^T fragment read feeds two MFMAs, which relieves the LDS port that
+      // bounds the one-sub-tile kernel (+4-8 %, profiles/r2_microbench_flash80_ab.log); short ones keep one sub-tile per wave.
+      if (!plain && aligned && kv_len % 64 == 0 && kv_len >= 512 && q_len >= 256) {
+        if (int rc = A3D_FN(a3d_launch_flash_dm80)(exact ? 0 : 1, groups, s, p)) return rc;
+        break;
       }
-#ifndef A3D_STORAGE_F16
-      // bf16, long aligned sequences: max-free first pass with the offset in the MFMA's C operand (a3d_tune_flash(40); 41: one query sub-tile)
-      if (g_flash_variant == 40 && aligned && kv_len % 32 == 0 && kv_len >= 128) { launch<80, 32, 2, OFS_ACC, 0, 1>(true, groups, s, p); break; }
-      if (g_flash_variant == 41 && aligned && kv_len % 64 == 0 && kv_len >= 256) { launch<80, 64, 1, OFS_ACC, 0, 1>(true, groups, s, p); break; }
-#endif
-      if (g_flash_variant == 8 || (g_flash_variant != 17 && q_len >= 2048 && kv_len >= 2048)) { launch<80, 32, 2, OFS_FMA>(aligned, groups, s, p); break; }
+      if (q_len >= 2048 && kv_len >= 2048) { launch<80, 32, 2, OFS_FMA>(aligned, groups, s, p); break; }
       launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p);
       break;
     case 64: launch<64, 64, 1, OFS_FMA>(aligned, groups, s, p); break;        // CLIP text tower (12 heads of 64)

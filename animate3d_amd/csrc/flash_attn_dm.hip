@@ -625,24 +625,13 @@ int launch_dm(int groups, hipStream_t s, const AttnParams& p) {
 
 }  // namespace
 
-// flags: see flash_attn_dm_kernel; + 8 = 16 waves x 32 queries instead of 8 x 64.  Shapes: head_dim 40, kv_len % 64 == 0, kv_len >= 256,
-// aligned segments (checked by the caller).
+// flags: 5 = max-free first pass + exact re-run on overflow (the default), 4 = exact pass only; both with P·V through the 16x16x32 MFMA and
+// 8 waves x 64 queries (the other flag sets of flash_attn_dm_kernel were round-3 A/B variants: profiles/README.md).  Shapes: head_dim 40,
+// kv_len % 64 == 0, kv_len >= 256, aligned segments (checked by the caller).
 int A3D_FN(a3d_launch_flash_dm)(int flags, int groups, hipStream_t s, const AttnParams& p) {
   switch (flags) {
-    case 0: return launch_dm<0, 2>(groups, s, p);
-    case 1: return launch_dm<1, 2>(groups, s, p);
-    case 2: return launch_dm<2, 2>(groups, s, p);
-    case 3: return launch_dm<3, 2>(groups, s, p);
     case 4: return launch_dm<4, 2>(groups, s, p);
     case 5: return launch_dm<5, 2>(groups, s, p);
-    case 7: return launch_dm<7, 2>(groups, s, p);
-    case 9: return launch_dm<1, 1>(groups, s, p);
-    case 12: return launch_dm<4, 1>(groups, s, p);
-    case 13: return launch_dm<5, 1>(groups, s, p);
-#ifdef A3D_ABLATIONS
-    case 14: return launch_dm<5 + 16, 2>(groups, s, p);      // no per-tile barrier
-    case 15: return launch_dm<1 + 16, 2>(groups, s, p);
-#endif
     default: return A3D_EINVAL;
   }
 }

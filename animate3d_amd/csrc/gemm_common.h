@@ -1,6 +1,5 @@
-// Shared pieces of the GEMM / implicit-GEMM convolution kernels (gemm_conv.hip: 128 x 128 and persistent two-stage kernels,
-// gemm_ring.hip: persistent four-stage ring kernel): launch parameters, epilogue arithmetic, LDS-DMA helpers and the
-// LDS-transposing epilogue of the persistent 256 x (NB*64) tiles.
+// Shared pieces of the GEMM / implicit-GEMM convolution kernels (gemm_conv.hip: 128 x 128 tiles and the dispatch; gemm_pp.hip: persistent
+// 256 x (NB*64) tiles): launch parameters, epilogue arithmetic, LDS-DMA helpers and the LDS-transposing epilogue of the persistent tiles.
 #pragma once
 #include "common.h"
 
@@ -15,20 +14,18 @@ struct GemmParams {
   float alpha, beta;
   int vec16;            // output / residual / rowbias rows allow 16-byte accesses
   int out_f32;          // 128x128 kernel only: Y is float (attention logits of the VAE mid block must not be rounded to bf16)
-  int vm_counted;       // persistent kernel: leave the epilogue's stores in flight across the next tile's first wait
-  int ring_spread;      // ring kernel: DMA pieces interleaved with the MFMAs (a3d_tune_gemm(10)) instead of issued back to back (9)
   int abl;              // -DA3D_ABLATIONS builds only (timing experiments, results wrong): bit 0 = every tile stores to output rows 0..255
                         // (writes stay in L2), bit 1 = no output stores
-  int stagger;          // persistent kernel (experiment, a3d_tune_gemm(500 + u)): CUs start (blockIdx / 8) % 4 * u * ~0.5 us apart
-#ifdef A3D_EXP_CHUNK_MAJOR
-  int chunk_major;      // 3x3 conv, experiment builds only: walk K as (64-channel chunk, tap) instead of (tap, chunk)
-#endif
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up, He, We;   // He x We: extent of the (virtual) upsampled image of the up2x conv
   int64_t tiles_n, tiles_m;
 };
 
 constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;
+
+// the per-call `flags` word of a3d_gemm / a3d_gemm_geglu / a3d_conv3x3 (include/animate3d_hip.h)
+static inline int a3d_gemm_kernel_of(int flags) { return flags & A3D_GEMM_KERNEL_MASK; }
+static inline int a3d_gemm_reserved_cus_of(int flags) { return flags & A3D_GEMM_RESERVED_CUS_MASK; }
 
 // alpha * v and + beta * r with the roundings pinned (no compiler-chosen fma contraction), so that every kernel variant
 // produces bit-identical outputs for any alpha (the AlphaBlender mix uses alpha = sigmoid(mix_factor))
@@ -96,11 +93,6 @@ A3D_DEV void glds16_v(const void* gsrc, uint32_t lds_dst) {
 }
 A3D_DEV void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_dst) {
   unsigned keep;
-#ifdef A3D_EXP_CHUNK_MAJOR
-  const uint64_t a = (uint64_t)(uintptr_t)sbase;      // wave-uniform by construction; say so (folds away when already scalar)
-  sbase = (const void*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
-#endif
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
@@ -352,8 +344,6 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
 
 // gemm_ring.hip: the four-stage ring variant of the persistent kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller
 // (try_launch_persist) has filled tiles_m / tiles_n / vm_counted and checked the shape
-// gemm_duo.hip: two 256-thread workgroups per CU on 128-row tiles (short-K dense GEMMs); tiles_m counts 128-row tiles
-__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_duo)(int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
-// gemm_pp.hip: the ping-pong main loop on the same tile / epilogue (var 1..3: phase length and DMA spread)
-__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_pp)(int var, int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
-__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_ring)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
+// gemm_pp.hip: the persistent 256 x (nb * 64) tile kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller (try_launch_persist,
+// gemm_conv.hip) has filled tiles_m / tiles_n and checked the shape
+__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_pp)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);

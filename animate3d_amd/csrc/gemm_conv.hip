@@ -14,41 +14,6 @@
 // share the same A rows are neighbours => A is fetched from HBM once per XCD, W stays in L2).
 #include "gemm_common.h"
 
-// tuning knobs shared by the bf16 and the fp16 build of this file (defined once, in the bf16 object)
-#ifdef A3D_STORAGE_F16
-extern int g_gemm_min_fill;
-extern int g_conv_chunk_major;
-extern int g_gemm_vm_counted;
-extern int g_gemm_persist;
-extern int g_gemm_bk;
-extern int g_gemm_reserved_cus;
-extern int g_gemm_stagger;
-extern int g_gemm_ring;
-extern int g_gemm_pp;
-extern int g_gemm_abl;
-extern int g_gemm_duo;
-#else
-extern int g_wgrad_dma;       // wgrad.hip
-int g_gemm_min_fill = 50;     // a3d_tune_gemm(300 + pct): minimum average CU fill of the persistent grid's rounds; at 50 % (level 3,
-                              // 128 tiles) it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md)
-int g_conv_chunk_major = 0;  // experiment builds (-DA3D_EXP_CHUNK_MAJOR) only: a3d_tune_gemm(6) tap-major K walk (= the shipped order), (7)
-                             // chunk-major.  Round 2: inside the experiment build chunk-major wins 0-7 % (profiles/r2_microbench_conv_korder.log),
-                             // but the build itself (scalarised DMA bases, K offset no longer a constant) makes every persistent GEMM / conv
-                             // 2-10 % slower than the shipped one in the full step (profiles/README.md): not shipped
-int g_gemm_vm_counted = 1;   // a3d_tune_gemm(4): drain every store before a tile's first K-step, (5): counted wait (default)
-int g_gemm_persist = 2;  // a3d_tune_gemm(1): persistent kernel off (A/B measurements), (2): on, compiler-scheduled K loop, (3): on, pinned
-                         // fragment prefetch (default: +0..6 % on MI355X, profiles/r1_microbench_persist.log)
-int g_gemm_bk = 0;      // a3d_tune_gemm(): 0 = auto (BK 32 when K <= 640), 32 / 64 = forced
-int g_gemm_ring = 0;           // a3d_tune_gemm(8): two-stage persistent kernel (default), (9) / (10): four-stage ring kernel of gemm_ring.hip with
-                               // back-to-back / MFMA-interleaved DMA issue (round-3 experiment: 5-15 % slower at full occupancy, profiles/README.md)
-int g_gemm_pp = 0;             // a3d_tune_gemm(13): lockstep persistent kernel, (14) / (15) / (16): ping-pong main loop of gemm_pp.hip, variants 1 / 2 / 3
-int g_gemm_duo = 0;            // a3d_tune_gemm(17): off, (18): two-workgroups-per-CU kernel (gemm_duo.hip) for dense K <= g_gemm_duo_maxk
-int g_gemm_abl = 0;            // -DA3D_ABLATIONS builds: a3d_tune_gemm(700 + bits), see GemmParams::abl
-int g_gemm_stagger = 0;        // a3d_tune_gemm(500 + u): start-time stagger of the persistent workgroups (A/B experiment: de-phase the epilogue store bursts)
-int g_gemm_reserved_cus = 0;   // a3d_tune_gemm(200 + k): the persistent grid leaves k CUs free (set by the sharded path while an RCCL
-                               // all-gather is in flight: its kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
-#endif
-
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -134,12 +99,6 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   RegTile rt0, rt1;     // two K-tiles in flight (prefetch distance 2)
   auto load_tile = [&](int64_t k0, RegTile& rt) {
     u32x4_t (&ra)[NPASS] = rt.a; u32x4_t (&rw)[NPASS] = rt.w;
-#ifdef A3D_EXP_CHUNK_MAJOR
-    if (CONV == 1 && p.chunk_major) {       // same K walk as the persistent kernel: (64-channel chunk, tap, position in the chunk)
-      const int64_t j = k0 >> 6, c = j / 9;
-      k0 = (j - c * 9) * p.Cin + c * 64 + (k0 & 63);
-    }
-#endif
     if constexpr (CONV != 0) {
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
@@ -383,289 +342,15 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 
 
 // =====================================================================================================================
-// Persistent 256 x (NB*64) variant for the big token matrices (levels 0-2 of the UNet: M = 32768 ... 524288).
-//
-// One 512-thread workgroup per CU (8 waves as 4(M) x 2(N), each wave owns 64 x NB*32 outputs = 2 x NB MFMA 32x32x16
-// tiles, NB = 5 => BN = 320: every channel count of the model is a multiple of 320, and a full-width N tile means A is
-// read from HBM exactly once at level 0) walks a strided list of output tiles.  Operand K-tiles (64 wide) go global ->
-// LDS directly with global_load_lds_dwordx4 (no staging registers, no ds_write: the ds_write_b128 path of the 128x128
-// kernel costs ~13 LDS cycles per instruction and was the co-limiter with the barrier), two LDS stages, ONE barrier per
-// K-tile.  The LDS image is lane-linear per DMA instruction (8 rows x 128 B), so the bank swizzle
-// (16-byte chunk index ^= (row >> 1) & 7, conflict-free for the 16-lane groups of ds_read_b128) is applied on the
-// per-lane SOURCE address and again on the fragment read address.  The K-tile stream runs across tile boundaries:
-// the first K-tile of the next tile is in flight while the epilogue of the current one drains through the LDS stage
-// that was just consumed, so prologue/epilogue latency is hidden even for the 5-step K = 320 contractions.
-// 3x3 convolutions use the same kernel: the A "row" pointer is the tap-(0,0) pixel, out-of-image taps read a zero page.
-constexpr int PBM = 256;
-template <int NB> struct PCfg {
-  static constexpr int BN = NB * 64;
-  static constexpr int XBYTES = PBM * 128;
-  static constexpr int WBYTES = BN * 128;
-  static constexpr int EPI_BYTES = 8 * 32 * 68 * 4;                    // per-wave 32 x 68 fp32 transposition buffers
-  static constexpr int STAGE = (XBYTES + WBYTES) > EPI_BYTES ? (XBYTES + WBYTES) : EPI_BYTES;
-  static constexpr int BIAS_OFF = 2 * STAGE;                           // [2 tile parities][bias fp32 @0 | rowbias bf16 @1280]
-  static constexpr int BIAS_STRIDE = 2048;
-  static constexpr int SMEM = 2 * STAGE + 2 * BIAS_STRIDE;
-  static constexpr int NPASS = (NB + 1) / 2;                           // epilogue passes of <= 64 columns per 32-row half
-};
-
-
-template <int CONV, int EPI, int NB, bool RES, int VAR>
-__global__ __launch_bounds__(512, 1) void gemm_persist_kernel(const GemmParams p) {
-  using PC = PCfg<NB>;
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  char* const smem_b = reinterpret_cast<char*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int l31 = lane & 31, g = lane >> 5;
-  const int lr = lane >> 3, pos = lane & 7;            // DMA role: row within the 8-row piece, 16-byte slot
-  const uint32_t lds0 = lds_addr(smem);
-
-  const int64_t ntiles = p.tiles_m * p.tiles_n;
-  const int64_t G = gridDim.x;
-  int64_t t = xcd_remap(blockIdx.x, G);
-  if (t >= ntiles) return;
-  const int nk = (int)(p.K / 64);
-  if (p.stagger > 0) {
-    const int phase = (int)((blockIdx.x >> 3) & 3);
-    for (int i = 0; i < phase * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);      // ~1 000 cycles each
-  }
-
-  // fragment reads: lane reads row (.. + l31), logical chunk 2*ks + g, stored at chunk ^ ((row >> 1) & 7); every block
-  // base row is a multiple of 16, so the swizzle term depends on the lane only: offset(ks) = koff0 ^ (ks << 5)
-  const uint32_t koff0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
-  const uint32_t xrd = (uint32_t)(wm * 64 + l31) * 128u;
-  // Column blocks of 32 owned by wave column wn (NB = 5): {4 wn .. 4 wn + 3} and 8 + wn, so that the 64-column epilogue
-  // passes of BOTH wave columns start on 128-byte lines of the output rows (a contiguous 160-column split starts wave
-  // column 1 at byte 320 = 2.5 lines and every one of its 128-byte row segments straddles two lines)
-  const int wblk = (NB == 5) ? wn * 4 : wn * NB;        // first column block (local tn 0)
-  const int wblk_last = (NB == 5) ? 8 + wn : wn * NB + NB - 1;
-  const uint32_t wrd = (uint32_t)PC::XBYTES + (uint32_t)(wblk * 32 + l31) * 128u;
-  const uint32_t wrd_last = (uint32_t)PC::XBYTES + (uint32_t)(wblk_last * 32 + l31) * 128u;
-
-  // ---- DMA sources.  A DMA piece is 8 consecutive tile rows; its rows are a uniform stride apart, so the piece
-  //      position goes into the scalar base address and the per-lane offset only depends on the piece parity
-  //      (through the swizzle): lane (lr, pos) fetches 16-byte chunk pos ^ ((row >> 1) & 7) of row lr of the piece.
-  // ldx, ldw are multiples of 64 elements here, so the row part has its low 7 bits clear and the odd-piece offset is
-  // the even-piece offset ^ 64 (slot ^ 4)
-  const uint32_t vx0 = (uint32_t)(lr * p.ldx * 2 + ((pos ^ (lr >> 1)) << 4));
-  const uint32_t vw0 = (uint32_t)(lr * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4));
-  // conv: byte offset of the row's tap-(0,0) pixel from (X - cbias) and two 9-bit in-image tap masks per register
-  uint32_t aoff[CONV ? 4 : 1];
-  uint32_t amask[CONV ? 2 : 1];
-  const int64_t cbias = CONV ? ((int64_t)p.Wd + 1) * p.Cin : 0;
-  int64_t ld_m0 = 0, ld_n0 = 0;         // origin of the tile being loaded
-  int ld_par = 0;                       // bias-area parity of the tile being loaded
-  int ik0 = 0, itap = 0, ici0 = 0;      // K position of the next K-tile to request (running state: no divisions in the loop)
-  // scalar DMA bases of this wave's first X / W piece for the K-tile requested next (+ 128 bytes per K-tile; piece i is i * 8 rows on):
-  // recomputing (row0 + 8 pc) * ld + k0 per piece was ~20 dependent SALU instructions per piece in front of every K-tile's MFMAs
-  uint64_t xk = 0, wk0 = 0, rbk = 0;
-  const uint32_t sx8 = (uint32_t)(p.ldx * 16), sw8 = (uint32_t)(p.ldw * 16);
-  auto setup_tile = [&](int64_t tt) {
-    const int64_t tile_n = tt % p.tiles_n, tile_m = tt / p.tiles_n;
-    ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
-    ik0 = 0; itap = 0; ici0 = 0;
-    ld_par ^= 1;
-    if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx);
-    wk0 = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw);
-    if (EPI == EPI_LINEAR && p.rowbias) rbk = (uint64_t)(uintptr_t)(p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0);
-    if constexpr (CONV != 0) {
-      amask[0] = 0; amask[1] = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = (wid * 4 + i) * 8 + lr;
-        const int slot = pos ^ ((r >> 1) & 7);
-        const int64_t m = ld_m0 + r;
-        const int hw = p.Ho * p.Wo;
-        const int b = (int)(m / hw);
-        const int rem = (int)(m - (int64_t)b * hw);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        uint32_t mask = 0;
-        if constexpr (CONV == 2) {
-          // nearest-2x upsample folded into the gather: tap (ky, kx) of output pixel (oy, ox) reads source pixel
-          // ((oy + ky - 1) >> 1, (ox + kx - 1) >> 1) = (sy0 + ((ky + ey) >> 1), sx0 + ((kx + ex) >> 1)) with
-          // sy0 = (oy - 1) >> 1 and ey = 1 for even oy (likewise x): the tap offset is one of four per K-tile
-          const int sy0 = (oy - 1) >> 1, sx0 = (ox - 1) >> 1;
-          aoff[i] = (uint32_t)(((((int64_t)b * p.H + sy0) * p.Wd + sx0) * p.Cin + cbias) * 2 + slot * 16);
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const int yy = oy + tp / 3 - 1, xx = ox + tp % 3 - 1;
-            if (yy >= 0 && yy < p.He && xx >= 0 && xx < p.We) mask |= 1u << tp;
-          }
-          amask[i >> 1] |= (mask << (9 * (i & 1))) | ((uint32_t)(~oy & 1) << (18 + 2 * (i & 1))) | ((uint32_t)(~ox & 1) << (19 + 2 * (i & 1)));
-        } else {
-          const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
-          aoff[i] = (uint32_t)(((((int64_t)b * p.H + y0) * p.Wd + x0) * p.Cin + cbias) * 2 + slot * 16);
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const int yy = y0 + tp / 3, xx = x0 + tp % 3;
-            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd) mask |= 1u << tp;
-          }
-          amask[i >> 1] |= mask << (9 * (i & 1));
-        }
-      }
-    }
-  };
-  auto issue = [&](int buf) {
-    const uint32_t dst = lds0 + (uint32_t)buf * PC::STAGE;
-#ifdef A3D_EXP_CHUNK_MAJOR
-    int wk = ik0;                       // K column of the weight rows of this K-tile
-#else
-    const int wk = ik0;
-    (void)wk;
-#endif
-    if (ik0 == 0) {
-      // per-tile epilogue vectors ride along with the first K-tile: bias (fp32, BN floats) and the tile's rowbias row
-      // (bf16; rb_div is a multiple of 256 here, so all 256 rows of the tile share it) -> no global loads in the epilogue
-      const uint32_t bdst = lds0 + (uint32_t)PC::BIAS_OFF + (uint32_t)ld_par * PC::BIAS_STRIDE;
-      if (p.bias) {
-        if (wid == 0) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0, bdst);
-        if (NB == 5 && wid == 1) { if (lane < 16) glds16_s((uint32_t)lane * 16u, p.bias + ld_n0 + 256, bdst + 1024u); }
-      }
-      if (EPI == EPI_LINEAR && p.rowbias && wid == 2) {
-        if (lane < PC::BN / 8) glds16_s((uint32_t)lane * 16u, (const void*)(uintptr_t)rbk, bdst + 1280u);
-      }
-    }
-    if constexpr (CONV != 0) {
-      const int ky = itap / 3, kx = itap - ky * 3;
-      const uint16_t* xb = CONV == 2 ? p.X + (ici0 - cbias) : p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
-      const uint32_t rowb = (uint32_t)(p.Wd * p.Cin * 2), colb = (uint32_t)(p.Cin * 2);
-      const uint32_t yE = (uint32_t)((ky + 1) >> 1) * rowb, yO = (uint32_t)(ky >> 1) * rowb;
-      const uint32_t xE = (uint32_t)((kx + 1) >> 1) * colb, xO = (uint32_t)(kx >> 1) * colb;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t d = dst + (uint32_t)(wid * 4 + i) * 1024u;
-        const uint32_t mk = amask[i >> 1];
-        uint32_t vo = aoff[i];
-        if constexpr (CONV == 2) vo += (((mk >> (18 + 2 * (i & 1))) & 1u) ? yE : yO) + (((mk >> (19 + 2 * (i & 1))) & 1u) ? xE : xO);
-        if ((mk >> (itap + 9 * (i & 1))) & 1u) glds16_s(vo, xb, d);
-        else glds16_s(0u, g_zero_page, d);                   // out-of-image tap: the piece's other lanes still come from X
-      }
-#ifdef A3D_EXP_CHUNK_MAJOR
-      if (p.chunk_major) {
-        wk = __builtin_amdgcn_readfirstlane(itap * p.Cin + ici0);
-        if (++itap == 9) { itap = 0; ici0 += 64; }
-      } else
-#endif
-      {
-        ici0 += 64;
-        if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pc = wid * 4 + i;
-        glds16_s(vx0 ^ (uint32_t)((i & 1) << 6), (const void*)(uintptr_t)(xk + (uint64_t)(uint32_t)(i * sx8)), dst + (uint32_t)pc * 1024u);
-      }
-    }
-#ifdef A3D_EXP_CHUNK_MAJOR
-    const uint64_t wkk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw + wk);
-#else
-    const uint64_t wkk = wk0;
-#endif
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int pc = wid * NB + i;
-      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), (const void*)(uintptr_t)(wkk + (uint64_t)(uint32_t)(i * sw8)), dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
-    }
-    ik0 += 64;
-    xk += 128; wk0 += 128;
-  };
-
-  f32x16_t acc[NB][2];   // [tn][tm]
-  u32x4_t fx[2][2], fw[2][NB];          // fragment double buffer: k-step ks+1 is requested before the MFMAs of ks issue
-  auto load_frags = [&](int slot, int buf, int ks) {
-    const char* xs = smem_b + buf * PC::STAGE + xrd;
-    const char* ws = smem_b + buf * PC::STAGE + wrd;
-    const char* wl = smem_b + buf * PC::STAGE + wrd_last;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) fx[slot][tm] = *reinterpret_cast<const u32x4_t*>(xs + tm * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
-#pragma unroll
-    for (int tn = 0; tn < NB - 1; ++tn) fw[slot][tn] = *reinterpret_cast<const u32x4_t*>(ws + tn * 4096 + (koff0 ^ (uint32_t)(ks << 5)));
-    fw[slot][NB - 1] = *reinterpret_cast<const u32x4_t*>(wl + (koff0 ^ (uint32_t)(ks << 5)));
-  };
-  auto mfma_step = [&](int slot) {
-#pragma unroll
-    for (int tn = 0; tn < NB; ++tn)
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[slot][tn], fx[slot][tm], acc[tn][tm]);
-  };
-
-  setup_tile(t);
-  issue(0);
-  int buf = 0;
-  bool first_tile = true;
-  // VMEM stores one wave issues per epilogue: they are the newest entries of the (in-order) vmcnt queue at the next
-  // tile's first wait, so vmcnt(NST) retires the K-tile DMA in front of them without draining the stores
-  constexpr int NST = (EPI == EPI_GEGLU) ? 2 * 2 * PC::NPASS : 2 * (4 * (NB / 2) + 2 * (NB & 1));
-  for (;;) {
-    const int64_t tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
-    const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
-    const int64_t tnext = t + G;
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int cur_par = ld_par;                             // bias-area parity of THIS tile (ld_par flips when the next is set up)
-    for (int kt = 0; kt < nk; ++kt) {
-      // this wave's DMA pieces of K-tile kt have landed ...
-      if (kt == 0 && !first_tile && p.vm_counted) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                         // ... everybody's have, and stage buf^1 is no longer read
-      load_frags(0, buf, 0);
-      if (kt + 1 < nk) {
-        issue(buf ^ 1);
-      } else if (tnext < ntiles) {
-        setup_tile(tnext);
-        issue(buf ^ 1);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) load_frags((ks + 1) & 1, buf, ks + 1);
-        if constexpr (VAR == 1) __builtin_amdgcn_sched_barrier(0);     // all 7 fragment reads of ks+1 ahead of the MFMAs of ks
-        mfma_step(ks & 1);
-        if constexpr (VAR == 1) __builtin_amdgcn_sched_barrier(0);
-      }
-      buf ^= 1;
-    }
-    __builtin_amdgcn_s_barrier();                           // stage buf^1 (just consumed) becomes the epilogue staging area
-
-    // ---- epilogue (gemm_common.h): LDS-transposing, 16-byte bias / rowbias / residual / output accesses
-    persist_epilogue<EPI, NB, RES>(p, acc, reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * 68),
-                                   reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE),
-                                   reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280),
-                                   m0, n0, wm, wblk, wblk_last, lane);
-    if (tnext >= ntiles) break;
-    t = tnext;
-    first_tile = false;
-  }
-}
-
-
-template <int CONV, int EPI, int NB, bool RES, int VAR = 0>
-int launch_persist_res(hipStream_t stream, GemmParams& p, int cus) {
-  using PC = PCfg<NB>;
-  if constexpr (VAR == 0) {
-    if (g_gemm_persist == 2) return launch_persist_res<CONV, EPI, NB, RES, 1>(stream, p, cus);
-  }
-  static uint64_t attr_done = 0;
-  if (int rc = a3d_once_per_device(attr_done, [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<CONV, EPI, NB, RES, VAR>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
-  const int64_t ntiles = p.tiles_m * p.tiles_n;
-  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  gemm_persist_kernel<CONV, EPI, NB, RES, VAR><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
-  return a3d_launch_status();
-}
-
+// The big token matrices (levels 0-2 of the UNet: M = 32768 ... 524288, 97 % of the GEMM / conv FLOPs) take the persistent
+// 256 x (NB*64) kernel of gemm_pp.hip (one 512-thread workgroup per CU, LDS-DMA staged K-tiles, ping-pong main loop).
 // returns -1000 when the shape is not eligible (caller falls back to the 128x128 kernel)
+constexpr int PBM = 256;
+constexpr int PERSIST_MIN_FILL = 50;     // minimum average CU fill (per cent) of the persistent grid's rounds: at 50 % (level 3, 128 tiles)
+                                         // it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md, round 1)
 template <int CONV, int EPI>
-int try_launch_persist(hipStream_t stream, GemmParams& p) {
-  if (!g_gemm_persist || p.out_f32) return -1000;
+int try_launch_persist(hipStream_t stream, GemmParams& p, int flags) {
+  if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || p.out_f32) return -1000;
   static int cus_of[64] = {0};
   const int dev = a3d_current_device();
   if (cus_of[dev] == 0) {
@@ -673,7 +358,10 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
     cus_of[dev] = n > 0 ? n : 256;
   }
-  const int cus = cus_of[dev] - g_gemm_reserved_cus > 32 ? cus_of[dev] - g_gemm_reserved_cus : 32;
+  // the persistent grid leaves the caller's reserved CUs free (the sharded path while an RCCL all-gather is in flight: its
+  // kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
+  const int reserved = a3d_gemm_reserved_cus_of(flags);
+  const int cus = cus_of[dev] - reserved > 32 ? cus_of[dev] - reserved : 32;
   if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return -1000;
   const int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
   if (nb == 0) return -1000;
@@ -685,27 +373,9 @@ int try_launch_persist(hipStream_t stream, GemmParams& p) {
   const int64_t tiles_m = (p.M + PBM - 1) / PBM, tiles_n = p.N / (nb * 64);
   const int64_t ntiles = tiles_m * tiles_n;
   const int64_t rounds = (ntiles + cus - 1) / cus;
-  if (ntiles * 100 < rounds * cus * g_gemm_min_fill) return -1000;                  // average fill of the rounds (per cent)
-  p.vm_counted = g_gemm_vm_counted;
-  if constexpr (CONV == 0) {
-    if (g_gemm_duo && p.K <= 1024 && p.M % 128 == 0 && p.K % 32 == 0) {
-      p.tiles_m = p.M / 128; p.tiles_n = tiles_n;
-      p.abl = g_gemm_abl;
-      return A3D_FN(a3d_launch_gemm_duo)(EPI, nb, stream, p, cus);
-    }
-  }
+  if (ntiles * 100 < rounds * cus * PERSIST_MIN_FILL) return -1000;                  // average fill of the rounds (per cent)
   p.tiles_m = tiles_m; p.tiles_n = tiles_n;
-  p.stagger = g_gemm_stagger;
-  p.abl = g_gemm_abl;
-  p.ring_spread = g_gemm_ring == 2;
-  if (g_gemm_pp) return A3D_FN(a3d_launch_gemm_pp)(g_gemm_pp, CONV, EPI, nb, stream, p, cus);
-  if (g_gemm_ring) return A3D_FN(a3d_launch_gemm_ring)(CONV, EPI, nb, stream, p, cus);
-  if constexpr (EPI == EPI_GEGLU) {
-    return launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
-  } else {
-    if (nb == 5) return p.R ? launch_persist_res<CONV, EPI, 5, true>(stream, p, cus) : launch_persist_res<CONV, EPI, 5, false>(stream, p, cus);
-    return p.R ? launch_persist_res<CONV, EPI, 4, true>(stream, p, cus) : launch_persist_res<CONV, EPI, 4, false>(stream, p, cus);
-  }
+  return A3D_FN(a3d_launch_gemm_pp)(CONV, EPI, nb, stream, p, cus);
 }
 
 
@@ -729,9 +399,11 @@ int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
 }
 
 template <int CONV, int EPI = EPI_LINEAR>
-int launch(hipStream_t stream, GemmParams& p) {
+int launch(hipStream_t stream, GemmParams& p, int flags) {
+  if (flags & ~(A3D_GEMM_RESERVED_CUS_MASK | A3D_GEMM_KERNEL_MASK)) return A3D_EINVAL;
+  if (a3d_gemm_kernel_of(flags) > A3D_GEMM_TILE128) return A3D_EINVAL;
   {
-    const int rc = try_launch_persist<CONV, EPI>(stream, p);
+    const int rc = try_launch_persist<CONV, EPI>(stream, p, flags);
     if (rc != -1000) return rc;
   }
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -740,7 +412,7 @@ int launch(hipStream_t stream, GemmParams& p) {
   if (nblk <= 0 || nblk > 0x7fffffffLL) return A3D_EINVAL;
   // measured on MI355X (profiles/r1_microbench_gemm_conv_v4.log): K-step 32 (3-4 workgroups per CU) wins for dense
   // K <= 640 and whenever the grid is under ~3 workgroups per CU; K-step 64 wins elsewhere (all 3x3 convs)
-  const bool small = g_gemm_bk == 32 || (g_gemm_bk == 0 && ((CONV == 0 && p.K <= 640) || nblk < 768));
+  const bool small = (CONV == 0 && p.K <= 640) || nblk < 768;
   if (small) return launch_bk<CONV, EPI, 32>(stream, p, nblk);
   return launch_bk<CONV, EPI, 64>(stream, p, nblk);
 }
@@ -751,7 +423,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int A3D_FN(a3d_gemm)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                              const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
-                             void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta) {
+                             void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
   if (K % 64 != 0 || N % 4 != 0) return A3D_EINVAL;
   if (ldx % 8 != 0 || ldw % 8 != 0 || ldy % 4 != 0 || (R && ldr % 4 != 0)) return A3D_EINVAL;
@@ -765,7 +437,7 @@ extern "C" int A3D_FN(a3d_gemm)(a3d_stream_t stream, const void* X, int64_t ldx,
   p.R = (const uint16_t*)R; p.ldr = ldr; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
   p.vec16 = (ldy % 8 == 0) && aligned16(Y) && (!R || (ldr % 8 == 0 && aligned16(R))) && (!rowbias || (N % 8 == 0 && aligned16(rowbias)));
-  return launch<0>((hipStream_t)stream, p);
+  return launch<0>((hipStream_t)stream, p, flags);
 }
 
 extern "C" int A3D_FN(a3d_gemm_f32out)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
@@ -778,12 +450,12 @@ extern "C" int A3D_FN(a3d_gemm_f32out)(a3d_stream_t stream, const void* X, int64
   p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
   p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = 0.f; p.vec16 = 1; p.out_f32 = 1;
-  return launch<0>((hipStream_t)stream, p);
+  return launch<0>((hipStream_t)stream, p, 0);
 }
 
 extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
                                 const void* rowbias, int64_t rb_div, const void* R, void* Y,
-                                int B, int H, int W, int Cin, int Cout, int stride, int up2x) {
+                                int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags) {
   if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
   if (Cin % 64 != 0 || Cout % 4 != 0 || (stride != 1 && stride != 2)) return A3D_EINVAL;
   if (up2x < 0 || up2x > 7 || (up2x > 1 && !(up2x & 1)) || (up2x && stride != 1)) return A3D_EINVAL;
@@ -803,14 +475,11 @@ extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const voi
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
   p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
-#ifdef A3D_EXP_CHUNK_MAJOR
-  p.chunk_major = up2x ? 0 : g_conv_chunk_major;       // both kernels walk K the same way, so they stay bit-identical
-#endif
-  return up2x ? launch<2>((hipStream_t)stream, p) : launch<1>((hipStream_t)stream, p);
+  return up2x ? launch<2>((hipStream_t)stream, p, flags) : launch<1>((hipStream_t)stream, p, flags);
 }
 
 extern "C" int A3D_FN(a3d_gemm_geglu)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
-                                   const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K) {
+                                   const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K, int flags) {
   if (!X || !W || !Y || M <= 0 || N2 <= 0 || K <= 0) return A3D_EINVAL;
   if (K % 64 != 0 || N2 % 64 != 0 || ldx % 8 != 0 || ldw % 8 != 0 || ldy % 8 != 0) return A3D_EINVAL;
   if (!aligned16(X) || !aligned16(W) || !aligned16(Y)) return A3D_EINVAL;
@@ -818,28 +487,5 @@ extern "C" int A3D_FN(a3d_gemm_geglu)(a3d_stream_t stream, const void* X, int64_
   p.X = (const uint16_t*)X; p.ldx = ldx; p.W = (const uint16_t*)W; p.ldw = ldw;
   p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N2; p.K = K; p.alpha = 1.f; p.beta = 0.f; p.vec16 = 1;
-  return launch<0, EPI_GEGLU>((hipStream_t)stream, p);
+  return launch<0, EPI_GEGLU>((hipStream_t)stream, p, flags);
 }
-
-#ifndef A3D_STORAGE_F16
-extern "C" int a3d_tune_gemm(int bk) {
-  if (bk >= 1 && bk <= 3) { g_gemm_persist = bk - 1; return A3D_OK; }
-  if (bk == 4 || bk == 5) { g_gemm_vm_counted = bk - 4; return A3D_OK; }
-  if (bk >= 8 && bk <= 10) { g_gemm_ring = bk - 8; return A3D_OK; }
-  if (bk == 11 || bk == 12) { g_wgrad_dma = bk - 11; return A3D_OK; }
-  if (bk >= 13 && bk <= 16) { g_gemm_pp = bk - 13; return A3D_OK; }
-  if (bk == 17 || bk == 18) { g_gemm_duo = bk - 17; return A3D_OK; }
-#ifdef A3D_ABLATIONS
-  if (bk >= 700 && bk <= 703) { g_gemm_abl = bk - 700; return A3D_OK; }
-#endif
-#ifdef A3D_EXP_CHUNK_MAJOR
-  if (bk == 6 || bk == 7) { g_conv_chunk_major = bk - 6; return A3D_OK; }
-#endif
-  if (bk >= 200 && bk <= 264) { g_gemm_reserved_cus = bk - 200; return A3D_OK; }
-  if (bk >= 500 && bk <= 600) { g_gemm_stagger = bk - 500; return A3D_OK; }
-  if (bk >= 300 && bk <= 400) { g_gemm_min_fill = bk - 300; return A3D_OK; }
-  if (bk != 0 && bk != 32 && bk != 64) return A3D_EINVAL;
-  g_gemm_bk = bk;
-  return A3D_OK;
-}
-#endif

@@ -1,18 +1,24 @@
-// Persistent GEMM / implicit-GEMM 3x3 convolution with a PING-PONG main loop (round 4).
+// Persistent GEMM / implicit-GEMM 3x3 convolution for the big token matrices (levels 0-2 of the UNet: M = 32768 ... 524288).
 //
-// Same tile, LDS images, LDS-DMA pieces and epilogue as gemm_persist_kernel (gemm_conv.hip): one 512-thread workgroup per CU owns
-// 256 x (NB*64) output tiles, 8 waves as 4(M) x 2(N), K-tiles of 64 go global -> LDS by global_load_lds_dwordx4 into two stages.
-// What is different is WHEN a wave does what.  gemm_persist_kernel runs all eight waves in lockstep: wait for the DMA, barrier,
-// nine DMA issues per wave, fragment reads, 40 MFMAs — the matrix pipe idles while every wave queues its DMA requests and
-// waits for its first fragments, and at full occupancy that serial part is as long as the MFMA part (K-tile period 2.4 us
-// against 1.07 us of matrix work; profiles/README.md).  Here the waves form two groups (waves 0-3 / 4-7 = one wave per SIMD
-// each) that run ONE BARRIER APART: while group A issues the MFMAs of a k-phase, group B issues its fragment reads and its share
-// of the next K-tile's DMA, then they swap (the 8-phase / ping-pong schedule of the CDNA4 guide, "256^2 8-phase template",
-// on this kernel's 256 x 320 tile and 32x32x16 MFMA).  Per phase and group:
+// One 512-thread workgroup per CU (8 waves as 4(M) x 2(N), each wave owns 64 x NB*32 outputs = 2 x NB MFMA 32x32x16 tiles, NB = 5 =>
+// BN = 320: every channel count of the model is a multiple of 320, and a full-width N tile means A is read from HBM exactly once at
+// level 0) walks a strided list of 256 x (NB*64) output tiles.  Operand K-tiles (64 wide) go global -> LDS directly with
+// global_load_lds_dwordx4 (no staging registers, no ds_write), two LDS stages.  The LDS image is lane-linear per DMA instruction
+// (8 rows x 128 B), so the bank swizzle (16-byte chunk index ^= (row >> 1) & 7, conflict-free for the 16-lane groups of ds_read_b128)
+// is applied on the per-lane SOURCE address and again on the fragment read address.  The K-tile stream runs across tile boundaries:
+// the first K-tile of the next tile is in flight while the epilogue of the current one drains through the LDS stage that was just
+// consumed.  3x3 convolutions use the same kernel: the A "row" pointer is the tap-(0,0) pixel, out-of-image taps read a zero page.
+//
+// PING-PONG main loop (round 4).  Rounds 1-3 ran the eight waves in lockstep: wait for the DMA, barrier, nine DMA issues per wave,
+// fragment reads, 40 MFMAs — the matrix pipe idled while every wave queued its DMA requests and waited for its first fragments.
+// Here the waves form two groups (waves 0-3 / 4-7 = one wave per SIMD each) that run ONE BARRIER APART: while group A issues the
+// MFMAs of a k-phase, group B issues its fragment reads and its share of the next K-tile's DMA, then they swap (the 8-phase /
+// ping-pong schedule of the CDNA4 guide, "256^2 8-phase template", on this kernel's 256 x 320 tile and 32x32x16 MFMA): +4-10 % at
+// K >= 1280, equal at K = 320 / 640 and for the convolutions, bit-identical outputs (profiles/README.md, round 4).  Per phase and group:
 //
 //     L section:  ds_read_b128 fragments of this phase | LDS-DMA pieces of the next K-tile | s_waitcnt lgkmcnt(0)
 //     s_barrier (B1)
-//     M section:  s_setprio 1 | PH x 10 (NB = 5) MFMAs | s_setprio 0
+//     M section:  s_setprio 1 | 10 (NB = 5) MFMAs of one k-step (16 of K) | s_setprio 0
 //     s_barrier (B2)
 //
 // Group 1 executes one extra barrier in front of every tile, so its L section coincides with group 0's M section and vice
@@ -41,17 +47,35 @@ template <int NB> struct PPCfg {
   static constexpr int SMEM = 2 * STAGE + 2 * BIAS_STRIDE;
 };
 
+// Tile order: groups of PP_GM rows of tiles, column-major inside a group, so that the 32 consecutive tile ids an XCD works on at
+// any time are an 8 x 4 block (8 A panels + 4 W panels per K-tile through that XCD's L2) instead of one row of up to 32 different
+// W panels — the wide projections (N >= 2560: 8-40 column tiles) otherwise stream all of W through every L2 once per row of tiles.
+#ifndef A3D_PP_GM
+#define A3D_PP_GM 8
+#endif
+constexpr int PP_GM = A3D_PP_GM;
+A3D_DEV void pp_tile_coords(int64_t t, int64_t tiles_m, int64_t tiles_n, int64_t& tile_m, int64_t& tile_n) {
+  const int64_t gsz = PP_GM * tiles_n;
+  const int64_t blk = t / gsz;
+  const int64_t first = blk * PP_GM;
+  const int64_t gm = tiles_m - first < PP_GM ? tiles_m - first : PP_GM;
+  const int64_t within = t - blk * gsz;
+  tile_n = within / gm;
+  tile_m = first + (within - tile_n * gm);
+}
+
 A3D_DEV void pp_barrier() {
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// PH: k-steps (16 of K) per phase, 1 or 2.  SCHED: how the 4 + NB DMA pieces a wave issues per K-tile are spread over the phases
-// (0: three per phase, 1: five then the rest).
-template <int CONV, int EPI, int NB, bool RES, int PH, int SCHED>
+// Four phases (k-steps of 16) per K-tile; the 4 + NB DMA pieces a wave issues per K-tile go three per phase into phases 0-2 (measured
+// against five-then-the-rest and against two k-steps per phase: profiles/r4_microbench_pp.log).
+// CONV: 0 = dense A, 1 = 3x3 conv gather (pad 1, stride 1|2), 2 = 3x3 conv over a nearest-2x upsampled input
+template <int CONV, int EPI, int NB, bool RES>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   using PC = PPCfg<NB>;
-  constexpr int NPH = 4 / PH;                 // phases per K-tile
+  constexpr int PH = 1, NPH = 4;              // k-steps per phase, phases per K-tile
   constexpr int NP = 4 + NB;                  // DMA pieces per wave and K-tile: X 0..3, W 0..NB-1
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   char* const smem_b = reinterpret_cast<char*>(smem);
@@ -90,7 +114,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   uint64_t xk = 0, wk = 0, rbk = 0;
   const uint32_t sx8 = (uint32_t)(p.ldx * 16), sw8 = (uint32_t)(p.ldw * 16);      // bytes between two pieces (8 rows)
   auto setup_tile = [&](int64_t tt) {
-    const int64_t tile_n = tt % p.tiles_n, tile_m = tt / p.tiles_n;
+    int64_t tile_n, tile_m;
+    pp_tile_coords(tt, p.tiles_m, p.tiles_n, tile_m, tile_n);
     ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
     ik0 = 0; itap = 0; ici0 = 0;
     ld_par ^= 1;
@@ -189,35 +214,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
       xk += 128; wk += 128;
     }
   };
-  // DMA share of phase PHASE (template) of a K-tile; `late` = first K-tile of a tile (everything one phase later)
+  // DMA share of phase ph of a K-tile; `late` = first K-tile of a tile (nothing in phase 0: the epilogue buffers; then five, then the rest)
   auto issue_phase = [&](int buf, auto ph_c, bool late) __attribute__((always_inline)) {
     constexpr int ph = decltype(ph_c)::value;
-    using I = std::integral_constant<int, 0>;
-    auto rng = [&](auto s_c) __attribute__((always_inline)) {       // pieces of schedule slot s
-      constexpr int s = decltype(s_c)::value;
-      if constexpr (NPH == 4 && SCHED == 0) {
-        constexpr int a = s == 0 ? 0 : (s == 1 ? 3 : 6), b = s == 0 ? 3 : (s == 1 ? 6 : NP);
-        issue_pieces(buf, std::integral_constant<int, a>{}, std::integral_constant<int, b>{});
-      } else if constexpr (NPH == 4) {
-        if constexpr (s == 0) issue_pieces(buf, I{}, std::integral_constant<int, 5>{});
-        if constexpr (s == 1) issue_pieces(buf, std::integral_constant<int, 5>{}, std::integral_constant<int, NP>{});
-      } else {
-        if constexpr (s == 0) issue_pieces(buf, I{}, std::integral_constant<int, NP>{});
-      }
-    };
-    if constexpr (NPH == 4) {
-      if (!late) {
-        if constexpr (ph < 3) rng(std::integral_constant<int, ph>{});
-      } else {
-        // first K-tile of a tile: nothing in phase 0 (epilogue buffers), then five pieces, then the rest
-        if constexpr (ph == 1) issue_pieces(buf, I{}, std::integral_constant<int, 5>{});
-        if constexpr (ph == 2) issue_pieces(buf, std::integral_constant<int, 5>{}, std::integral_constant<int, NP>{});
-      }
+    using I0 = std::integral_constant<int, 0>;
+    using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    using IN = std::integral_constant<int, NP>;
+    if (!late) {
+      if constexpr (ph == 0) issue_pieces(buf, I0{}, I3{});
+      if constexpr (ph == 1) issue_pieces(buf, I3{}, I6{});
+      if constexpr (ph == 2) issue_pieces(buf, I6{}, IN{});
     } else {
-      // two phases per K-tile: everything in phase 0 (first K-tile of a tile: group 0's phase 0 precedes the end of the other
-      // waves' epilogues, so it takes phase 1 there)
-      if constexpr (ph == 0) { if (!late) rng(I{}); }
-      if constexpr (ph == 1) { if (late) rng(I{}); }
+      if constexpr (ph == 1) issue_pieces(buf, I0{}, I5{});
+      if constexpr (ph == 2) issue_pieces(buf, I5{}, IN{});
     }
   };
 
@@ -253,7 +264,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   pp_barrier();
   int buf = 0;
   for (;;) {
-    const int64_t tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    int64_t tile_n, tile_m;
+    pp_tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
     const int64_t tnext = t + G;
 #pragma unroll
@@ -273,10 +285,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         // ---- L section
         load_frags(buf, ph * PH);
         if (more) {
-          if constexpr (ph == 0 || (NPH == 4 && ph == 1) || (NPH == 2 && ph == 1)) {
+          if constexpr (ph == 0 || ph == 1) {
             // the next tile's first K-tile: set the tile up right before its first piece is issued
-            const bool first_piece_here = (NPH == 4) ? (late ? ph == 1 : ph == 0) : (late ? ph == 1 : ph == 0);
-            if (last && first_piece_here) setup_tile(tnext);
+            if (last && (late ? ph == 1 : ph == 0)) setup_tile(tnext);
           }
           issue_phase(buf ^ 1, ph_c, late);
           if constexpr (ph == NPH - 1) { if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -304,45 +315,34 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   }
 }
 
-template <int CONV, int EPI, int NB, bool RES, int PH, int SCHED>
+template <int CONV, int EPI, int NB, bool RES>
 int launch_pp(hipStream_t stream, const GemmParams& p, int cus) {
   using PC = PPCfg<NB>;
   static uint64_t attr_done = 0;
   if (int rc = a3d_once_per_device(attr_done, [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, PH, SCHED>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
   const int64_t ntiles = p.tiles_m * p.tiles_n;
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  gemm_pp_kernel<CONV, EPI, NB, RES, PH, SCHED><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
+  gemm_pp_kernel<CONV, EPI, NB, RES><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
   return a3d_launch_status();
 }
 
-template <int CONV, int PH, int SCHED>
+template <int CONV>
 int launch_pp_conv(int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
   if (epi == EPI_GEGLU) {
-    if constexpr (CONV == 0) { if (nb == 4) return launch_pp<0, EPI_GEGLU, 4, false, PH, SCHED>(stream, p, cus); }
+    if constexpr (CONV == 0) { if (nb == 4) return launch_pp<0, EPI_GEGLU, 4, false>(stream, p, cus); }
     return A3D_EUNSUPPORTED;
   }
-  if (nb == 5) return p.R ? launch_pp<CONV, EPI_LINEAR, 5, true, PH, SCHED>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 5, false, PH, SCHED>(stream, p, cus);
-  if (nb == 4) return p.R ? launch_pp<CONV, EPI_LINEAR, 4, true, PH, SCHED>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 4, false, PH, SCHED>(stream, p, cus);
+  if (nb == 5) return p.R ? launch_pp<CONV, EPI_LINEAR, 5, true>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 5, false>(stream, p, cus);
+  if (nb == 4) return p.R ? launch_pp<CONV, EPI_LINEAR, 4, true>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 4, false>(stream, p, cus);
   return A3D_EUNSUPPORTED;
-}
-
-template <int PH, int SCHED>
-int launch_pp_var(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
-  if (conv == 0) return launch_pp_conv<0, PH, SCHED>(epi, nb, stream, p, cus);
-  if (conv == 1) return launch_pp_conv<1, PH, SCHED>(epi, nb, stream, p, cus);
-  return launch_pp_conv<2, PH, SCHED>(epi, nb, stream, p, cus);
 }
 
 }  // namespace
 
-// var: 1 = one k-step per phase, three DMA pieces per phase; 2 = one k-step per phase, five pieces then the rest; 3 = two k-steps per phase
-int A3D_FN(a3d_launch_gemm_pp)(int var, int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
-  switch (var) {
-    case 1: return launch_pp_var<1, 0>(conv, epi, nb, stream, p, cus);
-    case 2: return launch_pp_var<1, 1>(conv, epi, nb, stream, p, cus);
-    case 3: return launch_pp_var<2, 0>(conv, epi, nb, stream, p, cus);
-    default: return A3D_EINVAL;
-  }
+int A3D_FN(a3d_launch_gemm_pp)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
+  if (conv == 0) return launch_pp_conv<0>(epi, nb, stream, p, cus);
+  if (conv == 1) return launch_pp_conv<1>(epi, nb, stream, p, cus);
+  return launch_pp_conv<2>(epi, nb, stream, p, cus);
 }

@@ -15,11 +15,6 @@
 // LDS with register prefetch of the next 32 rows; one barrier per step.  4 waves = 2 x 2, each 64 x 64 of the tile.
 #include "gemm_common.h"      // LDS-DMA helpers (glds16_v, lds_addr), the zero page
 
-#ifdef A3D_STORAGE_F16
-extern int g_wgrad_dma;
-#else
-int g_wgrad_dma = 1;      // a3d_tune_gemm(11): round-2 kernel (register staging, v_perm transposition), (12): LDS-DMA kernel (default)
-#endif
 
 namespace {
 
@@ -29,106 +24,7 @@ struct WgParams {
   int64_t M; int N, K; int tiles_k; int tiles; int splits; int64_t rows_per_split; float alpha;
 };
 
-constexpr int WG_BR = 32;               // token rows per step
-constexpr int WG_TROW = WG_BR + 8;      // transposed image row stride (elements): 5 x 16 B, odd
-constexpr int WG_T = 128 * WG_TROW;     // elements per image
-
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgParams p) {
-  __shared__ __attribute__((aligned(16))) uint16_t smem[4 * WG_T];      // [buffer][A | B]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l31 = lane & 31, g = lane >> 5;
-  const int wn = wid >> 1, wk = wid & 1;
-  // grid.x = output tile, grid.y = token slice.  (Measured alternative: an XCD-aware order that keeps all tiles of one slice on one
-  // XCD's L2 — 2 x SLOWER; the kernel is bound by the latency of its one-step-ahead staging loads, not by HBM re-reads, and the plain
-  // order spreads each slice's lines over all eight L2s.  profiles/README.md, training section.)
-  const int tile = blockIdx.x, split = blockIdx.y;
-  const int n0 = (tile / p.tiles_k) * 128, k0 = (tile % p.tiles_k) * 128;
-  const int64_t m_beg = (int64_t)split * p.rows_per_split;
-  const int64_t m_end = min(p.M, m_beg + p.rows_per_split);
-  // staging role: threads 0..127 transpose dY (operand A), 128..255 transpose X (operand B); item = 4 rows x 8 columns
-  const bool is_a = tid < 128;
-  const int it = tid & 127;
-  const int rq = it >> 4, ch = it & 15;
-  const uint16_t* const src = is_a ? p.dY : p.X;
-  const int64_t ld = is_a ? p.lddy : p.ldx;
-  const int c_first = (is_a ? n0 : k0) + ch * 8;
-  const bool col_ok = c_first < (is_a ? p.N : p.K);
-  u32x4_t stg[4];
-  auto load = [&](int64_t m0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t m = m0 + 4 * rq + j;
-      stg[j] = (col_ok && m < m_end) ? *reinterpret_cast<const u32x4_t*>(src + m * ld + c_first) : u32x4_t{0u, 0u, 0u, 0u};
-    }
-  };
-  auto store = [&](int buf) __attribute__((always_inline)) {
-    uint16_t* const T = smem + (2 * buf + (is_a ? 0 : 1)) * WG_T;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {       // word j of a row holds columns 2j (lo) and 2j+1 (hi)
-      u32x2_t even, odd;
-      even[0] = __builtin_amdgcn_perm(stg[1][j], stg[0][j], 0x05040100u);
-      even[1] = __builtin_amdgcn_perm(stg[3][j], stg[2][j], 0x05040100u);
-      odd[0] = __builtin_amdgcn_perm(stg[1][j], stg[0][j], 0x07060302u);
-      odd[1] = __builtin_amdgcn_perm(stg[3][j], stg[2][j], 0x07060302u);
-      *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j) * WG_TROW + rq * 4) = even;
-      *reinterpret_cast<u32x2_t*>(T + (ch * 8 + 2 * j + 1) * WG_TROW + rq * 4) = odd;
-    }
-  };
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int a_off = (wn * 64 + l31) * WG_TROW + 8 * g;
-  const int b_off = (wk * 64 + l31) * WG_TROW + 8 * g;
-  const int64_t nsteps = (m_end - m_beg + WG_BR - 1) / WG_BR;
-  load(m_beg);
-  store(0);
-  __syncthreads();
-  for (int64_t t = 0; t < nsteps; ++t) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < nsteps) load(m_beg + (t + 1) * WG_BR);
-    const uint16_t* const TA = smem + (2 * buf) * WG_T + a_off;
-    const uint16_t* const TB = smem + (2 * buf + 1) * WG_T + b_off;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4_t af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const u32x4_t*>(TA + 32 * i * WG_TROW + 16 * ks);
-        bf[i] = *reinterpret_cast<const u32x4_t*>(TB + 32 * i * WG_TROW + 16 * ks);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(af[a], bf[b], acc[a][b]);
-    }
-    if (t + 1 < nsteps) store(buf ^ 1);
-    __syncthreads();
-  }
-
-  // partial tile -> workspace [split][n][k]: register r of a lane is row n = 8*(r>>2) + 4*g + (r&3), column k = l31 of its 32 x 32 block
-  float* const out = p.ws + (int64_t)split * p.N * p.K;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int kcol = k0 + wk * 64 + b * 32 + l31;
-      if (kcol < p.K) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nrow = n0 + wn * 64 + a * 32 + mfma_row(r, g);
-          if (nrow < p.N) out[(int64_t)nrow * p.K + kcol] = acc[a][b][r];
-        }
-      }
-    }
-}
-
-// ---- Round 3: the same split-K tile with LDS-DMA staging.  The round-2 kernel above spends its time between the MFMAs: per 32 token
+// ---- The split-K tile with LDS-DMA staging (round 3).  The round-2 kernel (register staging) spent its time between the MFMAs: per 32 token
 // rows a wave has 8 MFMAs (256 cycles) against global loads it waits for one step ahead, 16 v_perm + 8 ds_write_b64 of the
 // transposition and a barrier (130-200 TFLOP/s).  Here both operand tiles go global -> LDS untouched, row-major [token][128 columns]
 // (global_load_lds_dwordx4, 4 rows of 256 B per instruction, exactly four instructions per wave and stage so the wait is a counted
@@ -268,7 +164,7 @@ static void wgrad_plan(int64_t M, int64_t N, int64_t K, int64_t* splits, int64_t
   if (sp > max_splits) sp = max_splits;
   if (sp < 1) sp = 1;
   int64_t rps = (M + sp - 1) / sp;
-  rps = (rps + WG_BR - 1) / WG_BR * WG_BR;
+  rps = (rps + WD_BR - 1) / WD_BR * WD_BR;
   *splits = (M + rps - 1) / rps;
   *rows_per_split = rps;
 }
@@ -293,8 +189,7 @@ extern "C" int A3D_FN(a3d_wgrad)(a3d_stream_t stream, const void* dY, int64_t ld
   wgrad_plan(M, N, K, &splits, &rps);
   if (tiles > 0x7fffffffLL || splits > 65535) return A3D_EINVAL;
   WgParams p{(const uint16_t*)dY, lddy, (const uint16_t*)X, ldx, ws, M, (int)N, (int)K, (int)tiles_k, (int)tiles, (int)splits, rps, alpha};
-  if (g_wgrad_dma) wgrad_dma_kernel<<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), WD_SMEM, s>>>(p);
-  else wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, s>>>(p);
+  wgrad_dma_kernel<<<dim3((unsigned)tiles, (unsigned)splits), dim3(256), WD_SMEM, s>>>(p);
   const int64_t total4 = N * K / 4;
   wgrad_reduce_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s>>>(ws, dW, lddw, (int)N, (int)K, (int)splits, alpha, accumulate);
   return a3d_launch_status();

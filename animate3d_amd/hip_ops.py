@@ -41,15 +41,13 @@ class RowMap:
 # symbol -> (restype, argtypes); mirrors include/animate3d_hip.h line by line
 _SIGNATURES = {
     "a3d_version": (ctypes.c_char_p, []),
-    "a3d_gemm_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32]),
-    "a3d_gemm_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64]),
-    "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_gemm_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_int]),
+    "a3d_gemm_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int]),
+    "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                     c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
     "a3d_flash_attn2_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                      ctypes.POINTER(_RowMapC), c_int, c_int, c_int, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32, c_int]),
-    "a3d_tune_flash": (c_int, [c_int]),
-    "a3d_tune_gemm": (c_int, [c_int]),
     "a3d_temporal_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
     "a3d_temporal_attn_sharded_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32,
                                                c_int, c_int, c_int, c_i64]),
@@ -180,6 +178,13 @@ class HipOps:
         self.act_dtype = act_dtype
         self.lib = _Entry(self.raw_lib, act_dtype == torch.float16)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # compute units the persistent GEMM / conv kernels leave free for concurrently running kernels: passed with EVERY launch (the flags
+        # word of a3d_gemm / a3d_gemm_geglu / a3d_conv3x3) — the library keeps no state.  Set by animate3d_amd.parallel while an RCCL
+        # all-gather is in flight; a HIP graph captured meanwhile replays with the value of its capture.
+        self.reserved_cus = 0
+
+    def _gemm_flags(self, tile128: bool) -> int:
+        return (int(self.reserved_cus) & 0xFF) | (0x100 if tile128 else 0)
 
     # ---- helpers
     def _stream(self):
@@ -194,7 +199,9 @@ class HipOps:
         return torch.empty((rows, cols), dtype=self.act_dtype, device=self.device)
 
     # ---- GEMM family
-    def gemm(self, x, w, bias=None, *, residual=None, alpha: float = 1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None):
+    def gemm(self, x, w, bias=None, *, residual=None, alpha: float = 1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None,
+             tile128: bool = False):
+        """``tile128`` forces the 128 x 128-tile kernel (A3D_GEMM_TILE128: bit-identical results; parity tests and A/B timing)."""
         x, w = self._act(x, "gemm.x"), self._act(w, "gemm.w")
         M, K = x.shape
         N = w.shape[0]
@@ -211,7 +218,7 @@ class HipOps:
             assert bias.dtype == torch.float32 and bias.numel() == N
         rc = self.lib.a3d_gemm_bf16(self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(rowbias), rb_div,
                                     _p(residual), residual.stride(0) if residual is not None else 0, _p(y), y.stride(0),
-                                    M, N, K, alpha, beta)
+                                    M, N, K, alpha, beta, self._gemm_flags(tile128))
         _check(rc, f"a3d_gemm_bf16 M={M} N={N} K={K}")
         return y
 
@@ -223,18 +230,19 @@ class HipOps:
         h, g = w[:n].reshape(n // 32, 32, *w.shape[1:]), w[n:].reshape(n // 32, 32, *w.shape[1:])
         return torch.stack([h, g], dim=1).reshape(w.shape).contiguous()
 
-    def gemm_geglu(self, x, w_il, bias_il):
+    def gemm_geglu(self, x, w_il, bias_il, *, tile128: bool = False):
         """GEGLU(x) = (x Wh^T + bh) * gelu(x Wg^T + bg) with interleaved weights (see interleave_geglu)."""
         x, w_il = self._act(x, "geglu.x"), self._act(w_il, "geglu.w")
         M, K = x.shape
         N2 = w_il.shape[0]
         y = self.empty(M, N2 // 2)
-        rc = self.lib.a3d_gemm_geglu_bf16(self._stream(), _p(x), x.stride(0), _p(w_il), w_il.stride(0), _p(bias_il), _p(y), y.stride(0), M, N2, K)
+        rc = self.lib.a3d_gemm_geglu_bf16(self._stream(), _p(x), x.stride(0), _p(w_il), w_il.stride(0), _p(bias_il), _p(y), y.stride(0), M, N2, K,
+                                          self._gemm_flags(tile128))
         _check(rc, f"a3d_gemm_geglu_bf16 M={M} N2={N2} K={K}")
         return y
 
     def conv3x3(self, x, B: int, H: int, W: int, w, bias, *, stride: int = 1, up2x: bool = False, rowbias=None, rb_div: int = 1, residual=None,
-                up_size=None):
+                up_size=None, tile128: bool = False):
         """x [B*H*W, Cin] -> (y [B*Ho*Wo, Cout], Ho, Wo); w packed [Cout, 9*Cin] (ky, kx, ci).  ``up_size`` = (Ho, Wo) forces
         the size of the nearest upsampling in front of the conv (2H or 2H-1, likewise W: unet_motion_mv_model.py:831-837)."""
         x, w = self._act(x, "conv.x"), self._act(w, "conv.w")
@@ -255,15 +263,17 @@ class HipOps:
         if rowbias is not None:
             assert rowbias.is_contiguous() and rowbias.shape[1] == Cout
         rc = self.lib.a3d_conv3x3_bf16(self._stream(), _p(x), _p(w), _p(bias), _p(rowbias), rb_div, _p(residual), _p(y),
-                                       B, H, W, Cin, Cout, stride, up_code)
+                                       B, H, W, Cin, Cout, stride, up_code, self._gemm_flags(tile128))
         _check(rc, f"a3d_conv3x3_bf16 B={B} H={H} W={W} Cin={Cin} Cout={Cout} stride={stride} up={up2x}")
         return y, Ho, Wo
 
     # ---- attention
     def flash_attn(self, q, k, v, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
                    out=None, out_scale: float = 1.0, accumulate: bool = False, causal: bool = False, with_lse: bool = False,
-                   accumulation_target: bool = False):
-        """``accumulation_target`` is a hint for the autograd op set (autograd_ops.AutogradOps.flash_attn), ignored here.  ``with_lse``: returns (o, lse2) with lse2 [groups, heads, q_len] fp32 = log2 of every query's softmax denominator (training:
+                   accumulation_target: bool = False, exact: bool = False, plain: bool = False):
+        """``exact`` (A3D_ATTN_EXACT): the LDS-DMA staged kernels skip their max-free first pass; ``plain`` (A3D_ATTN_PLAIN): the generic
+        kernel of the short / ragged shapes — per-call choices for the parity tests and A/B timing, results agree to rounding.
+        ``accumulation_target`` is a hint for the autograd op set (autograd_ops.AutogradOps.flash_attn), ignored here.  ``with_lse``: returns (o, lse2) with lse2 [groups, heads, q_len] fp32 = log2 of every query's softmax denominator (training:
         ``flash_attn_bwd(stats=...)`` then skips its statistics pass)."""
         q, k, v = self._act(q, "attn.q"), self._act(k, "attn.k"), self._act(v, "attn.v")
         C = q.shape[1]
@@ -271,15 +281,16 @@ class HipOps:
         assert k.stride(0) == v.stride(0)
         o = out if out is not None else self.empty(q.shape[0], C)
         qm, km, om = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(o.stride(0))
+        flags = (1 if accumulate else 0) | (2 if causal else 0) | (4 if exact else 0) | (8 if plain else 0)
         if with_lse:
             lse = torch.empty((groups, heads, q_len), dtype=torch.float32, device=self.device)
             rc = self.lib.a3d_flash_attn_lse_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
                                                   groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale,
-                                                  (1 if accumulate else 0) | (2 if causal else 0), _p(lse))
+                                                  flags, _p(lse))
             _check(rc, f"a3d_flash_attn_lse_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
             return o, lse
         rc = self.lib.a3d_flash_attn_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
-                                          groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, (1 if accumulate else 0) | (2 if causal else 0))
+                                          groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, flags)
         _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
         return o
 

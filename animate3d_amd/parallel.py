@@ -57,9 +57,11 @@ class ShardPlan:
         self.collectives = 0
         self.gather_tokens = True        # all-gather the attention's input tokens (C wide) instead of projected K|V (2C wide)
         # while a gather is in flight the persistent GEMM / conv kernels (one workgroup per CU) leave this many CUs to the
-        # collective's own kernels; ``cu_knob`` = the C-ABI's a3d_tune_gemm (set by shard_unet on the HIP op set, None on CPU)
+        # collective's own kernels: ``ops.reserved_cus`` of the HIP op set (set by shard_unet; None on CPU) is passed with every
+        # a3d_gemm / a3d_conv3x3 launch as an explicit parameter — the library keeps no state, and a HIP graph captured while a
+        # reservation is active simply replays with it
         self.reserve_cus = 16
-        self.cu_knob = None
+        self.ops = None
         self._in_flight = 0
 
     # ---- layout: world = cfg_shards x view_shards x frame_shards
@@ -129,14 +131,14 @@ class ShardPlan:
     def _overlap(self, delta: int):
         """Book-keeping of asynchronous collectives in flight: the first one reserves CUs for RCCL, the last one to finish frees them."""
         before, self._in_flight = self._in_flight, max(0, self._in_flight + delta)
-        if self.cu_knob is not None and self.reserve_cus > 0 and (before == 0) != (self._in_flight == 0):
-            self.cu_knob(200 + (self.reserve_cus if self._in_flight else 0))
+        if self.ops is not None and self.reserve_cus > 0 and (before == 0) != (self._in_flight == 0):
+            self.ops.reserved_cus = self.reserve_cus if self._in_flight else 0
 
     def release_reservation(self):
         """Drop any CU reservation and forget collectives in flight (start of every configure(); error paths)."""
         self._in_flight = 0
-        if self.cu_knob is not None:
-            self.cu_knob(200)
+        if self.ops is not None:
+            self.ops.reserved_cus = 0
 
     # ---- view axis
     def all_gather_views_start(self, kv: torch.Tensor, b_local: int = 1):
@@ -233,8 +235,8 @@ def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: 
     frame_shards) or None for the default (CFG halves, then views, then frames); ``shape`` = (b, n, F) of the calls to come
     creates the process groups now instead of inside the first forward."""
     unet.parallel = ShardPlan(group, layout)
-    lib = getattr(getattr(unet, "ops", None), "lib", None)          # HIP op set: reserve CUs for RCCL while a gather overlaps the GEMMs
-    unet.parallel.cu_knob = getattr(lib, "a3d_tune_gemm", None) if lib is not None else None
+    ops = getattr(unet, "ops", None)                                # HIP op set: reserve CUs for RCCL while a gather overlaps the GEMMs
+    unet.parallel.ops = ops if hasattr(ops, "reserved_cus") else None
     if shape is not None:
         unet.parallel.configure(*shape)
     return unet.parallel

@@ -62,10 +62,19 @@ typedef struct a3d_rowmap {
  * 322-323,490-493; Transformer2D/Temporal proj_in/out; FeedForward; TimestepEmbedding;
  * ResnetBlock2D.time_emb_proj / conv_shortcut) with the residual add, AlphaBlender mix
  * (attention_processor.py:709) and time-embedding broadcast fused as epilogues.
- * bias, rowbias, R may be NULL.  Requires K % 64 == 0, N % 4 == 0, 16-byte aligned rows. */
+ * bias, rowbias, R may be NULL.  Requires K % 64 == 0, N % 4 == 0, 16-byte aligned rows.
+ * `flags` (also of a3d_gemm_geglu / a3d_conv3x3; 0 = defaults) is a per-call launch parameter — the library keeps no tuning state:
+ *   bits 0-7   A3D_GEMM_RESERVED_CUS: compute units the persistent kernel's grid leaves free for concurrently running kernels
+ *              (the sharded path passes the CUs an in-flight RCCL all-gather needs; at least 32 CUs are always used);
+ *   bits 8-9   kernel choice: 0 = automatic (persistent 256-row-tile kernel for the big token matrices, 128 x 128 tiles otherwise),
+ *              A3D_GEMM_TILE128 = always the 128 x 128-tile kernel (same K order and epilogue arithmetic: bit-identical results;
+ *              A/B measurements and the parity tests).  Other bits must be zero (A3D_EINVAL). */
+#define A3D_GEMM_RESERVED_CUS_MASK 0xff
+#define A3D_GEMM_KERNEL_MASK 0x300
+#define A3D_GEMM_TILE128 0x100
 int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
-                  void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
+                  void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags);
 
 /* Same contraction with an fp32 result: Y[M,N] (float, row stride ldy floats) = alpha * (X W^T + bias).  For logits that must
  * not be rounded to bf16: the single-head 512-wide self-attention of the VAE mid block (diffusers AutoencoderKL, used by
@@ -74,21 +83,13 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
 int a3d_gemm_f32out_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
 
-/* Tuning knob (diagnostics / A-B measurements; results are bit-identical in every mode):
- *   32 | 64  force the K-step of the 128x128-tile kernel, 0 = automatic;
- *   1        disable the persistent 256x320 LDS-DMA kernel (every shape takes the 128x128-tile kernel);
- *   2 | 3    enable it with a compiler-scheduled / pinned fragment prefetch (3 is the default);
- *   4 | 5    persistent kernel: drain every epilogue store before the next tile / leave them in flight (5, default);
- *   300+p    persistent kernel: minimum average fill of the grid's rounds in per cent (default 50). */
-int a3d_tune_gemm(int bk);
-
 /* Fused feed-forward input projection + GEGLU (diffusers FeedForward.net[0] = GEGLU: proj, chunk(2), h * gelu(gate)):
  *   Y[M, N2/2][m, j] = (X·Wh^T + bh)[m, j] * gelu_erf((X·Wg^T + bg)[m, j])
  * W / bias rows must be INTERLEAVED in blocks of 32: rows [64b, 64b+32) = h rows [32b, 32b+32),
  * rows [64b+32, 64b+64) = gate rows [32b, 32b+32), so h and gate of one output column land in the same
  * wave tile and the 2x wider intermediate never goes to HBM.  N2 % 64 == 0, K % 64 == 0. */
 int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
-                        const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K);
+                        const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K, int flags);
 
 /* 3x3 convolution, padding 1, NHWC, as an implicit GEMM (K = 9*Cin):
  *   Y[b, yo, xo, co] = bias[co] + rowbias[(row) / rb_div][co] + R[...]
@@ -100,14 +101,22 @@ int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const v
  * conv_out (unet_motion_mv_model.py:271,859).  Requires Cin % 64 == 0, Cout % 4 == 0. */
 int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
                      const void* rowbias, int64_t rb_div, const void* R, void* Y,
-                     int B, int H, int W, int Cin, int Cout, int stride, int up2x);
+                     int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags);
 
 /* softmax(Q K^T * scale) V per (group, head), flash-style (no score matrix in memory).
  *   O[row_o(g,s), h*D + d] = out_scale * attn(...)   (+ previous O contents if accumulate)
  * Replaces xformers.ops.memory_efficient_attention at attention_processor.py:103,233,268,
  * 405,416,656.  head_dim in {40, 80, 160} (the SD1.5 UNet levels) and 64 (CLIP text tower of pipeline.py:345-524).  K and V share
- * kmap.  `accumulate` bit 0: add to the previous O contents; bit 1: causal mask (key s visible to queries >= s of its group;
- * head_dim 64 / 160 only) — transformers' CLIPTextModel causal attention. */
+ * kmap.  `accumulate` is a per-call flag word: bit 0 (A3D_ATTN_ACCUMULATE): add to the previous O contents; bit 1
+ * (A3D_ATTN_CAUSAL): causal mask (key s visible to queries >= s of its group; head_dim 64 / 160 only) — transformers'
+ * CLIPTextModel causal attention; bit 2 (A3D_ATTN_EXACT): skip the max-free first pass of the LDS-DMA staged kernels (head_dim
+ * 40 / 80, long aligned K/V) and run their exact running-maximum pass directly — the pass a workgroup otherwise re-runs after an
+ * overflow; bit 3 (A3D_ATTN_PLAIN): use the generic kernel that serves the short / ragged shapes (parity tests, A/B timing).
+ * Results agree to rounding in every mode. */
+#define A3D_ATTN_ACCUMULATE 1
+#define A3D_ATTN_CAUSAL 2
+#define A3D_ATTN_EXACT 4
+#define A3D_ATTN_PLAIN 8
 int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
@@ -122,10 +131,6 @@ int a3d_flash_attn2_bf16(a3d_stream_t stream, const void* Q, const void* K, cons
                          const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* kmap2, const a3d_rowmap* omap,
                          int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int64_t kv_len2,
                          float scale, float out_scale, float out_scale2, int accumulate);
-
-/* Tuning knob (diagnostics, used by tools/microbench.py for in-process A/B timing): 0 = default dispatch,
- * 5 = never use the 8-wave ping-pong kernel for head_dim 40.  Results are identical for both. */
-int a3d_tune_flash(int variant);
 
 /* Temporal (AnimateDiff) self-attention over the F frames of every (video, pixel, head):
  * rows of Q/K/V/O are ((v*F + f)*L + l).  Replaces the unfused
@@ -315,14 +320,14 @@ int a3d_adamw_f32(a3d_stream_t stream, float* p, const float* g, float* m, float
  * --------------------------------------------------------------------------------------------------------------------- */
 int a3d_gemm_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
-                  void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta);
+                  void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags);
 int a3d_gemm_f32out_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
 int a3d_gemm_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
-                        const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K);
+                        const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N2, int64_t K, int flags);
 int a3d_conv3x3_f16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
                      const void* rowbias, int64_t rb_div, const void* R, void* Y,
-                     int B, int H, int W, int Cin, int Cout, int stride, int up2x);
+                     int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags);
 int a3d_flash_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,

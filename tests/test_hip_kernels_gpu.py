@@ -95,9 +95,9 @@ def test_gemm_layout_asymmetric(ops):
     assert torch.equal(y, w.t().contiguous())
 
 
-# The big token matrices (M % 256 == 0, >= 192 output tiles of 256 x 320 / 256 x 256) take the persistent LDS-DMA kernels (default: the
-# two-stage one of csrc/gemm_conv.hip; a3d_tune_gemm(9) / (10): the four-stage ring kernel of csrc/gemm_ring.hip, a measured experiment);
-# a3d_tune_gemm(1) forces the 128 x 128 kernel, whose K order and epilogue arithmetic are identical => bit-equal outputs.
+# The big token matrices (M % 256 == 0, >= 50 % average fill of the persistent grid's rounds) take the persistent LDS-DMA kernel with the
+# ping-pong main loop (csrc/gemm_pp.hip); ``tile128=True`` (A3D_GEMM_TILE128 in the call's flags word) forces the 128 x 128-tile kernel, whose
+# K order and epilogue arithmetic are identical => bit-equal outputs.
 def _persistent_eligible(M, N, geglu=False, cus=256):
     nb = (4 if N % 256 == 0 else 0) if geglu else (5 if N % 320 == 0 else (4 if N % 256 == 0 else 0))
     if nb == 0 or M % 256:
@@ -107,31 +107,22 @@ def _persistent_eligible(M, N, geglu=False, cus=256):
     return tiles * 100 >= rounds * cus * 50           # average fill of the persistent grid's rounds >= 50 %
 
 
+def _first(t):
+    return t[0] if isinstance(t, tuple) else t
+
+
 def _both_paths(ops, fn):
+    """fn(tile128) -> output.  Returns (default dispatch, 128 x 128-tile kernel, default dispatch with 16 CUs reserved)."""
+    classic = fn(True)
+    got = fn(False)
+    for _ in range(2):                              # the counted-wait pipeline must be deterministic run to run
+        assert torch.equal(_first(fn(False)), _first(got))
     try:
-        assert ops.lib.a3d_tune_gemm(1) == 0
-        classic = fn()
-        assert ops.lib.a3d_tune_gemm(2) == 0
-        unpinned = fn()
-        assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(4) == 0     # every store drained before each tile
-        drained = fn()
-        assert torch.equal(drained[0] if isinstance(drained, tuple) else drained, classic[0] if isinstance(classic, tuple) else classic)
-        assert ops.lib.a3d_tune_gemm(5) == 0 and ops.lib.a3d_tune_gemm(8) == 0     # the two-stage persistent kernel (round 1-2 default)
-        two_stage = fn()
-        assert torch.equal(two_stage[0] if isinstance(two_stage, tuple) else two_stage, classic[0] if isinstance(classic, tuple) else classic)
-        assert ops.lib.a3d_tune_gemm(9) == 0 and ops.lib.a3d_tune_gemm(4) == 0     # four-stage ring kernel, stores drained at tile starts
-        ring_drained = fn()
-        assert torch.equal(ring_drained[0] if isinstance(ring_drained, tuple) else ring_drained, classic[0] if isinstance(classic, tuple) else classic)
-        assert ops.lib.a3d_tune_gemm(10) == 0 and ops.lib.a3d_tune_gemm(5) == 0    # ring kernel, DMA pieces interleaved with the MFMAs
-        ring_spread = fn()
-        assert torch.equal(ring_spread[0] if isinstance(ring_spread, tuple) else ring_spread, classic[0] if isinstance(classic, tuple) else classic)
+        ops.reserved_cus = 16                       # a smaller persistent grid walks the same tiles
+        reserved = fn(False)
     finally:
-        assert ops.lib.a3d_tune_gemm(3) == 0 and ops.lib.a3d_tune_gemm(5) == 0 and ops.lib.a3d_tune_gemm(8) == 0     # the defaults
-    got = fn()
-    for _ in range(2):                              # the counted-vmcnt pipeline must be deterministic run to run
-        again = fn()
-        assert torch.equal(again[0] if isinstance(again, tuple) else again, got[0] if isinstance(got, tuple) else got)
-    return got, classic, unpinned
+        ops.reserved_cus = 0
+    return got, classic, reserved
 
 
 @pytest.mark.parametrize("M,N,K", [(65536, 320, 64), (65536, 320, 320), (65536, 640, 192), (65536, 256, 128), (49152, 1280, 128), (24576, 2560, 64)])
@@ -143,10 +134,10 @@ def test_gemm_persistent_path(ops, ref, M, N, K):
     rb = rnd(M // 4096, N, seed=15)
     for name, kw in (("plain", {}), ("residual", dict(residual=res, alpha=0.37, beta=1.0)), ("residual beta", dict(residual=res, alpha=0.63, beta=0.9)),
                      ("rowbias+res", dict(rowbias=rb, rb_div=4096, residual=res))):
-        got, classic, pinned = _both_paths(ops, lambda: ops.gemm(x, w, bias, **kw))
+        got, classic, pinned = _both_paths(ops, lambda t128: ops.gemm(x, w, bias, tile128=t128, **kw))
         check(f"gemm persistent {name} {M}x{N}x{K}", got, ref.gemm(x, w, bias, **kw))
         assert torch.equal(got, classic), f"persistent vs 128x128 kernel differ ({name})"
-        assert torch.equal(got, pinned), f"persistent variants differ ({name})"
+        assert torch.equal(got, pinned), f"persistent kernel with reserved CUs differs ({name})"
     big = rnd(M, 3 * K, seed=16)
     xs = big[:, K:2 * K]
     out = torch.zeros(M, 2 * N, device="cuda", dtype=BF)
@@ -163,11 +154,7 @@ def test_gemm_persistent_path_repeatable_under_memory_traffic(ops):
     for (M, N, K) in [(65536, 320, 320), (32768, 1280, 1280), (8192, 1280, 1280)]:
         x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5)
         bias, res = rnd(N, seed=43, dtype=torch.float32), rnd(M, N, seed=44)
-        assert ops.lib.a3d_tune_gemm(1) == 0
-        try:
-            want = ops.gemm(x, w, bias, residual=res, alpha=0.7)
-        finally:
-            assert ops.lib.a3d_tune_gemm(3) == 0
+        want = ops.gemm(x, w, bias, residual=res, alpha=0.7, tile128=True)
         for it in range(40):
             if it % 3 == 0:
                 junk.add_(1)
@@ -180,7 +167,7 @@ def test_gemm_geglu_persistent_path(ops, ref, M, N2, K):
     x, w = rnd(M, K, seed=21), rnd(N2, K, seed=22, scale=K ** -0.5)
     bias = rnd(N2, seed=23, dtype=torch.float32)
     w_il, b_il = ops.interleave_geglu(w), ops.interleave_geglu(bias)
-    got, classic, pinned = _both_paths(ops, lambda: ops.gemm_geglu(x, w_il, b_il))
+    got, classic, pinned = _both_paths(ops, lambda t128: ops.gemm_geglu(x, w_il, b_il, tile128=t128))
     check(f"gemm_geglu persistent {M}x{N2}x{K}", got, ref.geglu(ref.gemm(x, w, bias)))
     assert torch.equal(got, classic) and torch.equal(got, pinned)
 
@@ -197,7 +184,7 @@ def test_conv3x3_persistent_path(ops, ref, B, H, W, Cin, Cout, stride, up):
     res = rnd(B * Ho * Wo, Cout, seed=34)
     rb = rnd(B, Cout, seed=35)
     for name, kw in (("plain", {}), ("rowbias", dict(rowbias=rb, rb_div=Ho * Wo)), ("residual", dict(residual=res))):
-        (got, _, _), (classic, _, _), (pinned, _, _) = _both_paths(ops, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up, **kw))
+        (got, _, _), (classic, _, _), (pinned, _, _) = _both_paths(ops, lambda t128: ops.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up, tile128=t128, **kw))
         want, _, _ = ref.conv3x3(x, B, H, W, w, bias, stride=stride, up2x=up, **kw)
         check(f"conv persistent {name} B{B} {H}x{W} {Cin}->{Cout} s{stride} up{int(up)}", got, want)
         assert torch.equal(got, classic), f"persistent vs 128x128 conv differ ({name})"
@@ -227,6 +214,11 @@ def test_conv3x3_epilogue(ops, ref):
 
 
 # ------------------------------------------------------------------ attention
+# per-call kernel choices of a3d_flash_attn (flag bits of its last argument): default dispatch, the exact pass of the LDS-DMA staged
+# kernels alone (A3D_ATTN_EXACT), the generic kernel of the short / ragged shapes (A3D_ATTN_PLAIN)
+ATTN_MODES = {"default": {}, "exact": dict(exact=True), "plain": dict(plain=True)}
+
+
 def _mv_maps(n, F, L):
     return RowMap(F, n * F * L, L, L, F * L), RowMap(F, n * F * L, 0, L, F * L)
 
@@ -293,34 +285,30 @@ def test_flash_attn_rescale_branch(ops, ref):
     check("attn rescale spikes", ops.flash_attn(q, k, v, m, m, 1, heads, L, L), ref.flash_attn(q, k, v, m, m, 1, heads, L, L))
 
 
-@pytest.mark.parametrize("var", [0, 5])
+@pytest.mark.parametrize("mode", ["default", "plain"])
 @pytest.mark.parametrize("spikes", [(3,), (40, 70), (500,), (31, 32, 63, 64, 95, 96), (250, 260, 270, 280, 290, 300, 310)])
 @pytest.mark.parametrize("L,q_len", [(512, 512), (1024, 700)])
-def test_flash_attn_rescale_paths_at_level0_shapes(ops, ref, spikes, L, q_len, var):
+def test_flash_attn_rescale_paths_at_level0_shapes(ops, ref, spikes, L, q_len, mode):
     """Level-0 shapes: the default dispatch (flash_attn_dm_kernel) and the plain exact kernel that serves every shape the LDS-DMA
-    kernel does not (a3d_tune_flash(5)): its offset moves lazily per tile.  Spikes in the very first sub-tile (initial offset), in
+    kernel does not (``plain=True``): its offset moves lazily per tile.  Spikes in the very first sub-tile (initial offset), in
     consecutive sub-tiles, at sub-tile borders and in the last one (peeled iterations); a ragged query count exercises the masked rows."""
     heads, D = 8, 40
     C = heads * D
     q, k, v = rnd(q_len, C, seed=1), rnd(L, C, seed=2), rnd(L, C, seed=3)
     for t, row in enumerate(spikes):
         k[row] = q[7 + 3 * t] * (3.0 + 1.5 * t)
-    try:
-        assert ops.lib.a3d_tune_flash(var) == 0
-        got = ops.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L)
-    finally:
-        ops.lib.a3d_tune_flash(0)
-    check(f"attn var{var} spikes {spikes} L{L} q{q_len}", got, ref.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L))
+    got = ops.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L, **ATTN_MODES[mode])
+    check(f"attn {mode} spikes {spikes} L{L} q{q_len}", got, ref.flash_attn(q, k, v, RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0), 1, heads, q_len, L))
 
 
-@pytest.mark.parametrize("var", [20, 21, 23, 24, 25, 29, 32, 33])
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("spikes,gain", [((), 1.0), ((3,), 3.0), ((40, 70), 3.0), ((500,), 4.0), ((31, 32, 63, 64, 95, 96), 3.0),
                                          ((250,), 12.0), ((100, 400), 40.0), ((-1,), 60.0)])
 @pytest.mark.parametrize("L,q_len", [(512, 512), (1024, 700)])
-def test_flash_attn_dma_kernel(ops, ref, var, spikes, gain, L, q_len):
-    """flash_attn_dm_kernel (LDS-DMA staging, dense LDS images; a3d_tune_flash(20 + flags)): flags 0 = exact pass only, 1 = max-free
-    pass (bf16: offset fixed after the first 32 keys) with the exact re-run on overflow, 2 = static wave priority, 4 = P·V through the
-    16x16x32 MFMA, 8 = 16 waves x 32 queries per workgroup instead of 8 x 64.  Moderate spikes stay inside the max-free pass (probabilities up to ~2^70), gains >= 40 overflow bf16 and must take
+def test_flash_attn_dma_kernel(ops, ref, mode, spikes, gain, L, q_len):
+    """flash_attn_dm_kernel (LDS-DMA staging, dense LDS images, P·V through the 16x16x32 MFMA): the default = max-free pass (bf16: offset
+    fixed after the first 32 keys) with the exact re-run on overflow, and its exact pass alone (``exact=True``).  Moderate spikes stay
+    inside the max-free pass (probabilities up to ~2^70), gains >= 40 overflow bf16 and must take
     the re-run; a spike in the very last key, a ragged query count (masked rows) and spikes in the first sub-tile are covered.
     Bar: 4e-3 as for every attention kernel; 1e-2 for the gains >= 40, where scores reach ~370 log2 units and the 8-bit mantissa of
     the pre-scaled Q (a property of all the D = 40 kernels: Q' = bf16(Q * scale * log2 e)) moves near-ties between the huge scores."""
@@ -331,61 +319,51 @@ def test_flash_attn_dma_kernel(ops, ref, var, spikes, gain, L, q_len):
         k[row % L] = q[7 + 3 * t] * (gain + 0.5 * t)
     qm, km = RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0)
     want = ref.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
-    try:
-        assert ops.lib.a3d_tune_flash(var) == 0
-        got = ops.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
-    finally:
-        ops.lib.a3d_tune_flash(0)
-    check(f"dm attn var{var} spikes {spikes} x{gain} L{L} q{q_len}", got, want, tol=4e-3 if gain < 40 else 1e-2)
+    got = ops.flash_attn(q, k, v, qm, km, 1, heads, q_len, L, **ATTN_MODES[mode])
+    check(f"dm attn {mode} spikes {spikes} x{gain} L{L} q{q_len}", got, want, tol=4e-3 if gain < 40 else 1e-2)
 
 
-@pytest.mark.parametrize("var", [20, 21, 25, 33])
-def test_flash_attn_dma_kernel_multiview_maps(ops, ref, var):
+@pytest.mark.parametrize("mode", ["default", "exact"])
+def test_flash_attn_dma_kernel_multiview_maps(ops, ref, mode):
     """The same kernel through the multi-view and first-frame row maps (segments of L rows, 64-key tiles wrap at segment ends),
-    with accumulate / out_scale, against the fp32 reference and against the interleaved kernel."""
+    with accumulate / out_scale, against the fp32 reference."""
     heads, D, b, n, F, L = 8, 40, 2, 4, 2, 256
     C = heads * D
     qkv = rnd(b * n * F * L, 3 * C, seed=21)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     qm, k0 = _mv_maps(n, F, L)
     S = n * L
-    try:
-        for km, nm in ((qm, "mv"), (k0, "i2v")):
-            want = ref.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
-            assert ops.lib.a3d_tune_flash(var) == 0
-            check(f"dm var{var} {nm} attn", ops.flash_attn(q, k, v, qm, km, b * F, heads, S, S), want)
-        base = rnd(b * n * F * L, C, seed=22)
-        o = base.clone()
-        ops.flash_attn(q, k, v, qm, k0, b * F, heads, S, S, out=o, out_scale=0.6, accumulate=True)
-        o_r = ref.flash_attn(q, k, v, qm, k0, b * F, heads, S, S, out=base.float(), out_scale=0.6, accumulate=True)
-        check(f"dm var{var} accumulate", o, o_r, tol=6e-3)
-    finally:
-        ops.lib.a3d_tune_flash(0)
+    kw = ATTN_MODES[mode]
+    for km, nm in ((qm, "mv"), (k0, "i2v")):
+        want = ref.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
+        check(f"dm {mode} {nm} attn", ops.flash_attn(q, k, v, qm, km, b * F, heads, S, S, **kw), want)
+    base = rnd(b * n * F * L, C, seed=22)
+    o = base.clone()
+    ops.flash_attn(q, k, v, qm, k0, b * F, heads, S, S, out=o, out_scale=0.6, accumulate=True, **kw)
+    o_r = ref.flash_attn(q, k, v, qm, k0, b * F, heads, S, S, out=base.float(), out_scale=0.6, accumulate=True)
+    check(f"dm {mode} accumulate", o, o_r, tol=6e-3)
 
 
 def test_flash_attn_d80_kernel_variants(ops, ref):
-    """Head dim 80: the two-sub-tile kernel (long sequences, default from 2048 tokens) and the one-sub-tile kernel, forced both
-    ways on a long and a ragged short shape, each against the fp32 reference; the forced spike exercises the two-sub-tile
-    kernel's rescale path."""
+    """Head dim 80: the LDS-DMA staged kernel (default from 512 keys; its exact pass alone with ``exact=True``) and the generic
+    kernels (``plain=True``: two query sub-tiles per wave from 2 048 tokens, one below) on long and ragged short shapes, each against
+    the fp32 reference; the forced spikes exercise the rescale paths and (spike 2) the overflow re-run."""
     heads, D = 8, 80
     C = heads * D
-    try:
-        for (n, F, L, spike) in [(4, 1, 512, 1), (3, 2, 100, 0), (4, 1, 512, 2)]:
+    if True:
+        for (n, F, L, spike) in [(4, 1, 512, 1), (3, 2, 100, 0), (4, 1, 512, 2), (4, 1, 128, 1)]:
             qkv = rnd(n * F * L, 3 * C, seed=L)
             q, k, v = qkv[:, :C].contiguous(), qkv[:, C:2 * C].contiguous(), qkv[:, 2 * C:].contiguous()
             if spike:
-                k[700] = q[9] * 4.0
-                k[1500] = q[11] * 6.0
-            if spike == 2:          # ~260 log2 units above the rest: overflows the max-free pass of variants 40 / 41 (exact re-run)
+                k[700 % (n * F * L)] = q[9] * 4.0
+                k[1500 % (n * F * L)] = q[11] * 6.0
+            if spike == 2:          # ~260 log2 units above the rest: overflows the max-free pass (exact re-run)
                 k[900] = q[13] * 20.0
             qm, k0 = _mv_maps(n, F, L)
             want = ref.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L)
-            for var in (0, 8, 17, 40, 41, 42, 43):
-                assert ops.lib.a3d_tune_flash(var) == 0
-                check(f"D80 n{n} L{L} spike{spike} kernel variant {var}", ops.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L), want,
+            for mode, kw in ATTN_MODES.items():
+                check(f"D80 n{n} L{L} spike{spike} {mode}", ops.flash_attn(q, k, v, qm, k0, F, heads, n * L, n * L, **kw), want,
                       tol=4e-3 if spike < 2 else 1e-2)
-    finally:
-        ops.lib.a3d_tune_flash(0)
 
 
 def test_flash_attn_kernel_variants_agree(ops, ref):
@@ -396,12 +374,8 @@ def test_flash_attn_kernel_variants_agree(ops, ref):
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     qm, k0 = _mv_maps(n, F, L)
     want = ref.flash_attn(q, k, v, qm, k0, b * F, heads, n * L, n * L)
-    try:
-        for var in (0, 20, 5):
-            assert ops.lib.a3d_tune_flash(var) == 0
-            check(f"D40 kernel variant {var}", ops.flash_attn(q, k, v, qm, k0, b * F, heads, n * L, n * L), want)
-    finally:
-        ops.lib.a3d_tune_flash(0)
+    for mode, kw in ATTN_MODES.items():
+        check(f"D40 kernel choice {mode}", ops.flash_attn(q, k, v, qm, k0, b * F, heads, n * L, n * L, **kw), want)
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])
@@ -578,14 +552,14 @@ def test_fp16_storage_attention(ops16, ref, D):
     check(f"f16 temporal attn D{D}", ops16.temporal_attn(q, k, v, V, F, L, heads), ref.temporal_attn(q, k, v, V, F, L, heads), tol=1.5e-3)
 
 
-@pytest.mark.parametrize("var", [20, 21, 25, 29])
+@pytest.mark.parametrize("mode", ["default", "exact"])
 @pytest.mark.parametrize("spikes,gain", [((), 1.0), ((3,), 1.5), ((40, 70), 1.5), ((250,), 2.2), ((500,), 4.0), ((-1,), 12.0), ((16, 48, 80), 2.0)])
 @pytest.mark.parametrize("L,q_len", [(512, 512), (1024, 700)])
-def test_fp16_flash_attn_dma_kernel(ops16, ref, var, spikes, gain, L, q_len):
-    """fp16 storage through flash_attn_dm_kernel: the max-free pass (flags 1 / 5 / 9) estimates the offset from 32 keys spread over the
+def test_fp16_flash_attn_dma_kernel(ops16, ref, mode, spikes, gain, L, q_len):
+    """fp16 storage through flash_attn_dm_kernel: the max-free pass (default) estimates the offset from 32 keys spread over the
     key range (rows 0, L/32, 2L/32, ...) and keeps P inside fp16's 2^-24 .. 2^16: spikes of 9-14 log2 units above the sample stay inside
     the window (gain 1.5 - 2.2: also when the spike IS a sample key), larger ones (gain >= 4) overflow to inf and must take the exact
-    re-run; flags 0 is the exact pass alone.  Bar: the fp16 attention bar (1.5e-3)."""
+    re-run; ``exact=True`` is the exact pass alone.  Bar: the fp16 attention bar (1.5e-3)."""
     heads, D = 8, 40
     C = heads * D
     q, k, v = rnd(q_len, C, seed=1, dtype=H16), rnd(L, C, seed=2, dtype=H16), rnd(L, C, seed=3, dtype=H16)
@@ -593,21 +567,17 @@ def test_fp16_flash_attn_dma_kernel(ops16, ref, var, spikes, gain, L, q_len):
         k[row % L] = q[7 + 3 * t] * (gain + 0.25 * t)
     qm, km = RowMap(1, q_len, 0, q_len, 0), RowMap(1, L, 0, L, 0)
     want = ref.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
-    try:
-        assert ops16.lib.a3d_tune_flash(var) == 0
-        got = ops16.flash_attn(q, k, v, qm, km, 1, heads, q_len, L)
-    finally:
-        ops16.lib.a3d_tune_flash(0)
-    check(f"f16 dm attn var{var} spikes {spikes} x{gain} L{L} q{q_len}", got, want, tol=1.5e-3)
+    got = ops16.flash_attn(q, k, v, qm, km, 1, heads, q_len, L, **ATTN_MODES[mode])
+    check(f"f16 dm attn {mode} spikes {spikes} x{gain} L{L} q{q_len}", got, want, tol=1.5e-3)
 
 
 def test_fp16_flash_attn_dma_kernels_multiview_maps(ops16, ref):
     """fp16 storage, default dispatch (LDS-DMA kernels at head_dim 40 and 80, sampled max-free pass) through the multi-view and
     first-frame row maps — the sample keys are spread over all the views' segments —, against the fp32 reference and against the
-    plain exact kernels (a3d_tune_flash(5) at head_dim 40, 8: two-sub-tile D = 80)."""
+    generic exact kernels (``plain=True``)."""
     heads, b, n, F = 8, 2, 4, 2
-    try:
-        for D, L, old in ((40, 256, 5), (80, 256, 8)):
+    if True:
+        for D, L in ((40, 256), (80, 256)):
             C = heads * D
             qkv = rnd(b * n * F * L, 3 * C, seed=21 + D, dtype=H16)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
@@ -615,19 +585,14 @@ def test_fp16_flash_attn_dma_kernels_multiview_maps(ops16, ref):
             S = n * L
             for km, nm in ((qm, "mv"), (k0, "i2v")):
                 want = ref.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
-                assert ops16.lib.a3d_tune_flash(0) == 0
                 got = ops16.flash_attn(q, k, v, qm, km, b * F, heads, S, S)
                 check(f"f16 dm D{D} {nm} attn", got, want, tol=1.5e-3)
-                assert ops16.lib.a3d_tune_flash(old) == 0
-                check(f"f16 dm D{D} {nm} attn vs plain kernel", got, ops16.flash_attn(q, k, v, qm, km, b * F, heads, S, S), tol=1.5e-3)
+                check(f"f16 dm D{D} {nm} attn vs plain kernel", got, ops16.flash_attn(q, k, v, qm, km, b * F, heads, S, S, plain=True), tol=1.5e-3)
             q2, k2, v2 = q.contiguous(), k.clone(), v.contiguous()
             k2[5 * L + 17] = q2[9] * 9.0         # far outside the fp16 window: exact re-run of the workgroups that see it
-            assert ops16.lib.a3d_tune_flash(0) == 0
             check(f"f16 dm D{D} overflow re-run", ops16.flash_attn(q2, k2, v2, qm, qm, b * F, heads, S, S), ref.flash_attn(q2, k2, v2, qm, qm, b * F, heads, S, S), tol=1.5e-3)
             qw, kw = (q2.float() * 2.5).to(H16), (k2.float() * 2.5).to(H16)      # scores 6 x wider: the sample's spread sends every workgroup to the exact pass
             check(f"f16 dm D{D} wide scores", ops16.flash_attn(qw, kw, v2, qm, qm, b * F, heads, S, S), ref.flash_attn(qw, kw, v2, qm, qm, b * F, heads, S, S), tol=1.5e-3)
-    finally:
-        ops16.lib.a3d_tune_flash(0)
 
 
 def test_fp16_storage_norms_and_elementwise(ops16, ref):

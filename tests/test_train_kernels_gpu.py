@@ -208,13 +208,6 @@ def test_wgrad_split_over_tokens(ops, ref, M, N, K):
     got, want = ops.wgrad(dy, x, 0.5), ref.wgrad(dy, x, 0.5)
     assert got.dtype == torch.float32
     check(f"wgrad {M}x{N}x{K}", got, want, 2e-5)
-    try:        # default: the LDS-DMA kernel (transposition on the way out of LDS); a3d_tune_gemm(11): round 2's register-staged kernel — same tiles,
-        assert ops.lib.a3d_tune_gemm(11) == 0      # same token order within a split, same reduction: bit-identical
-        old = ops.wgrad(dy, x, 0.5)
-    finally:
-        assert ops.lib.a3d_tune_gemm(12) == 0
-    check(f"wgrad {M}x{N}x{K}, round-2 kernel", old, want, 2e-5)
-    assert torch.equal(got, old)
     assert torch.equal(ops.wgrad(dy, x, 0.5), got)          # counted vmcnt waits: deterministic run to run
 
 

@@ -34,8 +34,11 @@ def timeit(fn, reps=5, warm=1):
     return statistics.median(ts), min(ts)
 
 
+ATTN_MODES = (("default", {}), ("exact", dict(exact=True)), ("plain", dict(plain=True)))
+
+
 def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4, 16, 256, 2))):
-    print("== flash attention variants (multi-view map; median ms / TFLOP/s; err = rel L2 vs variant 0)")
+    print("== flash attention (multi-view map): default dispatch | exact pass of the LDS-DMA kernels | generic kernel; median ms / TFLOP/s; err = rel L2 vs default")
     for (D, n, F, L, b) in shapes:
         heads, C = 8, 8 * D
         rows = b * n * F * L
@@ -44,22 +47,17 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
         qm = RowMap(F, n * F * L, L, L, F * L)
         S, G = n * L, b * F
         flops = 4.0 * G * S * S * C
-        ops.lib.a3d_tune_flash(0)
         ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in ((0, 5, 21, 0, 5, 21) if D == 40 else ((17, 8, 42, 43, 17, 8, 42) if D == 80 else (0,))):   # 8 / 9: -DA3D_EXP_FLASH80 builds
-            if ops.lib.a3d_tune_flash(var) != 0:      # ablation variants exist only in -DA3D_ABLATIONS builds
-                continue
-            out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+        for name, kw in ATTN_MODES * 2:
+            out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw).float()
             err = ((out - ref).norm() / ref.norm()).item()
-            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5 if D == 40 else 10)
-            print(f"D={D:3d} S={S:5d} G={G} var={var}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
-        ops.lib.a3d_tune_flash(0)
+            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw), reps=5 if D == 40 else 10)
+            print(f"D={D:3d} S={S:5d} G={G} {name:8s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
 
 
-def bench_flashdm(ops, variants=(5, 21, 25, 29, 33, 32, 5, 21, 25, 29, 33), scales=(1.0, 0.0, 3.0)):
-    """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel
-    (a3d_tune_flash(20 + flags)) against the interleaved kernel (0), interleaved rounds in one process; err vs the interleaved
-    kernel's output.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
+def bench_flashdm(ops, scales=(1.0, 0.0, 3.0)):
+    """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel (default), its exact
+    pass alone and the generic kernel, interleaved rounds in one process.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
     D, n, F, L, b = 40, 4, 16, 4096, 2
     heads, C = 8, 8 * D
     qm = RowMap(F, n * F * L, L, L, F * L)
@@ -68,20 +66,16 @@ def bench_flashdm(ops, variants=(5, 21, 25, 29, 33, 32, 5, 21, 25, 29, 33), scal
     for sc in scales:
         qkv = rnd(b * n * F * L, 3 * C, scale=sc)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-        ops.lib.a3d_tune_flash(0)
-        ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-        for var in variants:
-            if ops.lib.a3d_tune_flash(var) != 0:
-                continue
-            out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+        ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, plain=True).float()
+        for name, kw in ATTN_MODES * 2:
+            out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw).float()
             err = ((out - ref).norm() / (ref.norm() + 1e-30)).item()
-            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5)
-            print(f"level-0 D=40 scale={sc} var={var:2d}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err vs var 0 = {err:.2e}", flush=True)
-        ops.lib.a3d_tune_flash(0)
+            med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw), reps=5)
+            print(f"level-0 D=40 scale={sc} {name:8s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err vs generic = {err:.2e}", flush=True)
 
 
 def bench_gemm(ops):
-    print("== GEMM  Y[M,N] = X[M,K] W[N,K]^T (+bias +residual); median ms / TFLOP/s")
+    print("== GEMM  Y[M,N] = X[M,K] W[N,K]^T (+bias +residual); median ms / TFLOP/s;  default dispatch | 128 x 128-tile kernel")
     shapes = [(524288, 1280, 320), (524288, 320, 320), (524288, 2560, 320), (524288, 320, 1280), (524288, 960, 320),
               (131072, 2560, 640), (131072, 640, 640), (131072, 5120, 640), (131072, 640, 2560),
               (32768, 5120, 1280), (32768, 1280, 1280), (32768, 10240, 1280), (32768, 1280, 5120), (8192, 1280, 1280), (8192, 10240, 1280)]
@@ -91,13 +85,21 @@ def bench_gemm(ops):
         res = rnd(M, N)
         fl = 2.0 * M * N * K
         out = []
-        for bk in (64, 32):
-            ops.lib.a3d_tune_gemm(bk)
-            med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res), reps=7)
-            med2, _ = timeit(lambda: ops.gemm(x, w, bias), reps=7)
-            out.append(f"bk{bk}: {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s | no-residual {med2:7.3f} ms {fl / med2 / 1e9:6.1f} TF/s")
-        ops.lib.a3d_tune_gemm(0)
-        print(f"M={M:7d} N={N:5d} K={K:5d}: " + "  ||  ".join(out))
+        for t128 in (False, True):
+            med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res, tile128=t128), reps=7)
+            med2, _ = timeit(lambda: ops.gemm(x, w, bias, tile128=t128), reps=7)
+            out.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s | no-residual {med2:7.3f} ms {fl / med2 / 1e9:6.1f} TF/s")
+        print(f"M={M:7d} N={N:5d} K={K:5d}: " + "  ||  ".join(out), flush=True)
+    print("-- fused GEGLU projection")
+    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
+        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
+        bias = torch.randn(N2, device="cuda")
+        fl = 2.0 * M * N2 * K
+        out = []
+        for t128 in (False, True):
+            med, mn = timeit(lambda: ops.gemm_geglu(x, w, bias, tile128=t128), reps=7)
+            out.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s")
+        print(f"M={M:7d} N2={N2:5d} K={K:5d}: " + "  ||  ".join(out), flush=True)
 
 
 def bench_conv(ops):
@@ -113,117 +115,23 @@ def bench_conv(ops):
         Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
         fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
         out = []
-        for bk in (64, 32):
-            ops.lib.a3d_tune_gemm(bk)
-            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
-            out.append(f"bk{bk}: {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s")
-        ops.lib.a3d_tune_gemm(0)
+        for t128 in (False, True):
+            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up, tile128=t128), reps=5)
+            out.append(f"{'tile128' if t128 else 'default'}: {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s")
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + "  ||  ".join(out))
-
-
-def bench_convk(ops):
-    print("== persistent conv3x3: K walked tap-major (default) vs chunk-major (a3d_tune_gemm(7)); median ms / TFLOP/s, max |diff|")
-    shapes = [(128, 64, 64, 320, 320), (128, 64, 64, 640, 320), (128, 64, 64, 960, 320), (128, 32, 32, 640, 640), (128, 32, 32, 1280, 640),
-              (128, 32, 32, 1920, 640), (128, 16, 16, 1280, 1280), (128, 16, 16, 2560, 1280)]
-    for (B, H, W, Cin, Cout) in shapes:
-        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
-        bias = torch.randn(Cout, device="cuda")
-        fl = 2.0 * B * H * W * 9 * Cin * Cout
-        out, ys = [], []
-        for mode in (6, 7, 6, 7):
-            ops.lib.a3d_tune_gemm(mode)
-            med, _ = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias), reps=7)
-            ys.append(ops.conv3x3(x, B, H, W, w, bias)[0].float())
-            out.append(f"{'tap' if mode == 6 else 'chunk'}: {med:6.3f} ms {fl / med / 1e9:6.1f} TF/s")
-        ops.lib.a3d_tune_gemm(7); ops.lib.a3d_tune_gemm(1)                  # chunk-major walk in the 128x128 kernel: must be bit-identical
-        same = torch.equal(ops.conv3x3(x, B, H, W, w, bias)[0].float(), ys[1])
-        ops.lib.a3d_tune_gemm(3); ops.lib.a3d_tune_gemm(6)
-        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d}: " + " | ".join(out) + f" | diff {(ys[0] - ys[1]).abs().max().item():.3g} of {ys[0].abs().max().item():.3g}"
-              f" | chunk-major 128x128 == persistent: {same}")
-
-
-def bench_persist(ops):
-    """128x128 kernel (a3d_tune_gemm(1)) vs the persistent 256x320 LDS-DMA kernels: two 64-wide stages (8, rounds 1-2) and the
-    four-stage ring of 32-wide half-tiles (9, default)."""
-    print("== persistent GEMM A/B: median ms / TFLOP/s / effective GB/s;  classic | two-stage persistent | four-stage ring | ring, spread DMA issue   [+res = with residual]")
-    MODES = ((1, 9), (3, 8), (3, 9), (3, 10))
-
-    def set_mode(m):
-        ops.lib.a3d_tune_gemm(m[0]); ops.lib.a3d_tune_gemm(m[1])
-    shapes = [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (524288, 320, 1280),
-              (131072, 640, 640), (131072, 1920, 640), (131072, 640, 2560), (32768, 1280, 1280), (32768, 3840, 1280), (32768, 1280, 5120)]
-    for (M, N, K) in shapes:
-        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-        bias = torch.randn(N, device="cuda")
-        res = rnd(M, N)
-        fl = 2.0 * M * N * K
-        for tag, kw, byts in (("     ", {}, 2.0 * (M * K + M * N)), (" +res", dict(residual=res), 2.0 * (M * K + 2 * M * N))):
-            outs, ref = [], None
-            for mode in MODES:
-                set_mode(mode)
-                y = ops.gemm(x, w, bias, **kw)
-                ref = y if ref is None else ref
-                med, mn = timeit(lambda: ops.gemm(x, w, bias, **kw), reps=7)
-                outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s {byts / med / 1e6:5.0f} GB/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-            set_mode((3, 8))
-            print(f"M={M:7d} N={N:5d} K={K:5d}{tag}: " + " | ".join(outs))
-    print("-- fused GEGLU projection")
-    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
-        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
-        bias = torch.randn(N2, device="cuda")
-        fl = 2.0 * M * N2 * K
-        outs, ref = [], None
-        for mode in MODES:
-            set_mode(mode)
-            y = ops.gemm_geglu(x, w, bias)
-            ref = y if ref is None else ref
-            med, mn = timeit(lambda: ops.gemm_geglu(x, w, bias), reps=7)
-            outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        set_mode((3, 8))
-        print(f"M={M:7d} N2={N2:5d} K={K:5d}: " + " | ".join(outs))
-    print("-- conv3x3")
-    for (B, H, W, Cin, Cout, st, up) in [(128, 64, 64, 320, 320, 1, False), (128, 64, 64, 640, 320, 1, False), (128, 32, 32, 640, 640, 1, False),
-                                         (128, 32, 32, 1280, 640, 1, False), (128, 16, 16, 1280, 1280, 1, False), (128, 16, 16, 2560, 1280, 1, False),
-                                         (128, 64, 64, 320, 320, 2, False), (128, 32, 32, 640, 640, 1, True), (128, 16, 16, 1280, 1280, 1, True)]:
-        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
-        bias = torch.randn(Cout, device="cuda")
-        He, We = (2 * H, 2 * W) if up else (H, W)
-        Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
-        fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
-        outs, ref = [], None
-        for mode in MODES:
-            set_mode(mode)
-            y = ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up)[0]
-            ref = y if ref is None else ref
-            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up), reps=5)
-            outs.append(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        set_mode((3, 8))
-        print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + " | ".join(outs))
 
 
 def bench_gemmscale(ops):
     """Per-K-tile time of the persistent GEMM against the number of active CUs: G output tiles of 256 x 320 (one per workgroup),
     K = 5120 (80 K-tiles per tile), so the time of a launch is 80 x the K-tile period (+ one epilogue).  Flat in G = latency /
-    issue bound per CU; growing with G = shared bandwidth (L2 / fabric) bound; zeros vs random data separates the power share."""
-    for kern, name in ((8, "two-stage"), (9, "ring"), (10, "ring-spread")):
-        ops.lib.a3d_tune_gemm(kern)
-        print(f"== persistent GEMM ({name}): period per 64 of K vs active CUs (M = 256 G, N = 320, K = 5120)")
-        for scale in (1.0,):
-            for G in (1, 32, 64, 128, 256, 1024):
-                x = rnd(256 * G, 5120, scale=scale)
-                w = rnd(320, 5120, scale=0.02 * scale)
-                med, mn = timeit(lambda: ops.gemm(x, w), reps=7, warm=2)
-                rounds = (G + 255) // 256
-                print(f"{name} data x{scale:.0f} G={G:4d}: {med * 1e3:8.1f} us   K-tile period {mn * 1e3 / (80 * rounds):6.3f} us  "
-                      f"({2.0 * 256 * G * 320 * 5120 / mn / 1e9:7.1f} TF/s best)")
-        print("== same, N = 1280 (4 column tiles share each A tile through L2)")
-        for G in (8, 64, 256, 1024):
-            x = rnd(64 * G, 5120)
-            w = rnd(1280, 5120, scale=0.02)
-            med, mn = timeit(lambda: ops.gemm(x, w), reps=7, warm=2)
-            rounds = (G + 255) // 256
-            print(f"{name} G={G:4d}: {med * 1e3:8.1f} us   K-tile period {mn * 1e3 / (80 * rounds):6.3f} us  ({2.0 * 64 * G * 1280 * 5120 / mn / 1e9:7.1f} TF/s best)")
-    ops.lib.a3d_tune_gemm(8)
+    issue bound per CU; growing with G = shared bandwidth (L2 / fabric) bound."""
+    print("== persistent GEMM: period per 64 of K vs active CUs (M = 256 G, N = 320, K = 5120)")
+    for G in (1, 32, 64, 128, 256, 1024):
+        x = rnd(256 * G, 5120)
+        w = rnd(320, 5120, scale=0.02)
+        med, mn = timeit(lambda: ops.gemm(x, w), reps=7, warm=2)
+        rounds = (G + 255) // 256
+        print(f"G={G:4d}: {med * 1e3:8.1f} us   K-tile period {mn * 1e3 / (80 * rounds):6.3f} us  ({2.0 * 256 * G * 320 * 5120 / mn / 1e9:7.1f} TF/s best)")
 
 
 def bench_gemmcal(ops):
@@ -243,133 +151,11 @@ def bench_gemmcal(ops):
         print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(outs), flush=True)
 
 
-def bench_pp(ops, modes=(13, 14, 15, 16)):
-    """Lockstep persistent kernel (a3d_tune_gemm(13)) vs the ping-pong main loop of gemm_pp.hip (14: one k-step per phase, DMA 3+3+3;
-    15: one k-step per phase, DMA 5+4; 16: two k-steps per phase), interleaved rounds in one process, outputs compared bit for bit."""
-    print("== ping-pong GEMM A/B: median ms / TFLOP/s per mode " + str(modes) + "  [+res = with residual]")
-
-    def run(tag, fl, fn):
-        outs, ref = [], None
-        for rnd_ in range(2):
-            for m in modes:
-                ops.lib.a3d_tune_gemm(m)
-                y = fn()
-                y = y[0] if isinstance(y, tuple) else y
-                if rnd_ == 0:
-                    ref = y.clone() if ref is None else ref
-                    ok = torch.equal(y, ref)
-                med, mn = timeit(fn, reps=9, warm=2)
-                if rnd_ == 0:
-                    outs.append([m, med, mn, ok])
-                else:
-                    o = outs[modes.index(m)]
-                    o[1] = min(o[1], med); o[2] = min(o[2], mn)
-        ops.lib.a3d_tune_gemm(13)
-        print(f"{tag}: " + " | ".join(f"[{m}] {med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if ok else ' MISMATCH'}" for m, med, mn, ok in outs), flush=True)
-
-    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (8192, 5120, 8192)]:
-        x = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF); w = (torch.rand(N, K, device="cuda") * 2 - 1).to(BF)
-        run(f"uniform M={M:6d} N={N:5d} K={K:5d}     ", 2.0 * M * N * K, lambda: ops.gemm(x, w))
-    shapes = [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (524288, 320, 1280),
-              (131072, 640, 640), (131072, 1920, 640), (131072, 640, 2560), (32768, 1280, 1280), (32768, 3840, 1280), (32768, 1280, 5120)]
-    for (M, N, K) in shapes:
-        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-        bias = torch.randn(N, device="cuda")
-        res = rnd(M, N)
-        run(f"M={M:7d} N={N:5d} K={K:5d}     ", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias))
-        if N <= 1280:
-            run(f"M={M:7d} N={N:5d} K={K:5d} +res", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias, residual=res))
-    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640), (32768, 10240, 1280)]:
-        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
-        bias = torch.randn(N2, device="cuda")
-        run(f"geglu M={M:7d} N2={N2:5d} K={K:5d}", 2.0 * M * N2 * K, lambda: ops.gemm_geglu(x, w, bias))
-    for (B, H, W, Cin, Cout, st, up) in [(128, 64, 64, 320, 320, 1, False), (128, 32, 32, 640, 640, 1, False), (128, 16, 16, 1280, 1280, 1, False),
-                                         (128, 16, 16, 2560, 1280, 1, False), (128, 64, 64, 320, 320, 2, False), (128, 32, 32, 640, 640, 1, True)]:
-        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
-        bias = torch.randn(Cout, device="cuda")
-        He, We = (2 * H, 2 * W) if up else (H, W)
-        Ho, Wo = (He - 1) // st + 1, (We - 1) // st + 1
-        run(f"conv B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}", 2.0 * B * Ho * Wo * 9 * Cin * Cout, lambda: ops.conv3x3(x, B, H, W, w, bias, stride=st, up2x=up))
-
-
-def bench_epiabl(ops):
-    """What the epilogue of the small-K persistent GEMMs waits for (-DA3D_ABLATIONS build, results wrong by construction): normal | every tile
-    stores to output rows 0..255 (the writes never leave L2) | no output stores at all; lockstep (13) and ping-pong (14) main loops."""
-    print("== epilogue ablations: median ms for  normal | stores stay in L2 | no stores")
-    shapes = [(524288, 320, 320, False), (524288, 320, 320, True), (524288, 960, 320, False), (524288, 1280, 320, False), (131072, 1920, 640, False),
-              (131072, 640, 640, True), (32768, 1280, 1280, True)]
-    for mode in (13, 14):
-        ops.lib.a3d_tune_gemm(mode)
-        for (M, N, K, r) in shapes:
-            x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-            bias = torch.randn(N, device="cuda")
-            res = rnd(M, N) if r else None
-            out = []
-            for a in (0, 1, 2):
-                if ops.lib.a3d_tune_gemm(700 + a) != 0:
-                    out.append("   n/a")
-                    continue
-                med, _ = timeit(lambda: ops.gemm(x, w, bias, residual=res), reps=9, warm=2)
-                out.append(f"{med:7.3f}")
-            ops.lib.a3d_tune_gemm(700)
-            print(f"mode {mode} M={M:7d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + " | ".join(out) + f"   (MFMA-only bound at 1250 TF/s: {2.0 * M * N * K / 1250e9:6.3f} ms; HBM bytes / 6 TB/s: {2.0 * (M * K + (2 if r else 1) * M * N) / 6e9:6.3f} ms)", flush=True)
-        x, w = rnd(524288, 320), rnd(2560, 320, scale=320 ** -0.5)
-        bias = torch.randn(2560, device="cuda")
-        out = []
-        for a in (0, 1, 2):
-            if ops.lib.a3d_tune_gemm(700 + a) != 0:
-                continue
-            med, _ = timeit(lambda: ops.gemm_geglu(x, w, bias), reps=9, warm=2)
-            out.append(f"{med:7.3f}")
-        ops.lib.a3d_tune_gemm(700)
-        print(f"mode {mode} geglu M=524288 N2=2560 K=320: " + " | ".join(out), flush=True)
-    ops.lib.a3d_tune_gemm(13)
-
-
-def bench_duo(ops):
-    """Short-K dense GEMMs: lockstep persistent kernel (13 + 17) | ping-pong (14 + 17) | two workgroups per CU on 128-row tiles (gemm_duo.hip, 18);
-    interleaved rounds, outputs compared bit for bit with the lockstep kernel's."""
-    print("== short-K GEMM A/B: median ms / TFLOP/s   lockstep | ping-pong | duo")
-    MODES = ((13, 17), (14, 17), (13, 18))
-
-    def run(tag, fl, fn):
-        outs, ref = [None] * len(MODES), None
-        for rnd_ in range(2):
-            for i, m in enumerate(MODES):
-                for k_ in m:
-                    ops.lib.a3d_tune_gemm(k_)
-                y = fn()
-                if rnd_ == 0:
-                    ref = y.clone() if ref is None else ref
-                    ok = torch.equal(y, ref)
-                    err = ((y.float() - ref.float()).norm() / ref.float().norm()).item()
-                med, mn = timeit(fn, reps=9, warm=2)
-                outs[i] = [med, ok, err] if rnd_ == 0 else [min(outs[i][0], med), outs[i][1], outs[i][2]]
-        ops.lib.a3d_tune_gemm(13); ops.lib.a3d_tune_gemm(17)
-        print(f"{tag}: " + " | ".join(f"{med:7.3f} ms {fl / med / 1e9:6.1f} TF/s{'' if ok else f' MISMATCH {err:.2e}'}" for med, ok, err in outs), flush=True)
-
-    for (M, N, K) in [(524288, 320, 320), (524288, 960, 320), (524288, 1280, 320), (131072, 640, 640), (131072, 1920, 640), (131072, 2560, 640),
-                      (32768, 1280, 640), (4096, 320, 320), (524288, 320, 64)]:
-        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-        bias = torch.randn(N, device="cuda")
-        res = rnd(M, N)
-        run(f"M={M:7d} N={N:5d} K={K:5d}     ", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias))
-        if N <= 1280:
-            run(f"M={M:7d} N={N:5d} K={K:5d} +res", 2.0 * M * N * K, lambda: ops.gemm(x, w, bias, residual=res))
-    rb = rnd(128, 320)
-    x, w = rnd(524288, 320), rnd(320, 320, scale=320 ** -0.5)
-    run("M= 524288 N=  320 K=  320 +rowbias", 2.0 * 524288 * 320 * 320, lambda: ops.gemm(x, w, None, rowbias=rb, rb_div=4096, alpha=0.7))
-    for (M, N2, K) in [(524288, 2560, 320), (131072, 5120, 640)]:
-        x, w = rnd(M, K), rnd(N2, K, scale=K ** -0.5)
-        bias = torch.randn(N2, device="cuda")
-        run(f"geglu M={M:7d} N2={N2:5d} K={K:5d}", 2.0 * M * N2 * K, lambda: ops.gemm_geglu(x, w, bias))
-
-
 def bench_flash16(_ops):
-    """fp16 storage: LDS-DMA kernels with the sampled max-free pass (default) against the round-2 kernels, BASELINE config-2 launch shapes."""
+    """fp16 storage: LDS-DMA kernels with the sampled max-free pass (default) against their exact pass and the generic kernels, BASELINE config-2 launch shapes."""
     ops = HipOps(act_dtype=torch.float16)
-    print("== fp16 storage flash attention: default (LDS-DMA, sampled max-free) vs round-2 kernels; median ms / TFLOP/s; err = rel L2 vs round-2 kernel")
-    for (D, n, F, L, b, old) in ((40, 4, 16, 4096, 2, 5), (80, 4, 16, 1024, 2, 8)):
+    print("== fp16 storage flash attention: default | exact | generic; median ms / TFLOP/s; err = rel L2 vs generic kernel")
+    for (D, n, F, L, b) in ((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2)):
         heads, C = 8, 8 * D
         rows = b * n * F * L
         for scale in (1.0, 2.0):
@@ -378,34 +164,23 @@ def bench_flash16(_ops):
             qm = RowMap(F, n * F * L, L, L, F * L)
             S, G = n * L, b * F
             flops = 4.0 * G * S * S * C
-            ops.lib.a3d_tune_flash(old)
-            ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
-            for var in (old, 0, old, 0):
-                ops.lib.a3d_tune_flash(var)
-                out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+            ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, plain=True).float()
+            for name, kw in ATTN_MODES * 2:
+                out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw).float()
                 err = ((out - ref).norm() / ref.norm()).item()
-                med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=5 if D == 40 else 10)
-                print(f"f16 D={D:3d} S={S:5d} scale={scale} var={var:2d}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
-    ops.lib.a3d_tune_flash(0)
+                med, mn = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw), reps=5 if D == 40 else 10)
+                print(f"f16 D={D:3d} S={S:5d} scale={scale} {name:8s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
 
 
 def bench_wgrad(ops):
-    """Weight gradient dW = dY^T X at the train.yaml shapes (4 views x 16 frames x 32x32 latent): round-2 kernel (a3d_tune_gemm(11)) vs the
-    LDS-DMA kernel (12, default)."""
-    print("== wgrad: median ms / TFLOP/s;  round-2 (register staging, v_perm transposition) | LDS-DMA + ds_read_b64_tr_b16")
+    """Weight gradient dW = dY^T X at the train.yaml shapes (4 views x 16 frames x 32x32 latent)."""
+    print("== wgrad (LDS-DMA + ds_read_b64_tr_b16): median us / TFLOP/s")
     for (M, N, K) in [(65536, 320, 320), (65536, 2560, 320), (65536, 320, 1280), (16384, 640, 640), (16384, 5120, 640), (16384, 640, 2560),
                       (4096, 1280, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (1024, 1280, 1280)]:
         dy, x = rnd(M, N), rnd(M, K)
         fl = 2.0 * M * N * K
-        outs, ref = [], None
-        for mode in (11, 12, 11, 12):
-            ops.lib.a3d_tune_gemm(mode)
-            y = ops.wgrad(dy, x)
-            ref = y if ref is None else ref
-            med, mn = timeit(lambda: ops.wgrad(dy, x), reps=9, warm=2)
-            outs.append(f"{med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s{'' if torch.equal(y, ref) else ' MISMATCH'}")
-        ops.lib.a3d_tune_gemm(12)
-        print(f"M={M:6d} N={N:5d} K={K:5d}: " + " | ".join(outs))
+        med, mn = timeit(lambda: ops.wgrad(dy, x), reps=9, warm=2)
+        print(f"M={M:6d} N={N:5d} K={K:5d}: {med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s")
 
 
 def bench_attnbwd(ops):
@@ -428,25 +203,6 @@ def bench_attnbwd(ops):
             fwd, _ = timeit(lambda: ops.flash_attn(q, k, v, qm, km, G, heads, S, S), reps=9, warm=2)
             fl = 4.0 * G * S * S * C
             print(f"D={D:3d} S={S:5d} {name:11s}: {fast:7.3f} ms ({2.5 * fl / fast / 1e9:6.1f} TF/s) | {slow:7.3f} ms   forward {fwd:6.3f} ms ({fl / fwd / 1e9:6.1f} TF/s)")
-
-
-def bench_fill(ops):
-    print("== persistent kernel on partially filled grids: median ms for 128x128 classic | persistent (a3d_tune_gemm(300 + 40): min fill 40 %)")
-    def ab(fn):
-        ops.lib.a3d_tune_gemm(1); a, _ = timeit(fn, reps=9)
-        ops.lib.a3d_tune_gemm(3); ops.lib.a3d_tune_gemm(340); b, _ = timeit(fn, reps=9)
-        ops.lib.a3d_tune_gemm(350)
-        return f"{a:7.3f} | {b:7.3f}"
-    for (M, N, K) in [(8192, 1280, 1280), (8192, 3840, 1280), (8192, 1280, 5120), (8192, 1280, 2560), (8192, 5120, 1280), (32768, 1280, 1280), (32768, 1920, 1280), (131072, 320, 640)]:
-        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
-        bias = torch.randn(N, device="cuda"); res = rnd(M, N)
-        tiles = (M // 256) * (N // 320)
-        print(f"M={M:7d} N={N:5d} K={K:5d} tiles={tiles:4d}: {ab(lambda: ops.gemm(x, w, bias, residual=res))}")
-    for (B, H, W, Cin, Cout) in [(128, 8, 8, 1280, 1280), (128, 8, 8, 2560, 1280), (128, 16, 16, 1280, 1280)]:
-        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
-        bias = torch.randn(Cout, device="cuda")
-        tiles = (B * H * W // 256) * (Cout // 320)
-        print(f"conv B={B} {H}x{W} {Cin}->{Cout} tiles={tiles:4d}: {ab(lambda: ops.conv3x3(x, B, H, W, w, bias))}")
 
 
 def bench_graph(ops):
@@ -536,16 +292,10 @@ def bench_misc(ops):
     u = rnd(M, 8 * C)
     med, _ = timeit(lambda: ops.geglu(u)); print(f"geglu             : {med:7.3f} ms  {M * 12 * C * 2 / med / 1e6:7.0f} GB/s")
     qkv = rnd(M, 3 * C)
-    for pix in (2, 1, 4):
-        ops.lib.a3d_tune_flash(10 + pix)
-        med, _ = timeit(lambda: ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, 8)); print(f"temporal_attn D40 pix={pix}: {med:7.3f} ms  {4 * M * C * 2 / med / 1e6:7.0f} GB/s")
-    ops.lib.a3d_tune_flash(12)
+    med, _ = timeit(lambda: ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, 8)); print(f"temporal_attn D40   : {med:7.3f} ms  {4 * M * C * 2 / med / 1e6:7.0f} GB/s")
     for (M2, C2, L2) in ((131072, 640, 1024), (32768, 1280, 256)):
         qkv2 = rnd(M2, 3 * C2)
-        for pix in (2, 1, 4):
-            ops.lib.a3d_tune_flash(10 + pix)
-            med, _ = timeit(lambda: ops.temporal_attn(qkv2[:, :C2], qkv2[:, C2:2 * C2], qkv2[:, 2 * C2:], V, F, L2, 8)); print(f"temporal_attn C={C2} pix={pix}: {med:7.3f} ms  {4 * M2 * C2 * 2 / med / 1e6:7.0f} GB/s")
-        ops.lib.a3d_tune_flash(12)
+        med, _ = timeit(lambda: ops.temporal_attn(qkv2[:, :C2], qkv2[:, C2:2 * C2], qkv2[:, 2 * C2:], V, F, L2, 8)); print(f"temporal_attn C={C2}: {med:7.3f} ms  {4 * M2 * C2 * 2 / med / 1e6:7.0f} GB/s")
     a, bb = rnd(M, 640), rnd(M, 320)
     med, _ = timeit(lambda: ops.concat(a, bb)); print(f"concat 640+320    : {med:7.3f} ms  {2 * M * 960 * 2 / med / 1e6:7.0f} GB/s")
 
@@ -556,13 +306,11 @@ if __name__ == "__main__":
     ops = HipOps()
     print(torch.cuda.get_device_name(0))
     for w in which:
-        {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "persist": bench_persist, "convk": bench_convk, "fill": bench_fill, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "pp": bench_pp, "duo": bench_duo, "epiabl": bench_epiabl, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+        {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
+         "flashdm": bench_flashdm, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
+         "flash160": lambda o: bench_flash(o, ((160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
          "gemm1": lambda o: ([o.gemm(rnd(32768, 5120), rnd(1280, 5120, scale=0.01)) for _ in range(3)],
                              [o.gemm(rnd(524288, 320), rnd(1280, 320, scale=0.05)) for _ in range(3)],
-                             [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)]),
-         "conv7": lambda o: (o.lib.a3d_tune_gemm(7), [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)],
-                             [o.conv3x3(rnd(128 * 32 * 32, 1280), 128, 32, 32, rnd(640, 11520, scale=0.01), torch.zeros(640, device="cuda")) for _ in range(3)],
-                             o.lib.a3d_tune_gemm(6), [o.conv3x3(rnd(128 * 32 * 32, 1280), 128, 32, 32, rnd(640, 11520, scale=0.01), torch.zeros(640, device="cuda")) for _ in range(3)])}[w](ops)
+                             [o.conv3x3(rnd(128 * 64 * 64, 320), 128, 64, 64, rnd(320, 2880, scale=0.02), torch.zeros(320, device="cuda")) for _ in range(3)])}[w](ops)
