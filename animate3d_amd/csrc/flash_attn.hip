@@ -73,17 +73,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
-  // Default order: head fastest, so with 8 heads block b runs on XCD b % 8 = head and all query tiles of a (group, head) share one
-  // L2 copy of its K/V.  When K/V are a handful of tokens (cross attention: 77 text + 4 image tokens) the traffic is Q in and O out, and
-  // a token row's 8 head slices (80 .. 320 B of one 640 .. 2560-B row) read / written from 8 different XCDs cost every 128-B line
-  // twice; then the order is query-tile-major per XCD: block b -> XCD x = b % 8, slot s = b / 8, head = s % heads, tile = 8 (s / heads) + x.
-  int head = blockIdx.x % p.heads;
-  int qt = blockIdx.x / p.heads;
-  if (p.q_tiles_per_xcd_order) {
-    const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
-    head = sl % p.heads;
-    qt = (sl / p.heads) * 8 + x;
-  }
+  // head fastest: with 8 heads block b runs on XCD b % 8 = head and all query tiles of a (group, head) share one L2 copy of its K/V
+  // (a query-tile-major order for the short-K/V cross attention measured no difference: that launch is bound by its per-workgroup
+  // prologue, not by the Q / O lines shared between XCDs; profiles/README.md, round 4)
+  const int head = blockIdx.x % p.heads;
+  const int qt = blockIdx.x / p.heads;
   const int64_t grp = blockIdx.y;
   const int64_t hoff = (int64_t)head * D;
 
@@ -572,20 +566,16 @@ bool map_ok(const a3d_rowmap* m, int head_dim) {
 
 
 template <int D, int BKV, int QT, int OFS, int VAR = 0, int NM = 0>
-void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p0) {
-  AttnParams p = p0;
+void launch(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
   const int q_tiles = (p.q_len + 128 * QT - 1) / (128 * QT);
-  p.q_tiles_per_xcd_order = (p.kv_len <= 128 && q_tiles % 8 == 0) ? 1 : 0;
   const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
   if (aligned) flash_attn_kernel<D, BKV, QT, OFS, true, VAR, NM><<<grid, dim3(256), 0, s>>>(p);
   else flash_attn_kernel<D, BKV, QT, OFS, false, 0><<<grid, dim3(256), 0, s>>>(p);
 }
 
 template <int D, int BKV, int OFS>
-void launch_two(bool aligned, int groups, hipStream_t s, const AttnParams& p0) {
-  AttnParams p = p0;
+void launch_two(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
   const int q_tiles = (p.q_len + 127) / 128;
-  p.q_tiles_per_xcd_order = (p.kv_len <= 128 && p.kv_len2 <= 128 && q_tiles % 8 == 0) ? 1 : 0;
   const dim3 grid((unsigned)(p.heads * q_tiles), (unsigned)groups);
   if (aligned) flash_attn_kernel<D, BKV, 1, OFS, true, 0, 0, true><<<grid, dim3(256), 0, s>>>(p);
   else flash_attn_kernel<D, BKV, 1, OFS, false, 0, 0, true><<<grid, dim3(256), 0, s>>>(p);

@@ -18,9 +18,6 @@ struct AttnParams {
   // training (a3d_flash_attn_lse): per query log2 sum_k 2^(s_qk * scale * log2 e), [groups][heads][q_len] floats, as the backward's
   // statistics pass would compute it (attn_bwd.hip); nullptr: not wanted
   float* lse;
-  // generic kernel, short K/V (text / IP tokens): blockIdx -> (query tile, head) so that the `heads` workgroups of one query tile run
-  // on ONE XCD (see flash_attn_kernel); 0 = head fastest (XCD = head: every query tile of a head shares that XCD's copy of its K/V)
-  int q_tiles_per_xcd_order;
 };
 
 namespace {
