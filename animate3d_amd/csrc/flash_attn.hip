@@ -672,9 +672,14 @@ extern "C" int A3D_FN(a3d_flash_attn2)(a3d_stream_t stream, const void* Q, const
   p.K2 = (const uint16_t*)K2; p.V2 = (const uint16_t*)V2;
   p.qm = *qmap; p.km = *kmap; p.km2 = *kmap2; p.om = *omap;
   p.heads = heads; p.q_len = (int)q_len; p.kv_len = (int)kv_len; p.kv_len2 = (int)kv_len2;
+  if (accumulate & ~(A3D_ATTN_ACCUMULATE | A3D_ATTN_PLAIN)) return A3D_EINVAL;
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.out_scale2 = out_scale2; p.accumulate = accumulate & 1; p.causal = 0;
   const bool aligned = ((kmap->seg_len % 64 == 0) || (kv_len <= kmap->seg_len)) && ((kmap2->seg_len % 64 == 0) || (kv_len2 <= kmap2->seg_len));
   hipStream_t s = (hipStream_t)stream;
+  if (head_dim == 40 && !(accumulate & A3D_ATTN_PLAIN)) {      // level 0: the register-resident cross-attention kernel (cross_attn.hip)
+    const int rc = A3D_FN(a3d_launch_cross_attn40)(groups, s, p);
+    if (rc != A3D_EUNSUPPORTED) return rc;
+  }
   if (head_dim == 40) launch_two<40, 64, OFS_PAD>(aligned, groups, s, p);
   else launch_two<80, 64, OFS_ACC>(aligned, groups, s, p);
   return a3d_launch_status();

@@ -255,10 +255,11 @@ def test_flash_attn_cross_text_ip(ops, ref, D):
 
 
 @pytest.mark.parametrize("D", [40, 80, 160])
-@pytest.mark.parametrize("V,F,L", [(2, 3, 64), (1, 2, 300)])
+@pytest.mark.parametrize("V,F,L", [(2, 3, 64), (1, 2, 300), (2, 2, 1024), (1, 1, 2100)])
 def test_flash_attn_two_key_sets_in_one_launch(ops, ref, D, V, F, L):
     """a3d_flash_attn2: text tokens (77) + IP-Adapter image tokens (4) in one launch, each with its own softmax, against the two-call
-    sequence of the fp32 reference (attention_processor.py:233, 254-283); head_dim 160 has no fused kernel and must say so (None)."""
+    sequence of the fp32 reference (attention_processor.py:233, 254-283); head_dim 160 has no fused kernel and must say so (None).
+    From 256 queries per group head_dim 40 takes the register-resident kernel of cross_attn.hip (ragged counts: 300 / 2 100 queries)."""
     heads, T, nt = 8, 77, 4
     C = heads * D
     q = rnd(V * F * L, C, seed=1)
@@ -272,6 +273,14 @@ def test_flash_attn_two_key_sets_in_one_launch(ops, ref, D, V, F, L):
     want = ref.flash_attn2(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), V * F, heads,
                            L, T, nt, out_scale2=0.7)
     check(f"text + ip attention in one launch D{D} V{V} F{F} L{L}", got, want)
+    if D == 40 and L >= 256:      # other token counts through the same kernel: a full 96 + 32, single tokens
+        for T2, nt2 in ((96, 32), (33, 1), (1, 5)):
+            kvt2, kvi2 = rnd(V * T2, 2 * C, seed=4), rnd(V * nt2, 2 * C, seed=5)
+            g2 = ops.flash_attn2(q, kvt2[:, :C], kvt2[:, C:], kvi2[:, :C], kvi2[:, C:], qc, RowMap(F, T2, 0, T2, 0), RowMap(F, nt2, 0, nt2, 0), V * F, heads,
+                                 L, T2, nt2, out_scale2=1.3)
+            w2 = ref.flash_attn2(q, kvt2[:, :C], kvt2[:, C:], kvi2[:, :C], kvi2[:, C:], qc, RowMap(F, T2, 0, T2, 0), RowMap(F, nt2, 0, nt2, 0), V * F, heads,
+                                 L, T2, nt2, out_scale2=1.3)
+            check(f"text + ip attention D{D} L{L} tokens {T2} + {nt2}", g2, w2)
 
 
 def test_flash_attn_rescale_branch(ops, ref):
