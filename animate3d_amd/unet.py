@@ -950,6 +950,37 @@ class MVUNetMotionModel(nn.Module):
         with torch.no_grad():
             return self._forward_impl(sample, timestep, encoder_hidden_states, packed=None, **kw)
 
+    def _reject_attention_mask(self, attention_mask, sample, num_views):
+        """``attention_mask`` (:639, 700-703, 778-841) cannot be honoured — by the reference either.  It becomes an additive bias
+        [B, 1, K] that every Transformer2D ``attn1`` hands to xformers after ``(b n f) l c -> (b f) (n l) c`` (attention_processor.py:340,
+        361-370, 405, 416); diffusers' ``prepare_attention_mask`` pads a mask whose length is not n * l BY n * l, so the bias can match
+        xformers' required [b F heads, n l, n l] at ONE resolution at most, and this UNet attends at several: the reference raises inside
+        xformers for any mask.  Same here, with the shape walk in the message (oracle/unet_ref.py: reference_attention_mask_trace restates
+        it; tests/test_host_logic.py pins it).  A UNet with attention at a single resolution would be consistent for a [b F, n l] mask;
+        that bias is not implemented in the attention kernels."""
+        if attention_mask.dim() != 2:
+            raise ValueError(f"attention_mask must be [batch, key_tokens] (unet_motion_mv_model.py:662), got {tuple(attention_mask.shape)}")
+        V, n, F = sample.shape[0], num_views, sample.shape[2]
+        h, w = sample.shape[-2:]
+        ls, hh, ww = [], h, w
+        for i in range(len(self.config.block_out_channels)):
+            if self.config.down_has_attn[i] or i == len(self.config.block_out_channels) - 1:
+                ls.append(hh * ww)
+            if i < len(self.config.block_out_channels) - 1:
+                hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        B, K = attention_mask.shape
+        heads, b = self.config.num_attention_heads, V // n
+        bad = []
+        for l in ls:
+            k_eff = K if K == n * l else K + n * l
+            b_eff = B * heads if B < b * F * heads else B
+            if (b_eff, k_eff) != (b * F * heads, n * l):
+                bad.append(f"{l} tokens per image: bias [{b_eff}, {n * l}, {k_eff}] vs required [{b * F * heads}, {n * l}, {n * l}]")
+        if bad:
+            raise ValueError("attention_mask " + str(tuple(attention_mask.shape)) + " is inconsistent with the attention shapes of this UNet, as it "
+                             "is in the reference (its xformers call raises): " + "; ".join(bad))
+        raise NotImplementedError("a key bias for a UNet that attends at a single resolution is not implemented in the attention kernels")
+
     def _forward_impl(self, sample, timestep, encoder_hidden_states, *, packed, timestep_cond, attention_mask, cross_attention_kwargs,
                       added_cond_kwargs, down_block_additional_residuals, mid_block_additional_residual, return_dict, camera, num_views,
                       i2v_cond_time_zero):
@@ -958,8 +989,7 @@ class MVUNetMotionModel(nn.Module):
             # the reference adds time_embedding.cond_proj(timestep_cond) (:726-730); the SD1.5 UNet has no cond_proj (time_cond_proj_dim = None)
             raise ValueError("timestep_cond needs a time_embedding.cond_proj, which this UNet (time_cond_proj_dim = None) does not have")
         if attention_mask is not None:
-            raise NotImplementedError("attention_mask (:700-703: an additive key bias inside every attention) is not supported; no caller "
-                                      "of the reference passes one")
+            self._reject_attention_mask(attention_mask, sample, num_views)
         if cross_attention_kwargs:
             # diffusers hands `scale` to the processors as the LoRA scale; without LoRA layers (this model has none) it changes nothing
             extra = set(cross_attention_kwargs) - {"scale"}

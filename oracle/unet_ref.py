@@ -244,6 +244,34 @@ def _sdpa(q, k, v, heads: int):
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
+def reference_attention_mask_trace(mask_shape, V, n, F, heads, tokens_per_image):
+    """What the reference does with ``attention_mask`` [B, K] at every Transformer2D ``attn1`` it reaches — the shape walk behind the
+    product's error for this argument (animate3d_amd/unet.py).
+
+    * unet_motion_mv_model.py:700-703: ``(1 - mask) * -10000`` and ``unsqueeze(1)`` -> [B, 1, K]; :778, 806, 815, 841 hand it to every
+      down / mid / up block, diffusers passes it to ``BasicTransformerBlock.attn1`` (the motion modules receive no mask).
+    * attention_processor.py:340 regroups ``(b n f) l c -> (b f) (n l) c``: batch_size = b * F, key_tokens = query_tokens = n * l; :361
+      calls ``attn.prepare_attention_mask(mask, key_tokens, batch_size)`` — diffusers 0.28 (pinned by the reference's requirements;
+      not under /root/reference): if the mask's last dimension differs from key_tokens it is PADDED BY key_tokens (``F.pad(mask, (0,
+      target_length))``, not to key_tokens), and it is ``repeat_interleave``d over the heads only when its batch is smaller than
+      batch_size * heads; :370 expands the singleton query dimension; :405, 416 pass it to xformers as ``attn_bias``, which requires
+      exactly [batch_size * heads, query_tokens, key_tokens].
+
+    ``tokens_per_image``: l = h * w at every resolution that has a Transformer2D (level 0 .. the mid block).  Returns one record per
+    resolution: (l, bias shape the reference builds, shape xformers requires, consistent?).  A UNet with attention at two resolutions can
+    never be consistent at both (K cannot equal n * l for two different l), i.e. the reference raises inside xformers for ANY mask."""
+    B, K = mask_shape
+    b = V // n
+    out = []
+    for l in tokens_per_image:
+        batch, key_tokens = b * F, n * l
+        k_eff = K if K == key_tokens else K + key_tokens
+        b_eff = B * heads if B < batch * heads else B
+        built, need = (b_eff, key_tokens, k_eff), (batch * heads, key_tokens, key_tokens)
+        out.append((l, built, need, built == need))
+    return out
+
+
 class Attention(nn.Module):
     """The subset of diffusers.models.attention_processor.Attention that the reference's
     processors touch (SURVEY.md §8c list)."""

@@ -364,7 +364,7 @@ def test_controlnet_residual_inputs(hw):
         model(**inp, down_block_additional_residuals=down[:-1])
     with pytest.raises(ValueError):
         model(**inp, timestep_cond=torch.zeros(n, 4))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="inconsistent with the attention shapes"):
         model(**inp, attention_mask=torch.ones(n, 77))
     with pytest.raises(NotImplementedError):
         model(**inp, cross_attention_kwargs={"gligen": {}})
@@ -405,3 +405,23 @@ def test_motion_module_save_load_freeze_surface(tmp_path):
         other.set_default_attn_processor()
     with pytest.raises(ValueError):
         other.enable_forward_chunking(2, 3)
+
+
+def test_attention_mask_cannot_be_consistent_in_the_reference_either():
+    """``attention_mask`` (unet_motion_mv_model.py:639, 700-703): the shape walk of what the reference builds from it
+    (oracle.unet_ref.reference_attention_mask_trace: regrouping of attention_processor.py:340, diffusers' prepare_attention_mask, the
+    xformers bias contract) is inconsistent at some resolution for EVERY mask shape a caller could pass to the full UNet — the reference
+    raises inside xformers, the product raises with the same walk in its message."""
+    from oracle.unet_ref import reference_attention_mask_trace as trace
+    V, n, F, heads = 8, 4, 16, 8
+    res = [64 * 64, 32 * 32, 16 * 16, 8 * 8]                       # tokens per image at the four resolutions that attend (config 2)
+    cands = set()
+    for B in (1, V // n, V, (V // n) * F, V * F, (V // n) * F * heads, V * F * heads):
+        for K in (77, 81, *res, *(n * l for l in res)):
+            cands.add((B, K))
+    for shape in sorted(cands):
+        walk = trace(shape, V, n, F, heads, res)
+        assert not all(ok for *_, ok in walk), (shape, walk)
+        assert sum(ok for *_, ok in walk) <= 1                     # at most one resolution can match
+    # the only consistent case: a UNet that attends at ONE resolution and a [b F, n l] mask
+    assert trace(((V // n) * F, n * 64), V, n, F, heads, [64]) == [(64, ((V // n) * F * heads, n * 64, n * 64), ((V // n) * F * heads, n * 64, n * 64), True)]
