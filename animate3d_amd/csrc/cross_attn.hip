@@ -95,7 +95,10 @@ __global__ __launch_bounds__(512, 2) void cross_attn40_kernel(const AttnParams p
 #pragma unroll
       for (int ks = 0; ks < XA_KS; ++ks) s[kt] = mfma32(kf[kt][ks], qf[ks], s[kt]);
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = vmax3(mx, s[kt][r], s[kt][r + 1]);       // (missing keys sit at ~-30000: they never win)
+      // (missing keys sit at ~-30000: they never win.  Plain fmaxf, not the v_max3 inline-asm helper: the compiler pads the MFMA-result ->
+      // VALU-read hazard only for instructions it can see, and an unpadded read right behind the MFMA returns a stale maximum — any maximum
+      // gives a correct softmax, so every parity test passed, but the bits changed from run to run)
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[kt][r], s[kt][r + 1]));
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
 #pragma unroll

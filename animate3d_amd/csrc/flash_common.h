@@ -40,13 +40,6 @@ A3D_DEV int kperm(int i) {
 A3D_DEV float round16(float x) { return lo16(pack16(x, 0.f)); }
 
 
-A3D_DEV float vmax3(float a, float b, float c) {      // no NaN canonicalisation of the MFMA results (fmaxf adds a v_max per input)
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
-
 // LDS-DMA: 64 lanes x 16 B, lane i -> LDS[lds_dst + 16 i]; source = scalar base + per-lane byte offset.  Not counted by the
 // compiler: s_waitcnt vmcnt by hand.
 A3D_DEV void dm_glds16(uint32_t voff, const void* sbase, uint32_t lds_dst) {

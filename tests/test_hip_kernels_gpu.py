@@ -273,6 +273,9 @@ def test_flash_attn_two_key_sets_in_one_launch(ops, ref, D, V, F, L):
     want = ref.flash_attn2(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), V * F, heads,
                            L, T, nt, out_scale2=0.7)
     check(f"text + ip attention in one launch D{D} V{V} F{F} L{L}", got, want)
+    again = ops.flash_attn2(q, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), V * F, heads,
+                            L, T, nt, out_scale2=0.7)
+    assert torch.equal(got, again), "the launch must be bit-reproducible (an unpadded MFMA -> inline-asm hazard once made it drift by an ulp)"
     if D == 40 and L >= 256:      # other token counts through the same kernel: a full 96 + 32, single tokens
         for T2, nt2 in ((96, 32), (33, 1), (1, 5)):
             kvt2, kvi2 = rnd(V * T2, 2 * C, seed=4), rnd(V * nt2, 2 * C, seed=5)
