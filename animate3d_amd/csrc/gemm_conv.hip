@@ -363,8 +363,15 @@ int try_launch_persist(hipStream_t stream, GemmParams& p, int flags) {
   const int reserved = a3d_gemm_reserved_cus_of(flags);
   const int cus = cus_of[dev] - reserved > 32 ? cus_of[dev] - reserved : 32;
   if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return -1000;
-  const int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
+  int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
   if (nb == 0) return -1000;
+  if (nb == 5 && p.N % 256 == 0) {
+    // both tile widths divide N (1280, 2560, 3840 ...): the 256 x 320 tile stages fewer operand bytes per FLOP and is the default, but when
+    // the grid is only a round or two (level 3: M = 8192) the narrower tile can fill more CUs — compare rounds x tile width
+    const int64_t tm = (p.M + PBM - 1) / PBM;
+    const int64_t cost5 = ((tm * (p.N / 320) + cus - 1) / cus) * 5, cost4 = ((tm * (p.N / 256) + cus - 1) / cus) * 4;
+    if (cost4 * 108 < cost5 * 100) nb = 4;
+  }
   // 32-bit DMA offsets
   if (p.ldw % 64 != 0 || (CONV == 0 && p.ldx % 64 != 0)) return -1000;
   if (CONV == 0 && (uint64_t)p.ldx * 16u >= (1ull << 31)) return -1000;

@@ -380,8 +380,9 @@ def main():
                                  "exp_issue_tflops_equivalent": round(exp_ceiling, 1), "frac_of_exp_ceiling": achieved / exp_ceiling,
                                  "note": "head_dim 40: one v_exp_f32 per 160 MFMA FLOPs; padding of the issued MFMA work: QK^T contraction 40->48, O^T rows "
                                          "41->48 (16x16x32 MFMA); the exp ceiling is the v_exp rate measured next to the "
-                                         "kernel's MFMA / cvt mix (tools/ubench_exp.hip); the kernel is clock-limited by power: zero inputs run it 22-29 % faster and "
-                                         "removing its per-tile barrier changes nothing on random data (profiles/README.md)"},
+                                         "kernel's MFMA / cvt mix (tools/ubench_exp.hip); the kernel is clock-limited by power: zero inputs run the shipped variant 13-14 % faster, "
+                                         "removing its per-tile barrier changes nothing on random data, and a one-wave-per-SIMD re-instantiation (round 4) lands on "
+                                         "the same 10.8 ms (profiles/README.md)"},
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                     "traffic_source": (pmc or {}).get("source", "no committed PMC pass for this launch shape"),
                     "algorithmic_bytes_per_launch": 4.0 * (V // n) * F * S0 * D * 8 * 2,      # Q, K, V read + O written once, bf16

@@ -102,6 +102,9 @@ def _persistent_eligible(M, N, geglu=False, cus=256):
     nb = (4 if N % 256 == 0 else 0) if geglu else (5 if N % 320 == 0 else (4 if N % 256 == 0 else 0))
     if nb == 0 or M % 256:
         return False
+    if nb == 5 and N % 256 == 0:         # both tile widths divide N: the narrower one when it needs fewer (rounds x width)
+        c5, c4 = -(-((M // 256) * (N // 320)) // cus) * 5, -(-((M // 256) * (N // 256)) // cus) * 4
+        nb = 4 if c4 * 108 < c5 * 100 else 5
     tiles = (M // 256) * (N // (64 * nb))
     rounds = -(-tiles // cus)
     return tiles * 100 >= rounds * cus * 50           # average fill of the persistent grid's rounds >= 50 %
@@ -125,7 +128,8 @@ def _both_paths(ops, fn):
     return got, classic, reserved
 
 
-@pytest.mark.parametrize("M,N,K", [(65536, 320, 64), (65536, 320, 320), (65536, 640, 192), (65536, 256, 128), (49152, 1280, 128), (24576, 2560, 64)])
+@pytest.mark.parametrize("M,N,K", [(65536, 320, 64), (65536, 320, 320), (65536, 640, 192), (65536, 256, 128), (49152, 1280, 128), (24576, 2560, 64),
+                                   (8192, 1280, 128)])          # last: one round only -> the 256 x 256 tile (160 tiles) instead of 256 x 320 (128 tiles)
 def test_gemm_persistent_path(ops, ref, M, N, K):
     assert _persistent_eligible(M, N)          # same rule as try_launch_persist() in csrc/gemm_conv.hip
     x, w = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5)
