@@ -150,8 +150,21 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
   // ds_write_b128 rate (~80 B/clk per CU) made the transposition the longest part of a K = 320 tile's epilogue.  Arithmetic and
   // rounding per element are exactly those of the fp32-staged path below (kept for residual epilogues: one rounding after the add).
   if constexpr (EPI == EPI_GEGLU || !RES) {
-    constexpr int RS = (EPI == EPI_GEGLU) ? 80 : 144;        // bytes per staged row: 32 / 64 values + 16 (keeps 16-byte alignment)
+    // Staged rows are unpadded (64 / 128 bytes) and swizzled instead: the 16-byte chunk index is XORed with row bits and the two
+    // 8-byte halves of a chunk trade places on rows with bit 3 set.  ds_write_b64 is served 16 consecutive lanes (= rows, same
+    // column) at a time over 32 banks and ds_read_b128 in the lane groups {0-3,12-15,20-27} ... over 64: both come out
+    // conflict-free (the padded layout of before was 2-way on the stores and overlapped rows on the loads: SQ_LDS_BANK_CONFLICT
+    // of a K = 640 launch was a quarter of its LDS cycles, profiles/r4_gemm_pp_pmc_sq.md).
+    constexpr int RS = (EPI == EPI_GEGLU) ? 64 : 128;
     char* const stg16 = reinterpret_cast<char*>(stg);
+    const int wsw = (EPI == EPI_GEGLU) ? ((l31 >> 1) & 3) : (l31 & 7);      // chunk swizzle of the row this lane stores
+    const int whalf = 8 * (g ^ ((l31 >> 3) & 1));
+    auto unswap = [](u32x4_t o, int row) {
+      const bool sw = row & 8;
+      u32x4_t r;
+      r[0] = sw ? o[2] : o[0]; r[1] = sw ? o[3] : o[1]; r[2] = sw ? o[0] : o[2]; r[3] = sw ? o[1] : o[3];
+      return r;
+    };
 #pragma unroll
     for (int pi = 0; pi < 2 * NP; ++pi) {
       const int tm = pi / NP, ps = pi % NP;
@@ -178,7 +191,7 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
             u32x2_t o;
             o[0] = pack16(y[4 * h], y[4 * h + 1]);
             o[1] = pack16(y[4 * h + 2], y[4 * h + 3]);
-            *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + (8 * (2 * q2 + h) + 4 * g) * 2) = o;
+            *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + 16 * ((2 * q2 + h) ^ wsw) + whalf) = o;
           }
         }
         wave_lds_fence();
@@ -188,7 +201,7 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
         for (int j = 0; j < 2; ++j) {
           const int row = 16 * j + (lane >> 2);
           const int64_t m = mbase + row;
-          const u32x4_t o = *reinterpret_cast<const u32x4_t*>(stg16 + row * RS + cc * 16);
+          const u32x4_t o = unswap(*reinterpret_cast<const u32x4_t*>(stg16 + row * RS + 16 * (cc ^ ((row >> 1) & 3))), row);
 #ifdef A3D_ABLATIONS
           if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
           *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + oc) = o;
@@ -218,7 +231,7 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
               u32x2_t o;
               o[0] = pack16(v[0], v[1]);
               o[1] = pack16(v[2], v[3]);
-              *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + c0 * 2) = o;
+              *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + 16 * ((4 * tl + q) ^ wsw) + whalf) = o;
             }
           }
         }
@@ -230,7 +243,7 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
           if (j * (64 / lpr) >= 32) continue;
           const int row = (64 / lpr) * j + lane / lpr;
           const int64_t m = mbase + row;
-          const u32x4_t o = *reinterpret_cast<const u32x4_t*>(stg16 + row * RS + cc * 16);
+          const u32x4_t o = unswap(*reinterpret_cast<const u32x4_t*>(stg16 + row * RS + 16 * (cc ^ (row & 7))), row);
 #ifdef A3D_ABLATIONS
           if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
           *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + nbase + 8 * cc) = o;

@@ -953,6 +953,26 @@ def synthetic_inputs(cfg: UNetConfig, videos: int, num_views: int, num_frames: i
                 added_cond_kwargs={"image_embeds": img}, camera=cam, num_views=num_views)
 
 
+def build_dense(cfg: UNetConfig, num_views: int, num_frames: int, latent_hw, seed: int = 0, dense: bool = True,
+                state_dict=None) -> "MVUNetMotionModelRef":
+    """``MVUNetMotionModelRef(...)`` + ``init_synthetic_weights(seed, dense)`` without paying torch's default parameter init
+    (~20 s of single-threaded Kaiming draws at the SD1.5 widths, all of it overwritten): build on the meta device, materialise,
+    refill the positional buffers, then draw the same seeded weights — value for value what the two-step construction gives.
+    With ``state_dict`` the tensors of an already drawn model are adopted instead (shared storage, read-only use): another
+    token geometry over the same weights costs ~1 s."""
+    with torch.device("meta"):
+        m = MVUNetMotionModelRef(cfg, num_views, num_frames, latent_hw)
+    if state_dict is not None:
+        m.load_state_dict(state_dict, strict=True, assign=True)
+        return m.eval()
+    m = m.to_empty(device="cpu").eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, TimePosEmbed):
+                mod.pe.copy_(sinusoidal_pos_1d(mod.pe.shape[2], mod.pe.shape[1]))
+    return init_synthetic_weights(m, seed=seed, dense=dense)
+
+
 def build_fast(cfg: UNetConfig, num_views: int, num_frames: int, latent_hw, seed: Optional[int] = 0) -> "MVUNetMotionModelRef":
     """Construct the oracle without torch's default (slow, single-threaded) parameter init: build on the
     meta device, materialise, refill the positional buffers and draw cheap seeded uniform weights.

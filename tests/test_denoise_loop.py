@@ -170,8 +170,8 @@ def test_denoise_loop_matches_oracle_loop():
     from oracle import unet_ref as O
     n, F, hw = 2, 3, (16, 16)
     ocfg = O.UNetConfig()
-    ref = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
-    O.init_synthetic_weights(ref, seed=0, dense=True)
+    from tests.conftest import oracle_unet
+    ref = oracle_unet(ocfg, n, F, hw, seed=0)
     hip = MVUNetMotionModel(UNetConfig(), num_views=n, device="cuda")
     hip.load_state_dict(ref.state_dict(), strict=True)
     hip = hip.to(torch.bfloat16).eval()

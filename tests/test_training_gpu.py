@@ -14,6 +14,7 @@ from animate3d_amd.config import UNetConfig
 from animate3d_amd.train import FlatAdamW, select_trainable, training_step
 from animate3d_amd.unet import MVUNetMotionModel
 from oracle import unet_ref as O
+from tests.conftest import oracle_unet
 from tests.torch_ops import TorchRefOps
 
 pytestmark = pytest.mark.gpu
@@ -29,8 +30,7 @@ def _cuda(inp):
 @pytest.fixture(scope="module")
 def oracle():
     ocfg = O.UNetConfig()
-    ref = O.MVUNetMotionModelRef(ocfg, N_VIEWS, FRAMES, HW)
-    O.init_synthetic_weights(ref, seed=0, dense=True)
+    ref = oracle_unet(ocfg, N_VIEWS, FRAMES, HW, seed=0).train()
     select_trainable(ref)
     inp = O.synthetic_inputs(ocfg, N_VIEWS, N_VIEWS, FRAMES, HW, seed=3, cfg_doubled=False)
     target = torch.randn(N_VIEWS, 4, FRAMES - 1, *HW, generator=torch.Generator().manual_seed(1))

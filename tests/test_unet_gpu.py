@@ -22,6 +22,7 @@ import torch
 from animate3d_amd.config import UNetConfig
 from animate3d_amd.unet import MVUNetMotionModel
 from oracle import unet_ref as O
+from tests.conftest import oracle_unet
 from tests.torch_ops import TorchRefOps
 
 pytestmark = pytest.mark.gpu
@@ -33,8 +34,7 @@ N_VIEWS, FRAMES, HW = 2, 3, (16, 16)
 def models():
     torch.manual_seed(0)
     ocfg = O.UNetConfig()
-    ref = O.MVUNetMotionModelRef(ocfg, N_VIEWS, FRAMES, HW).eval()
-    O.init_synthetic_weights(ref, seed=0, dense=True)
+    ref = oracle_unet(ocfg, N_VIEWS, FRAMES, HW, seed=0)
     sd = ref.state_dict()
     hip = MVUNetMotionModel(UNetConfig(), num_views=N_VIEWS, device="cuda")
     missing, unexpected = hip.load_state_dict(sd, strict=True)
@@ -88,8 +88,7 @@ def test_forward_parity_config4_geometry(models):
     first-frame row maps, 1x1-pixel feature maps at level 3."""
     ocfg, ref, hip, _ = models
     n, F, hw = 8, 32, (8, 8)
-    ref8 = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
-    ref8.load_state_dict(ref.state_dict(), strict=True)
+    ref8 = O.build_dense(ocfg, n, F, hw, state_dict=ref.state_dict())
     inp = O.synthetic_inputs(ocfg, n, n, F, hw, seed=5)
     y_ref = ref8(**inp).sample
     hip.num_views = n
@@ -125,8 +124,7 @@ def test_switch_sets_on_the_hip_path(kw):
     arch = dict(block_out_channels=(320, 640), down_has_attn=(True, True), layers_per_block=1)
     n, F, hw, V = 2, 3, (16, 16), 2
     ocfg = O.UNetConfig(**arch, **kw)
-    ref = O.MVUNetMotionModelRef(ocfg, n, F, hw).eval()
-    O.init_synthetic_weights(ref, seed=0, dense=True)
+    ref = O.build_dense(ocfg, n, F, hw, seed=0)
     hip = MVUNetMotionModel(UNetConfig(**arch, **kw), num_views=n, device="cuda")
     missing, unexpected = hip.load_state_dict(ref.state_dict(), strict=True)
     assert not missing and not unexpected
@@ -197,17 +195,23 @@ def test_fp16_model_and_inputs(models):
 
 
 def test_baseline_config1_shape():
-    """BASELINE config 1 exactly: 1 view x 4 frames x 64x64 latent, no CFG (the reference's CPU-runnable case)."""
-    ocfg = O.UNetConfig()
-    ref = O.build_fast(ocfg, 1, 4, (64, 64), seed=3)
+    """BASELINE config 1 exactly: 1 view x 4 frames x 64x64 latent, no CFG (the reference's CPU-runnable case), against the oracle's
+    output committed by tests/golden/make_gpu_tier_goldens.py (float16; weights and inputs re-drawn from the same seeds)."""
+    import numpy as np
+    from tests.golden import make_gpu_tier_goldens as G
+    gold = np.load(G.OUT)
+    ref = G.config1_weights()
     hip = MVUNetMotionModel(UNetConfig(), num_views=1, device="cuda")
     hip.load_state_dict(ref.state_dict(), strict=True)
+    del ref
     hip = hip.to(torch.bfloat16).eval()
-    inp = O.synthetic_inputs(ocfg, 1, 1, 4, (64, 64), seed=4)
-    y_ref = ref(**inp).sample
+    inp = G.config1_inputs()
+    assert abs(inp["sample"].double().sum().item() - float(gold["config1_in_checksum"])) < 1e-6, "inputs differ from the golden's"
+    y_ref = torch.from_numpy(gold["config1_sample"].astype(np.float32))
     y = hip(**_cuda(inp), ).sample
+    assert y.shape == y_ref.shape == (1, 4, 4, 64, 64)
     e, mx, sc = _rel(y, y_ref)
-    print(f"[parity] unet config-1 shape (1v x 4f x 64x64): rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e})")
+    print(f"[parity] unet config-1 shape (1v x 4f x 64x64) vs the oracle golden: rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e})")
     assert e <= 3e-2
 
 
@@ -305,6 +309,33 @@ def test_forward_is_hip_graph_capturable(models):
         torch.cuda.synchronize()
         y_eager = hip(**src).sample
         assert torch.equal(y_static, y_eager), "graph replay differs from the eager forward"
+
+
+def test_graph_capture_with_a_cu_reservation_active(models):
+    """The CU reservation of the sharded path (parallel.py: compute-units left free for an overlapped RCCL collective) is a
+    per-call argument of the C-ABI (``flags`` of a3d_gemm / a3d_conv3x3, include/animate3d_hip.h), held per op set — not process
+    state: a capture taken while a reservation is active bakes ITS grid sizes into the graph, and neither a later change of the
+    op set's value nor another op set in the same process can alter the replay.  The persistent kernels' results do not depend on
+    the number of workgroups, so every combination must be bit-identical."""
+    from animate3d_amd.hip_ops import HipOps
+    ocfg, ref, hip, _ = models
+    # 4 videos x 3 frames x 64x64 latent: 49 152 level-0 tokens = 192 row tiles, so the GEMMs and convolutions of levels 0 / 1 take
+    # the persistent kernels, whose grid is what the reservation shrinks (the 16x16 latent of the other tests never reaches them)
+    inp = _cuda(O.synthetic_inputs(ocfg, 2 * N_VIEWS, N_VIEWS, FRAMES, (64, 64), seed=23, cfg_doubled=True))
+    y_plain = hip(**inp).sample.clone()
+    other = HipOps()                                   # a second op set in the process keeps its own value
+    assert other.reserved_cus == 0 and hip.ops.reserved_cus == 0
+    hip.ops.reserved_cus = 24
+    try:
+        y_reserved = hip(**inp).sample.clone()
+        step = hip.capture_graph(**inp)
+        assert other.reserved_cus == 0
+    finally:
+        hip.ops.reserved_cus = 0
+    y_replay = step(**inp).sample
+    torch.cuda.synchronize()
+    assert torch.equal(y_reserved, y_plain), "result depends on the number of reserved CUs"
+    assert torch.equal(y_replay, y_plain), "graph captured under a reservation differs from the eager forward"
 
 
 def test_controlnet_residual_inputs_on_the_gpu():
