@@ -805,7 +805,8 @@ class MVUNetMotionModelRef(nn.Module):
             blk.attn1.set_processor(motion(c, hw, es))
             blk.attn2.set_processor(motion(c, hw, es))
             if not (cfg.motion_spatial_attn and (cfg.motion_use_spatial_encoding or cfg.motion_use_camera_encoding)):   # inference.py:176-178: pos_embed is kept
-                table = sinusoidal_pos_1d(c, cfg.motion_max_seq_length)
+                with torch.device("cpu"):                  # a constant captured by the closure, not a buffer: must be real under build_dense's meta construction
+                    table = sinusoidal_pos_1d(c, cfg.motion_max_seq_length)
                 blk.pos_embed = lambda t, table=table: t + table[:, : t.shape[1]].to(t)
 
         for i, blk in enumerate(self.down_blocks):
