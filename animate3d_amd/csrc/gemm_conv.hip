@@ -100,6 +100,12 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
   auto load_tile = [&](int64_t k0, RegTile& rt) {
     u32x4_t (&ra)[NPASS] = rt.a; u32x4_t (&rw)[NPASS] = rt.w;
     if constexpr (CONV != 0) {
+      {   // the persistent kernel's K walk (gemm_pp.hip): nine taps of one 64-channel slice, then the next slice; k0 becomes the
+          // column of W ([tap][Cin]) that the walk visits at linear position k0 — same accumulation order, bit-identical results
+        const int kt64 = (int)(k0 >> 6);
+        const int c64 = kt64 / 9, t = kt64 - 9 * c64;
+        k0 = (int64_t)t * p.Cin + c64 * 64 + (k0 & 63);
+      }
       const int tap = (int)(k0 / p.Cin);
       const int ci0 = (int)(k0 - (int64_t)tap * p.Cin);
       const int ky = tap / 3, kx = tap - ky * 3;

@@ -207,11 +207,17 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
     }
     if constexpr (B == NP) {
       if constexpr (CONV != 0) {
-        ici0 += 64;
-        if (ici0 >= p.Cin) { ici0 = 0; ++itap; }
+        // K walk of the implicit GEMM: all nine taps of one 64-channel slice, then the next slice (W rows are [tap][Cin]: a tap is
+        // Cin elements away).  Tap-major order touched a tile's whole input window (6 image rows x Cin) between two uses of the same
+        // line — ~5 MB per XCD at level 0, more than its L2; this order re-reads a 32 KB slice nine times in a row.  gemm_kernel walks
+        // the same order (conv_k0), so the two kernels stay bit-identical.
+        const uint64_t cin2 = (uint64_t)(uint32_t)p.Cin * 2u;
+        wk += cin2;
+        if (++itap == 9) { itap = 0; ici0 += 64; wk -= 9u * cin2 - 128u; }
+      } else {
+        xk += 128; wk += 128;
       }
       ik0 += 64;
-      xk += 128; wk += 128;
     }
   };
   // DMA share of phase ph of a K-tile; `late` = first K-tile of a tile (nothing in phase 0: the epilogue buffers; then five, then the rest)

@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  It carries
                  launch stream inside the timed region, against the dense bf16 MFMA peak; ``ceilings`` adds the second
                  ceiling that binds at head_dim 40 — the v_exp issue rate measured with tools/ubench_exp.hip — and ``traffic``
                  the HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (read from
-                 profiles/r3_flash_pmc_traffic.json; null when that file does not describe this kernel and launch shape);
+                 profiles/r4_flash_pmc_traffic.json, else round 3's; null when that file does not describe this kernel and launch shape);
   groups       — per kernel family (attention by head dim, GEMM, fused GEGLU GEMM, 3x3 conv, norms, ...): ms per step and
                  achieved TFLOP/s or GB/s, from one extra instrumented forward OUTSIDE the timed region;
   cpu_baseline — the CPU oracle (plain-PyTorch fp32 restatement of the reference forward; the reference itself cannot be
@@ -250,12 +250,13 @@ def cpu_baseline(threads, budget_s=150.0):
 
 def _pmc_traffic(S0, groups, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass, if it matches this kernel and launch shape."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r3_flash_pmc_traffic.json")))
-        if rec.get("kernel") == kernel and rec.get("kv_len") == S0 and rec.get("groups") == groups:
-            return rec
-    except Exception:
-        pass
+    for name in ("r4_flash_pmc_traffic.json", "r3_flash_pmc_traffic.json"):      # newest pass first; the kernel is unchanged since round 3
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if rec.get("kernel") == kernel and rec.get("kv_len") == S0 and rec.get("groups") == groups:
+                return rec
+        except Exception:
+            pass
     return None
 
 
