@@ -49,6 +49,12 @@ A3D_DEV uint32_t pack16(float lo, float hi) {
 A3D_DEV float lo16(uint32_t w) { return __uint_as_float(w << 16); }
 A3D_DEV float hi16(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 #endif
+// 16-byte accesses of the streaming (memory-bound) kernels — GroupNorm, LayerNorm, concat: tensors read or written once per launch
+// and larger than the caches (336 MB at level 0), marked non-temporal (global_load / global_store ... nt).  Measured against plain
+// accesses (profiles/r4_microbench_stream_variants.log): GroupNorm 0.220 -> 0.196 ms, two-output LayerNorm 0.254 -> 0.233 (with the
+// prefetch in layer_norm_rows_kernel), concat 0.40 -> 0.35-0.36; -1..-2 ms per denoise step.
+A3D_DEV u32x4_t ld_stream(const void* ptr) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ptr)); }
+A3D_DEV void st_stream(void* ptr, u32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(ptr)); }
 A3D_DEV uint16_t f2h(float f) { return (uint16_t)(pack16(f, 0.f) & 0xffffu); }
 // caller-side bf16 tensors at the boundary kernels (im2col_in / unpack_out): always bf16, whatever the storage type of the build
 A3D_DEV float bfbits2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

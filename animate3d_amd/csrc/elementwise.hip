@@ -63,7 +63,7 @@ __global__ void concat_kernel(const uint16_t* A, int64_t Ca8, const uint16_t* B,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / C8, c = i % C8;
     const uint16_t* src = (c < Ca8) ? A + (m * Ca8 + c) * 8 : B + (m * Cb8 + (c - Ca8)) * 8;
-    *reinterpret_cast<u32x4_t*>(Y + i * 8) = *reinterpret_cast<const u32x4_t*>(src);
+    st_stream(Y + i * 8, ld_stream(src));
   }
 }
 

@@ -39,11 +39,11 @@ __global__ void gn_partial_kernel(const GNParams p) {
   for (; r + 3 * ny < r1; r += 4 * ny) {          // four independent row loads in flight per thread, accumulated in row order
     u32x4_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (r + (int64_t)k * ny) * p.C);
+    for (int k = 0; k < 4; ++k) v[k] = ld_stream(base + (r + (int64_t)k * ny) * p.C);
 #pragma unroll
     for (int k = 0; k < 4; ++k) accum(v[k]);
   }
-  for (; r < r1; r += ny) accum(*reinterpret_cast<const u32x4_t*>(base + r * p.C));
+  for (; r < r1; r += ny) accum(ld_stream(base + r * p.C));
   float* mine = spart + ((size_t)ry * nx + c8) * 4;
   mine[0] = s_lo; mine[1] = q_lo; mine[2] = s_hi; mine[3] = q_hi;
   __syncthreads();
@@ -122,17 +122,17 @@ __global__ void gn_apply_kernel(const GNParams p) {
     u32x4_t o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = pack16(f[2 * j], f[2 * j + 1]);
-    *reinterpret_cast<u32x4_t*>(p.Y + off + r * p.C) = o;
+    st_stream(p.Y + off + r * p.C, o);
   };
   int64_t r = r0 + ry;
   for (; r + 3 * ny < r1; r += 4 * ny) {          // four independent row loads in flight per thread
     u32x4_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(p.X + off + (r + (int64_t)k * ny) * p.C);
+    for (int k = 0; k < 4; ++k) v[k] = ld_stream(p.X + off + (r + (int64_t)k * ny) * p.C);
 #pragma unroll
     for (int k = 0; k < 4; ++k) apply(v[k], r + (int64_t)k * ny);
   }
-  for (; r < r1; r += ny) apply(*reinterpret_cast<const u32x4_t*>(p.X + off + r * p.C), r);
+  for (; r < r1; r += ny) apply(ld_stream(p.X + off + r * p.C), r);
 }
 
 // ---------------- LayerNorm: one wave per row, up to 3 16-byte chunks per lane (C <= 1536)
@@ -239,15 +239,24 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) 
     be[i][0] = b0.x; be[i][1] = b0.y; be[i][2] = b0.z; be[i][3] = b0.w; be[i][4] = b1.x; be[i][5] = b1.y; be[i][6] = b1.z; be[i][7] = b1.w;
   }
   const float inv_c = 1.f / (float)p.C;
+  auto row_of = [&](int bt) { return (((int64_t)blockIdx.x * 4 + wid) * LN_BATCH + bt) * RPW + rsel; };
+  auto load_rows = [&](int bt, u32x4_t (&dst)[5]) {
+    const int64_t m = row_of(bt);
+    const uint16_t* xr = p.X + (m < p.M ? m : p.M - 1) * p.C;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dst[i] = ld_stream(xr + (sub + LPR * i) * 8);
+  };
+  u32x4_t nxt[5];
+  load_rows(0, nxt);
 #pragma unroll 1
   for (int bt = 0; bt < LN_BATCH; ++bt) {
-    const int64_t m = (((int64_t)blockIdx.x * 4 + wid) * LN_BATCH + bt) * RPW + rsel;
+    const int64_t m = row_of(bt);
     const bool ok = m < p.M;
     const int64_t mm = ok ? m : p.M - 1;
-    const uint16_t* xr = p.X + mm * p.C;
     u32x4_t raw[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) raw[i] = *reinterpret_cast<const u32x4_t*>(xr + (sub + LPR * i) * 8);
+    for (int i = 0; i < 5; ++i) raw[i] = nxt[i];
+    if (bt + 1 < LN_BATCH) load_rows(bt + 1, nxt);      // the next batch's rows are in flight under this batch's arithmetic and stores
     float f[5][8];
     float sum = 0.f;
 #pragma unroll
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) 
         u32x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = pack16(z[2 * j], z[2 * j + 1]);
-        if (ok) *reinterpret_cast<u32x4_t*>(p.Y1 + m * p.C + c * 8) = o;
+        if (ok) st_stream(p.Y1 + m * p.C + c * 8, o);
       }
       if (p.Y2) {
         float z[8];
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const LNParams p) 
         u32x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = pack16(z[2 * j], z[2 * j + 1]);
-        if (ok) *reinterpret_cast<u32x4_t*>(p.Y2 + m * p.C + c * 8) = o;
+        if (ok) st_stream(p.Y2 + m * p.C + c * 8, o);
       }
     }
   }
