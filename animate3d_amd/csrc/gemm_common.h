@@ -191,16 +191,9 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
             u32x2_t o;
             o[0] = pack16(y[4 * h], y[4 * h + 1]);
             o[1] = pack16(y[4 * h + 2], y[4 * h + 3]);
-#ifdef A3D_EXP_DIRECT_STORE
-            *reinterpret_cast<u32x2_t*>(p.Y + (mbase + l31) * p.ldy + nbase / 2 + 8 * (2 * q2 + h) + 4 * g) = o;
-#else
             *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + 16 * ((2 * q2 + h) ^ wsw) + whalf) = o;
-#endif
           }
         }
-#ifdef A3D_EXP_DIRECT_STORE
-        continue;       // experiment (profiles/README.md, round-5 candidates): 8-byte stores straight from the MFMA layout, no LDS transposition
-#endif
         wave_lds_fence();
         const int cc = lane & 3;
         const int64_t oc = nbase / 2 + 8 * cc;
@@ -238,17 +231,10 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
               u32x2_t o;
               o[0] = pack16(v[0], v[1]);
               o[1] = pack16(v[2], v[3]);
-#ifdef A3D_EXP_DIRECT_STORE
-              *reinterpret_cast<u32x2_t*>(p.Y + (mbase + l31) * p.ldy + nbase + c0) = o;
-#else
               *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + 16 * ((4 * tl + q) ^ wsw) + whalf) = o;
-#endif
             }
           }
         }
-#ifdef A3D_EXP_DIRECT_STORE
-        continue;
-#endif
         wave_lds_fence();
         const int lpr = ncol / 8;
         const int cc = lane & (lpr - 1);
