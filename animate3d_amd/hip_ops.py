@@ -311,14 +311,16 @@ class HipOps:
         _check(rc, f"a3d_flash_attn2_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len} kv_len2={kv_len2}")
         return o
 
-    def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int, *, q_f0: int = 0, q_frames: Optional[int] = None):
+    def temporal_attn(self, q, k, v, videos: int, frames: int, L: int, heads: int, *, q_f0: int = 0, q_frames: Optional[int] = None,
+                      out=None):
         """Unsharded: q / k / v rows ((v F + f) L + l).  Frame-sharded (``q_frames`` < ``frames``): q holds this rank's frames
         [q_f0, q_f0 + q_frames) only; k / v are the all-gathered tensors ``[frames / q_frames blocks, videos * q_frames * L, C]``."""
         q, k, v = self._act(q, "tattn.q"), self._act(k, "tattn.k"), self._act(v, "tattn.v")
         C = q.shape[1]
         D = C // heads
         assert k.stride(0) == v.stride(0)
-        o = self.empty(q.shape[0], C)
+        o = self._act(out, "tattn.out") if out is not None else self.empty(q.shape[0], C)
+        assert o.shape == (q.shape[0], C)
         if q_frames is None or q_frames == frames:
             assert q.stride(0) == k.stride(0)
             rc = self.lib.a3d_temporal_attn_bf16(self._stream(), _p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0),

@@ -413,6 +413,17 @@ class MVUNetMotionModel(nn.Module):
         w = self._d(conv.weight)
         return self._w(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
 
+    def _fold(self, a: torch.Tensor, b_t: torch.Tensor) -> torch.Tensor:
+        """fp32 ``a [M, K] @ b_t [N, K]^T`` on the HIP GEMM for pack-time weight folding: both operands are split into a 16-bit
+        head and a 16-bit remainder (three products, fp32 accumulation), so the folded weight carries ~16 significant bits
+        before it is rounded once to the storage type."""
+        ops = self._base_ops()
+        dt = ops.act_dtype
+        a, b_t = a.detach().float().contiguous(), b_t.detach().float().contiguous()
+        ah, bh = a.to(dt), b_t.to(dt)
+        al, bl = (a - ah.float()).to(dt), (b_t - bh.float()).to(dt)
+        return ops.gemm_f32out(ah, bh) + ops.gemm_f32out(ah, bl) + ops.gemm_f32out(al, bh)
+
     def _pack_resnet(self, r: M.ResnetBlock2D):
         return SimpleNamespace(
             n1=(self._f(r.norm1.weight), self._f(r.norm1.bias)), eps=r.norm1.eps,
@@ -456,6 +467,15 @@ class MVUNetMotionModel(nn.Module):
             ip_scale=list(p2.scale), ip_tokens=list(p2.num_tokens),
             o2=(self._w(a2.to_out[0].weight), self._f(a2.to_out[0].bias)),
             pout=(self._conv_w(t.proj_out), self._f(t.proj_out.bias)))
+        out.o1m = None
+        if i2v and not self._pack_grad:
+            # to_out[0](main + to_out_i2v(i2v)) as ONE GEMM over [main | i2v] (attention_processor.py:375-383, 433-436): the weight is
+            # [Wo | Wo Wi], the bias Wo b_i + b_o — one residual round trip instead of two HBM-bound N = K = C launches
+            wo, wi = a1.to_out[0].weight.detach().float(), p1.to_out_i2v.weight.detach().float()
+            bias = a1.to_out[0].bias.detach().float()
+            if p1.to_out_i2v.bias is not None:
+                bias = bias + self._fold(p1.to_out_i2v.bias.detach().float()[None, :], wo)[0]
+            out.o1m = (self._w(torch.cat([wo, self._fold(wo, wi.t())], dim=1)), self._f(bias))
         out.ff = self._pack_ff(tb)
         return out
 
@@ -493,6 +513,20 @@ class MVUNetMotionModel(nn.Module):
             if pr.use_image_attn:
                 ns.qkv_img = self._wcat([pr.to_k_i2v.weight, pr.to_v_i2v.weight, pr.to_q_i2v.weight])
                 ns.oimg = (self._w(pr.to_out_i2v.weight), self._f(pr.to_out_i2v.bias))
+            ns.om = None
+            if not self._pack_grad and (pr.use_spatial_attn or pr.use_image_attn):
+                # ct to_out(t) + cs to_out_sp(sp) + ci to_out_i2v(img) (attention_processor.py:639, 666, 698-713) as ONE GEMM over
+                # [t | sp | img] with the merge weights folded into [ct Wo | cs Wsp | ci Wimg]: one residual round trip instead of three
+                parts = [(ct, a.to_out[0])]
+                if pr.use_spatial_attn:
+                    parts.append((cs, pr.to_out_sp))
+                if pr.use_image_attn:
+                    parts.append((ci, pr.to_out_i2v))
+                bias = None
+                for c, lin in parts:
+                    if lin.bias is not None:
+                        bias = float(c) * lin.bias.detach().float() if bias is None else bias + float(c) * lin.bias.detach().float()
+                ns.om = (self._w(torch.cat([float(c) * lin.weight.detach().float() for c, lin in parts], dim=1)), self._f(bias))
             attns.append(ns)
         out = SimpleNamespace(norm=(self._f(m.norm.weight), self._f(m.norm.bias)),
                               pin=(self._w(m.proj_in.weight), self._f(m.proj_in.bias)),
@@ -606,14 +640,16 @@ class MVUNetMotionModel(nn.Module):
         k0 = RowMap(gdiv=F, ga=n * F * L, gb=0, seg_len=L, seg_stride=F * L)     # same, frame 0 of every b
         return qm, k0
 
-    def _mv_attention(self, x, w_kvq, C, V, n, F, L, heads, i2v, overlap=None):
+    def _mv_attention(self, x, w_kvq, C, V, n, F, L, heads, i2v, overlap=None, out_a=None, out_ai=None):
         """Multi-view attention over the n*L tokens of every (b, f) group (+ the first-frame branch).
         ``w_kvq`` rows are [K; V; Q; (Q_i2v)].  Unsharded: one fused GEMM, K/V/Q are column views.
         View-sharded (animate3d_amd.parallel): this rank holds n of the N views; K|V is projected
         into its own contiguous buffer, all-gathered over the view group (RCCL) and the kernels
         read the gathered K/V through the unsharded row map while Q stays local.  The gather is
         asynchronous: the Q projection and ``overlap()`` (independent work of the caller, e.g. the
-        temporal branch of a motion module) are issued while it is in flight.  Returns (a, a_i2v, overlap())."""
+        temporal branch of a motion module) are issued while it is in flight.  ``out_a`` / ``out_ai``: [rows, C] views (own row
+        stride) the two attention outputs are written to — the column blocks of a merged out-projection's A operand.
+        Returns (a, a_i2v, overlap())."""
         ops, par = self.ops, self.parallel
         if par is not None and par.world == 1:
             par = None
@@ -635,13 +671,15 @@ class MVUNetMotionModel(nn.Module):
         if not vsh:
             kvq = ops.gemm(x, w_kvq)
             k, v, q = kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C]
-            a = ops.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L)
+            oa = {} if out_a is None else {"out": out_a}
+            oi = {} if out_ai is None else {"out": out_ai}
+            a = ops.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L, **oa)
             ai = None
             if i2v and fsh:
                 kv0, km0 = first_frame_kv()
-                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, n * L)
+                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, n * L, **oi)
             elif i2v:
-                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L)
+                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L, **oi)
             return a, ai, (overlap() if overlap is not None else None)
         if par.gather_tokens:
             # gather the (normalised) INPUT tokens [rows_local, C] and project K|V for all N views locally: half the
@@ -658,13 +696,15 @@ class MVUNetMotionModel(nn.Module):
             kv_all = par.all_gather_views_finish(pending, b)  # [b * N*F*L, 2C] in unsharded (b n f) l order
         km, km0 = self._mv_maps(N, F, L)
         k, v = kv_all[:, :C], kv_all[:, C:]
-        a = ops.flash_attn(qq[:, :C], k, v, qm, km, b * F, heads, n * L, N * L)
+        oa = {} if out_a is None else {"out": out_a}
+        oi = {} if out_ai is None else {"out": out_ai}
+        a = ops.flash_attn(qq[:, :C], k, v, qm, km, b * F, heads, n * L, N * L, **oa)
         ai = None
         if i2v and fsh:
             kv0, km0 = first_frame_kv()
-            ai = ops.flash_attn(qq[:, C:2 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, N * L)
+            ai = ops.flash_attn(qq[:, C:2 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, N * L, **oi)
         elif i2v:
-            ai = ops.flash_attn(qq[:, C:2 * C], k, v, qm, km0, b * F, heads, n * L, N * L)
+            ai = ops.flash_attn(qq[:, C:2 * C], k, v, qm, km0, b * F, heads, n * L, N * L, **oi)
         return a, ai, extra
 
     def _t2d(self, x, V, n, F, H, W, pk, text_rows, ip_rows, T):
@@ -708,6 +748,11 @@ class MVUNetMotionModel(nn.Module):
         """MVDream(I2V) processor (attention_processor.py:39-126, 325-445) on normalised tokens ``n1``."""
         ops = self.ops
         C = n1.shape[1]
+        if pk.o1m is not None and self._active_ops is None:
+            # inference: both attention kernels write into the column halves of one [rows, 2C] buffer, one K = 2C out-projection
+            cat = ops.empty(n1.shape[0], 2 * C)
+            self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=True, out_a=cat[:, :C], out_ai=cat[:, C:])
+            return ops.gemm(cat, pk.o1m[0], pk.o1m[1], residual=residual)
         a, ai, _ = self._mv_attention(n1, pk.qkv, C, V, n, F, L, pk.heads, i2v=pk.i2v)
         if pk.i2v:
             a = ops.gemm(ai, pk.oi2v[0], pk.oi2v[1], residual=a)          # main + to_out_i2v(i2v)
@@ -724,25 +769,33 @@ class MVUNetMotionModel(nn.Module):
         par = self.parallel if (self.parallel is not None and self.parallel.world > 1) else None
         fsh = par is not None and par.frame_shards > 1
         F_all, f0 = self._frames
+        # inference: the branch kernels write the column blocks [t | sp | img] of ONE buffer and a single out-projection with the
+        # merge weights folded in (``a.om``) replaces the two / three residual-accumulating ones
+        merged = a.om is not None and self._active_ops is None
+        nblk = 1 + int(a.spatial) + int(a.image)
+        cat = ops.empty(nt.shape[0], nblk * C) if merged else None
+        blk = lambda i: {} if cat is None else {"out": cat[:, i * C:(i + 1) * C]}
 
         def temporal_branch(nt=nt, a=a):
             if not fsh:
                 qkv = ops.gemm(nt, a.qkv)
-                return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads)
+                return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads, **blk(0))
             # frame-sharded: every rank needs the keys / values of ALL frames of its pixels; queries stay local
             kv = ops.gemm(nt, a.qkv[C:])                      # [rows_local, 2C], contiguous
             pending = par.all_gather_frames_start(kv)
             q = ops.gemm(nt, a.qkv[:C])                       # overlaps the gather
             kv_all = par.all_gather_frames_finish(pending)    # [Sf, (v f_l) l, 2C], read in place
-            return ops.temporal_attn(q, kv_all[:, :C], kv_all[:, C:], V, F_all, L, a.heads, q_f0=f0, q_frames=F)
+            return ops.temporal_attn(q, kv_all[:, :C], kv_all[:, C:], V, F_all, L, a.heads, q_f0=f0, q_frames=F, **blk(0))
         if a.spatial:
             # the temporal branch is independent of the multi-view one: it runs while the K|V gather is in flight
-            asp, _, at = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False, overlap=temporal_branch)
+            asp, _, at = self._mv_attention(ns, a.qkv_sp, C, V, n, F, L, a.heads, i2v=False, overlap=temporal_branch,
+                                            out_a=None if cat is None else cat[:, C:2 * C])
         else:
             at = temporal_branch()
-        out = ops.gemm(at, a.o[0], a.o[1], residual=h, alpha=ct, beta=1.0)
-        if a.spatial:
-            out = ops.gemm(asp, a.osp[0], a.osp[1], residual=out, alpha=cs, beta=1.0)
+        if not merged:
+            out = ops.gemm(at, a.o[0], a.o[1], residual=h, alpha=ct, beta=1.0)
+            if a.spatial:
+                out = ops.gemm(asp, a.osp[0], a.osp[1], residual=out, alpha=cs, beta=1.0)
         if a.image:
             # per-view first-frame attention (:672-698): every image attends to frame 0 of its own video
             qm = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
@@ -750,12 +803,16 @@ class MVUNetMotionModel(nn.Module):
                 x0 = nimg.view(V, F, L, C)[:, 0].reshape(V * L, C) if par.frame_rank == 0 else None
                 kv0 = ops.gemm(par.broadcast_frame0(x0, (V * L, C), nimg.dtype, nimg.device), a.qkv_img[:2 * C])
                 qi = ops.gemm(nimg, a.qkv_img[2 * C:])
-                ai = ops.flash_attn(qi, kv0[:, :C], kv0[:, C:], qm, RowMap(gdiv=F, ga=L, gb=0, seg_len=L, seg_stride=0), V * F, a.heads, L, L)
+                ai = ops.flash_attn(qi, kv0[:, :C], kv0[:, C:], qm, RowMap(gdiv=F, ga=L, gb=0, seg_len=L, seg_stride=0), V * F, a.heads, L, L,
+                                    **blk(nblk - 1))
             else:
                 kvq = ops.gemm(nimg, a.qkv_img)
                 k0 = RowMap(gdiv=F, ga=F * L, gb=0, seg_len=L, seg_stride=0)
-                ai = ops.flash_attn(kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C], qm, k0, V * F, a.heads, L, L)
-            out = ops.gemm(ai, a.oimg[0], a.oimg[1], residual=out, alpha=ci, beta=1.0)
+                ai = ops.flash_attn(kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C], qm, k0, V * F, a.heads, L, L, **blk(nblk - 1))
+            if not merged:
+                out = ops.gemm(ai, a.oimg[0], a.oimg[1], residual=out, alpha=ci, beta=1.0)
+        if merged:
+            out = ops.gemm(cat, a.om[0], a.om[1], residual=h)
         return out
 
     def _motion(self, x, V, n, F, H, W, pk):

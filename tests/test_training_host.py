@@ -438,7 +438,9 @@ def test_staged_training_refreezing_a_module_drops_its_stale_frozen_pack():
     with torch.no_grad():
         y_eval = model(**inp).sample
     assert not torch.allclose(y_train, y0)                # the new weights are seen ...
-    torch.testing.assert_close(y_train.detach(), y_eval, rtol=1e-5, atol=1e-6)      # ... exactly as the re-packing inference path sees them
+    # ... as the re-packing inference path sees them (that path runs the merged out-projections of round 5 — [t | sp | img] x
+    # [ct Wo | cs Wsp | ci Wimg] in one fp32 sum — so the two agree to fp32 summation order, not bit for bit; stale weights are O(1) off)
+    torch.testing.assert_close(y_train.detach(), y_eval, rtol=1e-3, atol=1e-4)
 
 
 def test_trainable_merge_weights_are_read_back_once_per_forward(monkeypatch):

@@ -106,7 +106,7 @@ class TorchRefOps:
             res[flat] = self._o(o.reshape(-1, C))
         return res
 
-    def temporal_attn(self, q, k, v, videos, frames, L, heads, *, q_f0=0, q_frames=None):
+    def temporal_attn(self, q, k, v, videos, frames, L, heads, *, q_f0=0, q_frames=None, out=None):
         C = q.shape[1]
         D = C // heads
         fq = frames if q_frames is None else q_frames
@@ -120,6 +120,9 @@ class TorchRefOps:
             v = v.reshape(nb, videos, fq, L, C).permute(1, 0, 2, 3, 4).reshape(videos * frames * L, C)
         p = torch.softmax(seq(q, fq) @ seq(k, frames).transpose(-1, -2) * (D ** -0.5), dim=-1)
         o = (p @ seq(v, frames)).permute(0, 3, 1, 2, 4).reshape(videos * fq * L, C)
+        if out is not None:
+            out.copy_(self._o(o))
+            return out
         return self._o(o)
 
     def group_norm_sums(self, x, B, rows, groups):
