@@ -33,13 +33,37 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 class _GradSink:
     """fp32 gradient of a packed kernel weight, handed from the GEMM backward that computed it (``a3d_wgrad`` produces fp32) to ``PackW.backward``
     next to the 16-bit placeholder autograd carries between the two: no fp32 -> 16-bit -> fp32 round trip of every weight gradient."""
-    __slots__ = ("grad32",)
+    __slots__ = ("grad32", "announced")
 
     def __init__(self):
         self.grad32 = None
+        self.announced = False       # one placeholder per backward pass has been handed to autograd (see _weight_grad)
 
     def put(self, g: torch.Tensor) -> None:
         self.grad32 = g if self.grad32 is None else self.grad32 + g
+
+
+class _SinkRows:
+    """The sink of a row range of a packed weight (``weight_rows``): the consumer of ``w_kvq[:2 * C]`` deposits its fp32 gradient into
+    those rows of the parent's sink instead of sending a 16-bit gradient through autograd's slice backward."""
+    __slots__ = ("parent", "r0", "rows_total")
+
+    def __init__(self, parent, r0: int, rows_total: int):
+        self.parent, self.r0, self.rows_total = parent, r0, rows_total
+
+    @property
+    def announced(self):
+        return self.parent.announced
+
+    @announced.setter
+    def announced(self, v):
+        self.parent.announced = v
+
+    def put(self, g: torch.Tensor) -> None:
+        p = self.parent
+        if p.grad32 is None:
+            p.grad32 = torch.zeros((self.rows_total, *g.shape[1:]), dtype=torch.float32, device=g.device)
+        p.grad32[self.r0:self.r0 + g.shape[0]] += g
 
 
 _PLACEHOLDERS = {}
@@ -71,9 +95,11 @@ class PackW(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dw):
         g, ctx.sink.grad32 = ctx.sink.grad32, None
-        # a consumer of a SLICE / view of the packed operand (unet._mv_attention: w_kvq[:2 * C] for the first-frame K|V) has no sink and
-        # returns a real gradient through autograd; it arrives here summed with the sink consumers' stride-0 zero placeholders
-        real = dw is not None and not (dw.dim() > 0 and all(s_ == 0 for s_ in dw.stride()))
+        announced, ctx.sink.announced = ctx.sink.announced, False
+        # Sink consumers hand autograd exactly ONE stride-0 zero placeholder per backward pass (the first of them; the others return
+        # None — see _weight_grad), so ``dw`` is that placeholder alone, or a dense tensor that contains a real gradient: a consumer
+        # of a plain slice / view of the packed operand that went around the sink (``weight_rows`` gives slices a sink of their own).
+        real = dw is not None and not (announced and dw.dim() > 0 and all(s_ == 0 for s_ in dw.stride()))
         if g is None:
             g = dw.float()
         elif real:
@@ -109,8 +135,21 @@ def _weight_grad(ctx_sink, w, dw32: torch.Tensor) -> torch.Tensor:
     """What a GEMM backward returns for its weight operand: through the sink (fp32, no cast) when the operand came from ``pack_weight``."""
     if ctx_sink is not None:
         ctx_sink.put(dw32)
+        if ctx_sink.announced:          # autograd already holds this pass's placeholder: nothing more to sum into it
+            return None
+        ctx_sink.announced = True
         return _placeholder(w)
     return dw32.to(w.dtype)
+
+
+def weight_rows(w: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
+    """``w[r0:r1]`` of a packed kernel weight that keeps the fp32 gradient path: the slice carries a sink that deposits into rows
+    [r0, r1) of the parent's (plain slicing drops ``_a3d_sink``, and the consumer's weight gradient would travel and be summed in 16 bits)."""
+    v = w[r0:r1]
+    sink = getattr(w, "_a3d_sink", None)
+    if sink is not None:
+        v._a3d_sink = _SinkRows(sink, r0, w.shape[0])
+    return v
 
 
 class _Gemm(torch.autograd.Function):

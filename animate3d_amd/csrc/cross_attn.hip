@@ -189,9 +189,11 @@ __global__ __launch_bounds__(512, 2) void cross_attn40_kernel(const AttnParams p
 }  // namespace
 
 // returns A3D_EUNSUPPORTED when the shape is not this kernel's (the caller then takes the generic two-key-set kernel): head_dim 40,
-// <= 8 heads, <= 96 + 32 keys, each key set inside ONE row-map segment, no accumulation into O
+// <= 8 heads, <= 96 + 32 keys, each key set inside ONE row-map segment, no accumulation into O, O rows 16-byte aligned (the kernel
+// stores 16 bytes per lane at head offsets of 80 bytes: base and row pitch must both be multiples of 16 bytes — a3d_flash_attn2 itself only asks for 8)
 int A3D_FN(a3d_launch_cross_attn40)(int groups, hipStream_t s, const AttnParams& p) {
   if (p.heads > 8 || p.kv_len > 96 || p.kv_len2 > 32 || p.accumulate || p.lse) return A3D_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(p.O) & 15u) || (p.om.ld % 8) != 0) return A3D_EUNSUPPORTED;
   if (p.kv_len > p.km.seg_len || p.kv_len2 > p.km2.seg_len || p.q_len > p.qm.seg_len || p.q_len > p.om.seg_len || p.q_len < 256) return A3D_EUNSUPPORTED;
   // up to 1 024 queries per workgroup: the K / V^T register images are built once per workgroup (96 two-byte gathers per lane)
   int q_per_wg = p.q_len >= 2048 ? 1024 : (p.q_len >= 1024 ? 512 : 256);

@@ -19,6 +19,11 @@ struct GemmParams {
   // conv geometry (CONV only)
   int B, H, Wd, Cin, Ho, Wo, stride, up, He, We;   // He x We: extent of the (virtual) upsampled image of the up2x conv
   int64_t tiles_n, tiles_m;
+  // split-K of the persistent kernel (small M, long K: levels 2 / 3 leave most of the chip idle at one 256-row tile per item): the K-tiles
+  // are dealt to `ksplit` work items per output tile, each writes its fp32 accumulators to `ws` in register order, a second kernel adds
+  // the slices in index order and applies the epilogue arithmetic (splitk_reduce_kernel, gemm_pp.hip).  ksplit <= 1: off.
+  int ksplit, nk_item;   // K-tiles (64 wide) per work item
+  float* ws; int64_t ws_bytes;
 };
 
 constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;
@@ -102,6 +107,14 @@ A3D_DEV const uint16_t* scalar_ptr(const uint16_t* ptr) {
   return (const uint16_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
 }
+// LDS reads whose ISSUE position matters (software-pipelined operand fetches): volatile keeps instruction selection from sinking them next to
+// their use; the explicit LDS address space keeps them ds_read instructions (a volatile access through a generic pointer stays a flat load)
+A3D_DEV u32x4_t lds_vload128(const void* p) {
+  return *(const volatile __attribute__((address_space(3))) u32x4_t*)(uintptr_t)lds_addr(p);
+}
+A3D_DEV u32x2_t lds_vload64(const void* p) {
+  return *(const volatile __attribute__((address_space(3))) u32x2_t*)(uintptr_t)lds_addr(p);
+}
 A3D_DEV void wave_lds_fence() {          // orders this wave's LDS writes before its later LDS reads (LDS executes a wave's ops in order)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -165,23 +178,43 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
       r[0] = sw ? o[2] : o[0]; r[1] = sw ? o[3] : o[1]; r[2] = sw ? o[0] : o[2]; r[3] = sw ? o[1] : o[3];
       return r;
     };
+    // Round 5: the epilogue was LDS-LATENCY bound, not bandwidth bound: the compiler issued {broadcast read of a bias quad, s_waitcnt lgkmcnt(0),
+    // ~10 VALU, ds_write_b64} eight times per pass and {ds_read_b128, s_waitcnt, global_store} four times — twelve LDS round trips in series,
+    // 6 passes per tile = the ~8 k cycles the K = 320 ablations attribute to "the epilogue's own instruction stream" (profiles/README.md).
+    // Now (a) the bias / rowbias operands of quad i + 1 are requested before quad i is computed (8 more live registers: all the epilogue's
+    // first pass has to spare next to a 160-register accumulator), (b) a pass's transposed rows are read back in one batch before its stores,
+    // (c) consecutive passes alternate between two 4 KB staging buffers, so a pass's read-back / stores and the next pass's arithmetic overlap
+    // (one wave-level fence per pass instead of two).  Arithmetic and rounding per element are unchanged (bit-identical outputs).
+    constexpr int BUF2 = 32 * RS;                       // second staging buffer of this wave (2 x 4 KB <= its 8.5 KB region)
 #pragma unroll
     for (int pi = 0; pi < 2 * NP; ++pi) {
       const int tm = pi / NP, ps = pi % NP;
       const int ncol = pass_cols(ps);
       const int64_t mbase = m0 + wm * 64 + tm * 32;
       const int64_t nbase = n0 + pass_col0(ps);
+      char* const sb = stg16 + (pi & 1) * BUF2;
       if constexpr (EPI == EPI_GEGLU) {
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {                      // register quads 2 q2, 2 q2 + 1: columns 16 q2 + 4 g + {0..3} and + 8
-          float hv[8], gv[8], bh[8], bg[8], y[8];
+        // operands of one step (register quads 2 q2, 2 q2 + 1 of h and of the gate): four float4 broadcast reads
+        u32x4_t bq[2][4];
+        auto fetch = [&](int q2, int slot) __attribute__((always_inline)) {       // (the LDS bias image is zero-filled when there is no bias)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int c0 = 8 * (2 * q2 + h) + 4 * g;
-            const float4 b0 = p.bias ? *reinterpret_cast<const float4*>(bias_lds + pass_col0(ps) + c0) : float4{0.f, 0.f, 0.f, 0.f};
-            const float4 b1 = p.bias ? *reinterpret_cast<const float4*>(bias_lds + pass_col0(ps) + 32 + c0) : float4{0.f, 0.f, 0.f, 0.f};
-            bh[4 * h] = b0.x; bh[4 * h + 1] = b0.y; bh[4 * h + 2] = b0.z; bh[4 * h + 3] = b0.w;
-            bg[4 * h] = b1.x; bg[4 * h + 1] = b1.y; bg[4 * h + 2] = b1.z; bg[4 * h + 3] = b1.w;
+            bq[slot][2 * h] = lds_vload128(bias_lds + pass_col0(ps) + c0);      // volatile: see the linear epilogue below
+            bq[slot][2 * h + 1] = lds_vload128(bias_lds + pass_col0(ps) + 32 + c0);
+          }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {                      // register quads 2 q2, 2 q2 + 1: columns 16 q2 + 4 g + {0..3} and + 8
+          if (q2 + 1 < 2) fetch(q2 + 1, (q2 + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);                    // (the scheduler otherwise sinks the reads next to their use)
+          float hv[8], gv[8], bh[8], bg[8], y[8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x4_t b0 = bq[q2 & 1][2 * h], b1 = bq[q2 & 1][2 * h + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bh[4 * h + j] = __uint_as_float(b0[j]); bg[4 * h + j] = __uint_as_float(b1[j]); }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { hv[4 * h + j] = acc[2 * ps][tm][4 * (2 * q2 + h) + j]; gv[4 * h + j] = acc[2 * ps + 1][tm][4 * (2 * q2 + h) + j]; }
           }
@@ -191,17 +224,23 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
             u32x2_t o;
             o[0] = pack16(y[4 * h], y[4 * h + 1]);
             o[1] = pack16(y[4 * h + 2], y[4 * h + 3]);
-            *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + 16 * ((2 * q2 + h) ^ wsw) + whalf) = o;
+            *reinterpret_cast<u32x2_t*>(sb + l31 * RS + 16 * ((2 * q2 + h) ^ wsw) + whalf) = o;
           }
         }
         wave_lds_fence();
         const int cc = lane & 3;
         const int64_t oc = nbase / 2 + 8 * cc;
+        u32x4_t ob[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = 16 * j + (lane >> 2);
+          ob[j] = *reinterpret_cast<const u32x4_t*>(sb + row * RS + 16 * (cc ^ ((row >> 1) & 3)));
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int row = 16 * j + (lane >> 2);
           const int64_t m = mbase + row;
-          const u32x4_t o = unswap(*reinterpret_cast<const u32x4_t*>(stg16 + row * RS + 16 * (cc ^ ((row >> 1) & 3))), row);
+          const u32x4_t o = unswap(ob[j], row);
 #ifdef A3D_ABLATIONS
           if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
           *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + oc) = o;
@@ -210,40 +249,68 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
 #endif
         }
       } else {
+        constexpr int NQ = 8;                                   // quads of a 64-column pass (tl, q); a 32-column pass uses the first four
+        const int nq = (2 * ps + 1 < NB) ? 8 : 4;
+        u32x4_t bq[3];
+        u32x2_t tq[3];
+        auto fetch = [&](int idx, int slot) __attribute__((always_inline)) {
+          const int c0 = (idx >> 2) * 32 + 8 * (idx & 3) + 4 * g;   // column within the pass
+          // unconditional: the kernel zero-fills the LDS bias / rowbias images once when the launch has none (a branch per operand and
+          // quad made the compiler wait for the read it had just issued: s_waitcnt merges its counters at every join)
+          // volatile: these reads provably do not alias the staging stores, so nothing but the volatile ordering (against the
+          // sched_barrier below) keeps instruction selection from sinking them next to their use, one exposed LDS round trip per quad
+          bq[slot] = lds_vload128(bias_lds + pass_col0(ps) + c0);
+          tq[slot] = lds_vload64(rowbias_lds + pass_col0(ps) + c0);
+        };
+        // a launch with neither operand (the bias-free Q|K|V projections: the largest N of the step) skips the reads: they are broadcast
+        // ds_read_b128, 8 LDS cycles each whatever they deliver, and the LDS — shared by the eight waves that run the epilogue at the
+        // same time — is what the epilogue is bound by (round 5: pipelining the reads changed nothing, leaving them out is worth 3 %)
+        auto quads = [&](auto with_c) __attribute__((always_inline)) {
+          constexpr bool WITH = decltype(with_c)::value;
+          if constexpr (WITH) { fetch(0, 0); fetch(1, 1); }
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-          const int tn = 2 * ps + tl;
-          if (tn < NB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int c0 = tl * 32 + 8 * q + 4 * g;           // column within the pass
-              float v[4] = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
-              if (p.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(bias_lds + pass_col0(ps) + c0);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-              }
-              if (p.rowbias) {
-                const u32x2_t tb = *reinterpret_cast<const u32x2_t*>(rowbias_lds + pass_col0(ps) + c0);
-                v[0] += lo16(tb[0]); v[1] += hi16(tb[0]); v[2] += lo16(tb[1]); v[3] += hi16(tb[1]);
-              }
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = epi_scale(v[e], p.alpha);
-              u32x2_t o;
-              o[0] = pack16(v[0], v[1]);
-              o[1] = pack16(v[2], v[3]);
-              *reinterpret_cast<u32x2_t*>(stg16 + l31 * RS + 16 * ((4 * tl + q) ^ wsw) + whalf) = o;
+          for (int idx = 0; idx < NQ; ++idx) {
+            if (idx >= nq) continue;
+            const int tl = idx >> 2, q = idx & 3;
+            const int tn = 2 * ps + tl;
+            if constexpr (WITH) {
+              if (idx + 2 < nq) fetch(idx + 2, (idx + 2) % 3);      // two quads ahead: an LDS round trip is ~2 quads of arithmetic
+              __builtin_amdgcn_sched_barrier(0);                    // (the scheduler otherwise sinks the reads next to their use)
             }
+            float v[4] = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+            if constexpr (WITH) {
+              const u32x4_t b = bq[idx % 3];
+              v[0] += __uint_as_float(b[0]); v[1] += __uint_as_float(b[1]); v[2] += __uint_as_float(b[2]); v[3] += __uint_as_float(b[3]);
+              const u32x2_t tb = tq[idx % 3];
+              v[0] += lo16(tb[0]); v[1] += hi16(tb[0]); v[2] += lo16(tb[1]); v[3] += hi16(tb[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = epi_scale(v[e], p.alpha);
+            u32x2_t o;
+            o[0] = pack16(v[0], v[1]);
+            o[1] = pack16(v[2], v[3]);
+            *reinterpret_cast<u32x2_t*>(sb + l31 * RS + 16 * ((4 * tl + q) ^ wsw) + whalf) = o;
+            if constexpr (WITH) __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        };
+        if (p.bias || p.rowbias) quads(std::true_type{});
+        else quads(std::false_type{});
         wave_lds_fence();
         const int lpr = ncol / 8;
         const int cc = lane & (lpr - 1);
+        u32x4_t ob[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j * (64 / lpr) >= 32) continue;
+          const int row = (64 / lpr) * j + lane / lpr;
+          ob[j] = *reinterpret_cast<const u32x4_t*>(sb + row * RS + 16 * (cc ^ (row & 7)));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j * (64 / lpr) >= 32) continue;
           const int row = (64 / lpr) * j + lane / lpr;
           const int64_t m = mbase + row;
-          const u32x4_t o = unswap(*reinterpret_cast<const u32x4_t*>(stg16 + row * RS + 16 * (cc ^ (row & 7))), row);
+          const u32x4_t o = unswap(ob[j], row);
 #ifdef A3D_ABLATIONS
           if (p.abl & 2) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); continue; }
           *reinterpret_cast<u32x4_t*>(p.Y + ((p.abl & 1) ? (m & 255) : m) * p.ldy + nbase + 8 * cc) = o;
@@ -252,7 +319,7 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
 #endif
         }
       }
-      wave_lds_fence();
+      // (no second fence: the next pass writes the OTHER staging buffer; the one after next is separated from this pass's reads by that pass's fence)
     }
     return;
   }
@@ -285,7 +352,7 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
       {
         const float* bl = bias_lds + (pass_col0(ps) + 8 * cc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bh[e] = p.bias ? bl[e] : 0.f; bg[e] = p.bias ? bl[32 + e] : 0.f; }
+        for (int e = 0; e < 8; ++e) { bh[e] = bl[e]; bg[e] = bl[32 + e]; }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -316,9 +383,8 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
       const int ncl = pass_col0(ps) + 8 * cc;                   // column within the tile
       float bv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = p.bias ? bias_lds[ncl + e] : 0.f;
-      u32x4_t tb = {0u, 0u, 0u, 0u};
-      if (p.rowbias) tb = *reinterpret_cast<const u32x4_t*>(rowbias_lds + ncl);
+      for (int e = 0; e < 8; ++e) bv[e] = bias_lds[ncl + e];          // (zero-filled images when the launch has no bias / rowbias)
+      const u32x4_t tb = *reinterpret_cast<const u32x4_t*>(rowbias_lds + ncl);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j * (64 / lpr) >= 32) continue;                    // 32-column pass: two row groups of 16
@@ -329,10 +395,8 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
         float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        if (p.rowbias) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] += lo16(tb[e]); v[2 * e + 1] += hi16(tb[e]); }
-        }
+        for (int e = 0; e < 4; ++e) { v[2 * e] += lo16(tb[e]); v[2 * e + 1] += hi16(tb[e]); }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = epi_scale(v[e], p.alpha);
         if constexpr (RES) {

@@ -354,41 +354,71 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_kernel(const Ge
 constexpr int PBM = 256;
 constexpr int PERSIST_MIN_FILL = 50;     // minimum average CU fill (per cent) of the persistent grid's rounds: at 50 % (level 3, 128 tiles)
                                          // it still ties or beats the 128x128 kernel by 3-10 % (profiles/README.md, round 1)
+// Tile width and split-K factor of a persistent launch.  Returns false when the shape is not the persistent kernel's.  Cost model of one
+// candidate (nb, S): rounds of the grid x (K-tiles per item + a fixed ~12 K-tiles of epilogue / turn-around) x tile width; S > 1 (only with
+// a workspace, EPI_LINEAR, 16-bit output) must beat S = 1 by 15 % and leave >= 9 K-tiles per item, conv items hold whole 64-channel slices.
+struct PPPlan { int nb, S, cus; int64_t tiles_m, tiles_n; };
+constexpr int SPLITK_MAX = 16;
 template <int CONV, int EPI>
-int try_launch_persist(hipStream_t stream, GemmParams& p, int flags) {
-  if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || p.out_f32) return -1000;
+bool plan_persist(const GemmParams& p, int flags, bool allow_split, PPPlan& out) {
+  if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || p.out_f32) return false;
   static int cus_of[64] = {0};
   const int dev = a3d_current_device();
   if (cus_of[dev] == 0) {
     int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     cus_of[dev] = n > 0 ? n : 256;
   }
   // the persistent grid leaves the caller's reserved CUs free (the sharded path while an RCCL all-gather is in flight: its
   // kernels need CUs of their own to overlap with the GEMMs; animate3d_amd/parallel.py)
   const int reserved = a3d_gemm_reserved_cus_of(flags);
   const int cus = cus_of[dev] - reserved > 32 ? cus_of[dev] - reserved : 32;
-  if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return -1000;
-  int nb = (EPI == EPI_GEGLU) ? (p.N % 256 == 0 ? 4 : 0) : (p.N % 320 == 0 ? 5 : (p.N % 256 == 0 ? 4 : 0));
-  if (nb == 0) return -1000;
-  if (nb == 5 && p.N % 256 == 0) {
-    // both tile widths divide N (1280, 2560, 3840 ...): the 256 x 320 tile stages fewer operand bytes per FLOP and is the default, but when
-    // the grid is only a round or two (level 3: M = 8192) the narrower tile can fill more CUs — compare rounds x tile width
-    const int64_t tm = (p.M + PBM - 1) / PBM;
-    const int64_t cost5 = ((tm * (p.N / 320) + cus - 1) / cus) * 5, cost4 = ((tm * (p.N / 256) + cus - 1) / cus) * 4;
-    if (cost4 * 108 < cost5 * 100) nb = 4;
-  }
+  if (!p.vec16 || p.K % 64 != 0 || p.M % PBM != 0 || (p.rowbias && p.rb_div % PBM != 0)) return false;
   // 32-bit DMA offsets
-  if (p.ldw % 64 != 0 || (CONV == 0 && p.ldx % 64 != 0)) return -1000;
-  if (CONV == 0 && (uint64_t)p.ldx * 16u >= (1ull << 31)) return -1000;
-  if ((uint64_t)p.ldw * 16u >= (1ull << 31)) return -1000;
-  if (CONV != 0 && ((uint64_t)p.B * p.H * p.Wd + 2u * p.Wd + 2u) * (uint64_t)p.Cin * 2u >= (1ull << 32)) return -1000;
-  const int64_t tiles_m = (p.M + PBM - 1) / PBM, tiles_n = p.N / (nb * 64);
-  const int64_t ntiles = tiles_m * tiles_n;
-  const int64_t rounds = (ntiles + cus - 1) / cus;
-  if (ntiles * 100 < rounds * cus * PERSIST_MIN_FILL) return -1000;                  // average fill of the rounds (per cent)
-  p.tiles_m = tiles_m; p.tiles_n = tiles_n;
-  return A3D_FN(a3d_launch_gemm_pp)(CONV, EPI, nb, stream, p, cus);
+  if (p.ldw % 64 != 0 || (CONV == 0 && p.ldx % 64 != 0)) return false;
+  if (CONV == 0 && (uint64_t)p.ldx * 16u >= (1ull << 31)) return false;
+  if ((uint64_t)p.ldw * 16u >= (1ull << 31)) return false;
+  if (CONV != 0 && ((uint64_t)p.B * p.H * p.Wd + 2u * p.Wd + 2u) * (uint64_t)p.Cin * 2u >= (1ull << 32)) return false;
+  const int64_t tm = (p.M + PBM - 1) / PBM;
+  const int nk = (int)(p.K / 64);
+  const int unit = CONV ? 9 : 1;                       // K-tiles an item may be cut at
+  // the PLAN is made for the whole chip whatever the caller reserves: the split factor fixes the order of the K sum, and a launch's result must
+  // not depend on how many CUs an in-flight all-gather was given (a smaller grid walks the same work items; tests/test_unet_gpu.py)
+  const int cus_plan = cus_of[dev];
+  constexpr int OVH = 12;
+  int64_t best = -1, best1 = -1;
+  int bnb = 0, bS = 1, bnb1 = 0;
+  for (int nb = 5; nb >= 4; --nb) {
+    if (EPI == EPI_GEGLU && nb == 5) continue;                  // (h | gate pairs: 64-column blocks)
+    if (p.N % (nb * 64) != 0) continue;
+    const int64_t tiles = tm * (p.N / (nb * 64));
+    for (int S = 1; S <= (allow_split && EPI == EPI_LINEAR ? SPLITK_MAX : 1); ++S) {
+      if ((nk / unit) % S != 0 || (S > 1 && nk / S < 9)) continue;
+      const int64_t items = tiles * S;
+      const int64_t rounds = (items + cus_plan - 1) / cus_plan;
+      if (items * 100 < rounds * cus_plan * PERSIST_MIN_FILL) continue;             // average fill of the rounds (per cent)
+      if (S > 1 && p.ws != nullptr && items * nb * 65536 > p.ws_bytes) continue;    // (workspace too small for this factor)
+      // both tile widths divide N (1280, 2560, 3840 ...): the 256 x 320 tile stages fewer operand bytes per FLOP and is the default (8 % handicap
+      // for the narrower one), but when the grid is only a round or two (level 3: M = 8192) the narrower tile can fill more CUs
+      const int64_t cost = rounds * (nk / S + OVH) * nb * (nb == 4 ? 108 : 100) + (S > 1 ? 100 * nb : 0);
+      if (S == 1 && (best1 < 0 || cost < best1)) { best1 = cost; bnb1 = nb; }
+      if (best < 0 || cost < best) { best = cost; bnb = nb; bS = S; }
+    }
+  }
+  if (best < 0) return false;
+  if (bS > 1 && best1 >= 0 && best * 100 > best1 * 85) { bnb = bnb1; bS = 1; }      // split-K has to be worth its reduce pass
+  out.nb = bnb; out.S = bS; out.cus = cus;
+  out.tiles_m = tm; out.tiles_n = p.N / (bnb * 64);
+  return true;
+}
+
+template <int CONV, int EPI>
+int try_launch_persist(hipStream_t stream, GemmParams& p, int flags) {
+  PPPlan pl;
+  if (!plan_persist<CONV, EPI>(p, flags, p.ws != nullptr, pl)) return -1000;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+  p.ksplit = pl.S; p.nk_item = (int)(p.K / 64) / pl.S;
+  return A3D_FN(a3d_launch_gemm_pp)(CONV, EPI, pl.nb, stream, p, pl.cus);
 }
 
 
@@ -434,9 +464,23 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int A3D_FN(a3d_gemm)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
-                             const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
-                             void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags) {
+namespace {
+// workspace query of the *_ws entry points: the bytes a split-K launch of this call would use (0: the call does not split)
+template <int CONV>
+int64_t splitk_ws_bytes(const GemmParams& p, int flags) {
+  PPPlan pl;
+  GemmParams q = p;
+  q.ws = nullptr; q.ws_bytes = 0;
+  if (flags & ~(A3D_GEMM_RESERVED_CUS_MASK | A3D_GEMM_KERNEL_MASK)) return 0;
+  if (!plan_persist<CONV, EPI_LINEAR>(q, flags, true, pl) || pl.S <= 1) return 0;
+  return pl.tiles_m * pl.tiles_n * pl.S * pl.nb * 65536;
+}
+}  // namespace
+
+static int gemm_entry(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                      const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                      void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags,
+                      void* ws, int64_t ws_bytes, int64_t* ws_needed) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;
   if (K % 64 != 0 || N % 4 != 0) return A3D_EINVAL;
   if (ldx % 8 != 0 || ldw % 8 != 0 || ldy % 4 != 0 || (R && ldr % 4 != 0)) return A3D_EINVAL;
@@ -450,7 +494,22 @@ extern "C" int A3D_FN(a3d_gemm)(a3d_stream_t stream, const void* X, int64_t ldx,
   p.R = (const uint16_t*)R; p.ldr = ldr; p.Y = (uint16_t*)Y; p.ldy = ldy;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
   p.vec16 = (ldy % 8 == 0) && aligned16(Y) && (!R || (ldr % 8 == 0 && aligned16(R))) && (!rowbias || (N % 8 == 0 && aligned16(rowbias)));
+  if (ws_needed) { *ws_needed = splitk_ws_bytes<0>(p, flags); return 0; }
+  if (ws && ws_bytes > 0 && aligned16(ws)) { p.ws = (float*)ws; p.ws_bytes = ws_bytes; }
   return launch<0>((hipStream_t)stream, p, flags);
+}
+
+extern "C" int A3D_FN(a3d_gemm)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                             const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                             void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags) {
+  return gemm_entry(stream, X, ldx, W, ldw, bias, rowbias, rb_div, R, ldr, Y, ldy, M, N, K, alpha, beta, flags, nullptr, 0, nullptr);
+}
+
+extern "C" int A3D_FN(a3d_gemm_ws)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                                const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                                void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags,
+                                void* ws, int64_t ws_bytes, int64_t* ws_needed) {
+  return gemm_entry(stream, X, ldx, W, ldw, bias, rowbias, rb_div, R, ldr, Y, ldy, M, N, K, alpha, beta, flags, ws, ws_bytes, ws_needed);
 }
 
 extern "C" int A3D_FN(a3d_gemm_f32out)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
@@ -466,9 +525,10 @@ extern "C" int A3D_FN(a3d_gemm_f32out)(a3d_stream_t stream, const void* X, int64
   return launch<0>((hipStream_t)stream, p, 0);
 }
 
-extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
-                                const void* rowbias, int64_t rb_div, const void* R, void* Y,
-                                int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags) {
+static int conv_entry(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                      const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                      int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags,
+                      void* ws, int64_t ws_bytes, int64_t* ws_needed) {
   if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0) return A3D_EINVAL;
   if (Cin % 64 != 0 || Cout % 4 != 0 || (stride != 1 && stride != 2)) return A3D_EINVAL;
   if (up2x < 0 || up2x > 7 || (up2x > 1 && !(up2x & 1)) || (up2x && stride != 1)) return A3D_EINVAL;
@@ -488,7 +548,22 @@ extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const voi
   p.M = (int64_t)B * p.Ho * p.Wo; p.N = Cout; p.K = (int64_t)9 * Cin;
   p.alpha = 1.f; p.beta = 1.f;
   p.vec16 = (Cout % 8 == 0) && aligned16(Y) && (!R || aligned16(R)) && (!rowbias || aligned16(rowbias));
+  if (ws_needed) { *ws_needed = up2x ? splitk_ws_bytes<2>(p, flags) : splitk_ws_bytes<1>(p, flags); return 0; }
+  if (ws && ws_bytes > 0 && aligned16(ws)) { p.ws = (float*)ws; p.ws_bytes = ws_bytes; }
   return up2x ? launch<2>((hipStream_t)stream, p, flags) : launch<1>((hipStream_t)stream, p, flags);
+}
+
+extern "C" int A3D_FN(a3d_conv3x3)(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                                const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                                int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags) {
+  return conv_entry(stream, X, Wp, bias, rowbias, rb_div, R, Y, B, H, W, Cin, Cout, stride, up2x, flags, nullptr, 0, nullptr);
+}
+
+extern "C" int A3D_FN(a3d_conv3x3_ws)(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                                   const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                                   int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags,
+                                   void* ws, int64_t ws_bytes, int64_t* ws_needed) {
+  return conv_entry(stream, X, Wp, bias, rowbias, rb_div, R, Y, B, H, W, Cin, Cout, stride, up2x, flags, ws, ws_bytes, ws_needed);
 }
 
 extern "C" int A3D_FN(a3d_gemm_geglu)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,

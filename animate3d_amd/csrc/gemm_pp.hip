@@ -72,7 +72,9 @@ A3D_DEV void pp_barrier() {
 // Four phases (k-steps of 16) per K-tile; the 4 + NB DMA pieces a wave issues per K-tile go three per phase into phases 0-2 (measured
 // against five-then-the-rest and against two k-steps per phase: profiles/r4_microbench_pp.log).
 // CONV: 0 = dense A, 1 = 3x3 conv gather (pad 1, stride 1|2), 2 = 3x3 conv over a nearest-2x upsampled input
-template <int CONV, int EPI, int NB, bool RES>
+// SPLIT: split-K work items (GemmParams::ksplit > 1) — a separate instantiation: the item bookkeeping and the fp32 partial stores cost the
+// unsplit kernels registers they do not have (the conv instantiations sit at 256)
+template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   using PC = PPCfg<NB>;
   constexpr int PH = 1, NPH = 4;              // k-steps per phase, phases per K-tile
@@ -87,11 +89,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   const int lr = lane >> 3, pos = lane & 7;
   const uint32_t lds0 = lds_addr(smem);
 
-  const int64_t ntiles = p.tiles_m * p.tiles_n;
+  // work items: one per output tile, or (split-K) `ksplit` consecutive items per tile, item s of a tile contracting K-tiles [s nk, (s + 1) nk)
+  const int S = SPLIT ? p.ksplit : 1;
+  const int64_t ntiles = p.tiles_m * p.tiles_n * S;
   const int64_t G = gridDim.x;
   int64_t t = xcd_remap(blockIdx.x, G);
   if (t >= ntiles) return;
-  const int nk = (int)(p.K / 64);
+  const int nk = SPLIT ? p.nk_item : (int)(p.K / 64);
 
   const uint32_t koff0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
   const uint32_t xrd = (uint32_t)(wm * 64 + l31) * 128u;
@@ -104,10 +108,26 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   const uint32_t vw0 = (uint32_t)(lr * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4));
   uint32_t aoff[CONV ? 4 : 1];
   uint32_t amask[CONV ? 2 : 1];
+  // scalar copies of the tap masks: bit set <=> ALL 8 pixels of the piece are inside the image for that tap.  Such a (piece, tap) — 90 % of them
+  // at 64 x 64, 80 % at 32 x 32 — is one saddr + 32-bit-offset DMA like a dense piece; only pieces that touch the border select between
+  // the image and the zero page per lane (7 VALU instructions each: the conv's L section carried 46 more VALU instructions per K-tile than
+  // the dense kernel's, profiles/r5_conv_pmc.md)
+  uint32_t sok[CONV ? 2 : 1];
   const int64_t cbias = CONV ? ((int64_t)p.Wd + 1) * p.Cin : 0;
   int64_t ld_m0 = 0, ld_n0 = 0;
   int ld_par = 0;
-  int ik0 = 0, itap = 0, ici0 = 0;
+  int ik0 = 0, itap = 0, ikx = 0, iky = 0;
+  // 3x3 conv: byte address of (tap, channel slice) of the K-tile requested next relative to a lane's tap-(0,0) offset aoff[], advanced
+  // incrementally with the K walk (round 5: recomputing it from (tap / 3, tap % 3, slice) in each of the three DMA phases of a K-tile
+  // was ~17 dependent SALU instructions per phase, and the zero page's address came back through the GOT — s_getpc + s_load_dwordx2 +
+  // s_waitcnt lgkmcnt(0) BEHIND the phase's fragment reads — three times per K-tile: the L section was longer than the M section
+  // it hides under).  The zero page's address is pinned in a scalar pair once per kernel.
+  uint64_t xck = 0;
+  uint64_t zpage = 0;
+  if constexpr (CONV != 0) {
+    zpage = (uint64_t)(uintptr_t)g_zero_page;
+    asm volatile("" : "+s"(zpage));
+  }
   // Scalar DMA bases of this wave's first X / W piece for the K-tile requested next, advanced by 128 bytes per K-tile; the other
   // pieces are a 32-bit offset away (i * 8 rows).  (Recomputing (row0 + 8 pc) * ld + k0 per piece cost ~20 dependent SALU
   // instructions per piece — 180 per wave and K-tile — in front of the first MFMA of every K-tile.)
@@ -115,12 +135,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   const uint32_t sx8 = (uint32_t)(p.ldx * 16), sw8 = (uint32_t)(p.ldw * 16);      // bytes between two pieces (8 rows)
   auto setup_tile = [&](int64_t tt) {
     int64_t tile_n, tile_m;
-    pp_tile_coords(tt, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int64_t tile_id = SPLIT ? (int64_t)((uint32_t)tt / (uint32_t)S) : tt;
+    // K offset of this item in elements of a row of X / W (conv: whole 64-channel slices = 9 K-tiles each, the launcher makes nk a multiple of 9)
+    const int64_t kofs = SPLIT ? (CONV ? ((int64_t)(tt - tile_id * S) * nk / 9) * 64 : (int64_t)(tt - tile_id * S) * nk * 64) : 0;
+    pp_tile_coords(tile_id, p.tiles_m, p.tiles_n, tile_m, tile_n);
     ld_m0 = tile_m * PBM; ld_n0 = tile_n * PC::BN;
-    ik0 = 0; itap = 0; ici0 = 0;
+    ik0 = 0; itap = 0; ikx = 0; iky = 0;
     ld_par ^= 1;
-    if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx);
-    wk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw);
+    if constexpr (CONV != 0) xck = (uint64_t)(uintptr_t)p.X - (uint64_t)cbias * 2u + (uint64_t)kofs * 2u;
+    if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx + kofs);
+    wk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw + kofs);
     if (EPI == EPI_LINEAR && p.rowbias) rbk = (uint64_t)(uintptr_t)(p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0);
     if constexpr (CONV != 0) {
       amask[0] = 0; amask[1] = 0;
@@ -128,11 +152,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
       for (int i = 0; i < 4; ++i) {
         const int r = (wid * 4 + i) * 8 + lr;
         const int slot = pos ^ ((r >> 1) & 7);
-        const int64_t m = ld_m0 + r;
-        const int hw = p.Ho * p.Wo;
+        // 32-bit divisions: the launcher admits conv inputs below 4 GB only (32-bit DMA offsets), so M < 2^25
+        const uint32_t m = (uint32_t)ld_m0 + (uint32_t)r;
+        const uint32_t hw = (uint32_t)(p.Ho * p.Wo);
         const int b = (int)(m / hw);
-        const int rem = (int)(m - (int64_t)b * hw);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int rem = (int)(m - (uint32_t)b * hw);
+        const int oy = (int)((uint32_t)rem / (uint32_t)p.Wo), ox = rem - oy * p.Wo;
         uint32_t mask = 0;
         if constexpr (CONV == 2) {
           const int sy0 = (oy - 1) >> 1, sx0 = (ox - 1) >> 1;
@@ -154,9 +179,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
           amask[i >> 1] |= mask << (9 * (i & 1));
         }
       }
+      sok[0] = 0; sok[1] = 0;
+#pragma unroll
+      for (int bit = 0; bit < 18; ++bit) {
+        if (__builtin_amdgcn_ballot_w64(((amask[0] >> bit) & 1u) != 0u) == ~0ull) sok[0] |= 1u << bit;
+        if (__builtin_amdgcn_ballot_w64(((amask[1] >> bit) & 1u) != 0u) == ~0ull) sok[1] |= 1u << bit;
+      }
     }
   };
-  // DMA pieces [A, B) of the K-tile at the running position (ik0 / itap / ici0) into stage buf; the position moves on with the last piece
+  // DMA pieces [A, B) of the K-tile at the running position (ik0 / itap / xck) into stage buf; the position moves on with the last piece
   auto issue_pieces = [&](int buf, auto a_c, auto b_c) __attribute__((always_inline)) {
     constexpr int A = decltype(a_c)::value, B = decltype(b_c)::value;
     if constexpr (A >= B) return;
@@ -174,8 +205,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
       }
     }
     if constexpr (CONV != 0) {
-      const int ky = itap / 3, kx = itap - ky * 3;
-      const uint16_t* xb = CONV == 2 ? p.X + (ici0 - cbias) : p.X + ((int64_t)(ky * p.Wd + kx) * p.Cin + ici0 - cbias);
+      const int ky = iky, kx = ikx;
       const uint32_t rowb = (uint32_t)(p.Wd * p.Cin * 2), colb = (uint32_t)(p.Cin * 2);
       const uint32_t yE = (uint32_t)((ky + 1) >> 1) * rowb, yO = (uint32_t)(ky >> 1) * rowb;
       const uint32_t xE = (uint32_t)((kx + 1) >> 1) * colb, xO = (uint32_t)(kx >> 1) * colb;
@@ -186,10 +216,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         const uint32_t mk = amask[i >> 1];
         uint32_t vo = aoff[i];
         if constexpr (CONV == 2) vo += (((mk >> (18 + 2 * (i & 1))) & 1u) ? yE : yO) + (((mk >> (19 + 2 * (i & 1))) & 1u) ? xE : xO);
-        // one DMA instruction per piece with per-lane 64-bit sources: in-image taps read X, the others the zero page (the two exec-masked
-        // instructions of the lockstep kernel cost two branches per piece in the L section)
-        const uint64_t src = ((mk >> (itap + 9 * (i & 1))) & 1u) ? (uint64_t)(uintptr_t)xb + vo : (uint64_t)(uintptr_t)g_zero_page;
-        glds16_v((const void*)(uintptr_t)src, d);
+        const int bit = itap + 9 * (i & 1);
+        if ((sok[i >> 1] >> bit) & 1u) {
+          glds16_s(vo, (const void*)(uintptr_t)xck, d);          // whole piece inside the image: scalar base + per-lane 32-bit offset
+        } else {
+          // one DMA instruction with per-lane 64-bit sources: in-image taps read X, the others the zero page (the two exec-masked
+          // instructions of the lockstep kernel cost two branches per piece in the L section)
+          const uint64_t src = ((mk >> bit) & 1u) ? xck + vo : zpage;
+          glds16_v((const void*)(uintptr_t)src, d);
+        }
       }
     } else {
 #pragma unroll
@@ -213,7 +248,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         // the same order (conv_k0), so the two kernels stay bit-identical.
         const uint64_t cin2 = (uint64_t)(uint32_t)p.Cin * 2u;
         wk += cin2;
-        if (++itap == 9) { itap = 0; ici0 += 64; wk -= 9u * cin2 - 128u; }
+        ++itap;
+        if (++ikx == 3) { ikx = 0; ++iky; }
+        if (itap == 9) {                                  // next 64-channel slice, back to tap (0, 0)
+          itap = 0; iky = 0; wk -= 9u * cin2 - 128u;
+          if constexpr (CONV == 1) xck -= (2u * (uint64_t)(uint32_t)p.Wd + 2u) * cin2;
+          xck += 128u;
+        } else if constexpr (CONV == 1) {
+          xck += ikx == 0 ? ((uint64_t)(uint32_t)p.Wd - 2u) * cin2 : cin2;
+        }
       } else {
         xk += 128; wk += 128;
       }
@@ -263,6 +306,17 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma32(fw[s][tn], fx[s][tm], acc[tn][tm]);
   };
 
+  // the epilogue reads the per-tile bias (fp32) and rowbias (16-bit) images from LDS unconditionally: a launch without one of them
+  // zero-fills both parities of the image once (+0.0 is what the 128 x 128 kernel adds for an absent bias, too)
+  if (!p.bias || !(EPI == EPI_LINEAR && p.rowbias)) {
+    uint32_t* const bz = reinterpret_cast<uint32_t*>(smem_b + PC::BIAS_OFF);
+    for (int i = tid; i < 2 * PC::BIAS_STRIDE / 4; i += 512) {
+      const int o = (i * 4) % PC::BIAS_STRIDE;                 // byte offset inside one parity: [0, 1280) bias, [1280, 1920) rowbias
+      if ((o < 1280 && !p.bias) || (o >= 1280 && !(EPI == EPI_LINEAR && p.rowbias))) bz[i] = 0u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pp_barrier();
+  }
   // prologue: the first K-tile of the first tile, complete for everybody
   setup_tile(t);
   issue_pieces(0, std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
@@ -271,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   int buf = 0;
   for (;;) {
     int64_t tile_n, tile_m;
-    pp_tile_coords(t, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    pp_tile_coords(SPLIT ? (int64_t)((uint32_t)t / (uint32_t)S) : t, p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
     const int64_t tnext = t + G;
 #pragma unroll
@@ -312,32 +366,110 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
     }
     if (!grp) pp_barrier();                        // group 0 waits for group 1's last phase: both run the epilogue together
 
-    persist_epilogue<EPI, NB, RES>(p, acc, reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * 68),
-                                   reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE),
-                                   reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280),
-                                   m0, n0, wm, wblk, wblk_last, lane);
+    if constexpr (SPLIT) {
+      // split-K item: the fp32 accumulators leave in register order (1 KB per store instruction, no LDS); splitk_reduce_kernel reads them back
+      float* const wsi = p.ws + ((t * 8 + wid) * (NB * 8)) * 256 + lane * 4;
+#pragma unroll
+      for (int tn = 0; tn < NB; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(wsi + ((tn * 2 + tm) * 4 + q) * 256) =
+                float4{acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+    } else {
+      persist_epilogue<EPI, NB, RES>(p, acc, reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * 68),
+                                     reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE),
+                                     reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280),
+                                     m0, n0, wm, wblk, wblk_last, lane);
+    }
     if (tnext >= ntiles) break;
     t = tnext;
   }
 }
 
-template <int CONV, int EPI, int NB, bool RES>
+// Second half of a split-K launch: per output tile, add the `ksplit` fp32 slices in index order (deterministic) and apply the epilogue's
+// arithmetic — ((acc + bias) + rowbias) * alpha, then + beta * R, one rounding — in the layout the accumulators were stored in: thread =
+// (wave, lane) of the producing workgroup, 8-byte stores of 4 consecutive columns.
+template <int NB>
+__global__ __launch_bounds__(512) void splitk_reduce_kernel(const GemmParams p) {
+  using PC = PPCfg<NB>;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, g = lane >> 5;
+  const int wblk = (NB == 5) ? wn * 4 : wn * NB;
+  const int wblk_last = (NB == 5) ? 8 + wn : wn * NB + NB - 1;
+  const int S = p.ksplit;
+  int64_t tile_n, tile_m;
+  pp_tile_coords(blockIdx.x, p.tiles_m, p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = tile_m * PBM, n0 = tile_n * PC::BN;
+  const float* const w0 = p.ws + (((int64_t)blockIdx.x * S * 8 + wid) * (NB * 8)) * 256 + lane * 4;
+  const int64_t item_stride = (int64_t)8 * NB * 8 * 256;
+#pragma unroll
+  for (int tn = 0; tn < NB; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int64_t m = m0 + wm * 64 + tm * 32 + l31;
+      const int64_t nb0 = n0 + (tn < NB - 1 ? wblk + tn : wblk_last) * 32 + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* src = w0 + ((tn * 2 + tm) * 4 + q) * 256;
+        float4 a = *reinterpret_cast<const float4*>(src);
+        for (int s = 1; s < S; ++s) {
+          const float4 b = *reinterpret_cast<const float4*>(src + s * item_stride);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const int64_t n = nb0 + 8 * q;
+        float v[4] = {a.x, a.y, a.z, a.w};
+        if (p.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.rowbias) {
+          const u32x2_t tb = *reinterpret_cast<const u32x2_t*>(p.rowbias + (m / p.rb_div) * p.N + n);
+          v[0] += lo16(tb[0]); v[1] += hi16(tb[0]); v[2] += lo16(tb[1]); v[3] += hi16(tb[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = epi_scale(v[e], p.alpha);
+        if (p.R) {
+          const u32x2_t tr = *reinterpret_cast<const u32x2_t*>(p.R + m * p.ldr + n);
+          v[0] = epi_axpy(v[0], p.beta, lo16(tr[0])); v[1] = epi_axpy(v[1], p.beta, hi16(tr[0]));
+          v[2] = epi_axpy(v[2], p.beta, lo16(tr[1])); v[3] = epi_axpy(v[3], p.beta, hi16(tr[1]));
+        }
+        u32x2_t o;
+        o[0] = pack16(v[0], v[1]);
+        o[1] = pack16(v[2], v[3]);
+        *reinterpret_cast<u32x2_t*>(p.Y + m * p.ldy + n) = o;
+      }
+    }
+}
+
+template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false>
 int launch_pp(hipStream_t stream, const GemmParams& p, int cus) {
   using PC = PPCfg<NB>;
   static uint64_t attr_done = 0;
   if (int rc = a3d_once_per_device(attr_done, [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
-  const int64_t ntiles = p.tiles_m * p.tiles_n;
+  const int64_t ntiles = p.tiles_m * p.tiles_n * (SPLIT ? p.ksplit : 1);
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  gemm_pp_kernel<CONV, EPI, NB, RES><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
-  return a3d_launch_status();
+  gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
+  if (int rc = a3d_launch_status()) return rc;
+  if constexpr (SPLIT) {
+    splitk_reduce_kernel<NB><<<dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, stream>>>(p);
+    return a3d_launch_status();
+  }
+  return 0;
 }
 
 template <int CONV>
 int launch_pp_conv(int epi, int nb, hipStream_t stream, const GemmParams& p, int cus) {
   if (epi == EPI_GEGLU) {
     if constexpr (CONV == 0) { if (nb == 4) return launch_pp<0, EPI_GEGLU, 4, false>(stream, p, cus); }
+    return A3D_EUNSUPPORTED;
+  }
+  if (p.ksplit > 1) {        // (the residual is applied by the reduce kernel)
+    if (nb == 5) return launch_pp<CONV, EPI_LINEAR, 5, false, true>(stream, p, cus);
+    if (nb == 4) return launch_pp<CONV, EPI_LINEAR, 4, false, true>(stream, p, cus);
     return A3D_EUNSUPPORTED;
   }
   if (nb == 5) return p.R ? launch_pp<CONV, EPI_LINEAR, 5, true>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 5, false>(stream, p, cus);

@@ -42,8 +42,12 @@ class RowMap:
 _SIGNATURES = {
     "a3d_version": (ctypes.c_char_p, []),
     "a3d_gemm_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_int]),
+    "a3d_gemm_ws_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_int,
+                                 c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "a3d_gemm_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int]),
     "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "a3d_conv3x3_ws_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                     c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
     "a3d_flash_attn2_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
@@ -182,9 +186,21 @@ class HipOps:
         # word of a3d_gemm / a3d_gemm_geglu / a3d_conv3x3) — the library keeps no state.  Set by animate3d_amd.parallel while an RCCL
         # all-gather is in flight; a HIP graph captured meanwhile replays with the value of its capture.
         self.reserved_cus = 0
+        # split-K of the small-M / long-K GEMMs and convs (UNet levels 2 / 3, the whole 4D-SDS shape): on by default; results then agree
+        # with the unsplit kernels to fp32 summation order only, so runs that are compared BIT FOR BIT across different row counts
+        # (a sharded forward against the unsharded one: animate3d_amd.parallel turns it off) must not use it
+        self.split_k = True
+        # ... of dense GEMMs too: off.  Measured (profiles/r5_microbench_splitk.log): the mid-block convolutions (K = 11 520 ... 23 040) gain
+        # 13-55 %, but the level-2 / 3 linears (K <= 5 120, 35-120 us per launch) LOSE 20-100 %: 84 MB of fp32 partials written and read
+        # back plus a second launch cost more than the idle CUs return.  The entry point and its tests stay (a3d_gemm_ws_*).
+        self.split_k_gemm = False
+        self._ws_plan = {}           # launch shape -> split-K workspace bytes (0: the shape does not split)
 
     def _gemm_flags(self, tile128: bool) -> int:
-        return (int(self.reserved_cus) & 0xFF) | (0x100 if tile128 else 0)
+        r = int(self.reserved_cus)
+        if not 0 <= r <= 0xFF:
+            raise ValueError(f"reserved_cus = {self.reserved_cus}: the flags word of a3d_gemm / a3d_conv3x3 carries 0..255 reserved compute units")
+        return r | (0x100 if tile128 else 0)
 
     # ---- helpers
     def _stream(self):
@@ -216,9 +232,21 @@ class HipOps:
             assert rowbias.is_contiguous() and rowbias.shape[1] == N
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.numel() == N
-        rc = self.lib.a3d_gemm_bf16(self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(rowbias), rb_div,
-                                    _p(residual), residual.stride(0) if residual is not None else 0, _p(y), y.stride(0),
-                                    M, N, K, alpha, beta, self._gemm_flags(tile128))
+        flags = self._gemm_flags(tile128)
+        args = (self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(rowbias), rb_div,
+                _p(residual), residual.stride(0) if residual is not None else 0, _p(y), y.stride(0), M, N, K, alpha, beta, flags)
+        if self.split_k and self.split_k_gemm and not tile128 and M <= 32768 and K >= 1152:
+            key = ("gemm", M, N, K, x.stride(0), w.stride(0), y.stride(0), rb_div if rowbias is not None else 0, flags)
+            need = self._ws_plan.get(key)
+            if need is None:
+                q = c_i64(0)
+                _check(self.lib.a3d_gemm_ws_bf16(*args, None, 0, ctypes.byref(q)), f"a3d_gemm_ws_bf16 (query) M={M} N={N} K={K}")
+                need = self._ws_plan[key] = int(q.value)
+            if need > 0:
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _check(self.lib.a3d_gemm_ws_bf16(*args, _p(ws), need, None), f"a3d_gemm_ws_bf16 M={M} N={N} K={K}")
+                return y
+        rc = self.lib.a3d_gemm_bf16(*args)
         _check(rc, f"a3d_gemm_bf16 M={M} N={N} K={K}")
         return y
 
@@ -262,8 +290,20 @@ class HipOps:
             assert residual.is_contiguous() and residual.shape == y.shape
         if rowbias is not None:
             assert rowbias.is_contiguous() and rowbias.shape[1] == Cout
-        rc = self.lib.a3d_conv3x3_bf16(self._stream(), _p(x), _p(w), _p(bias), _p(rowbias), rb_div, _p(residual), _p(y),
-                                       B, H, W, Cin, Cout, stride, up_code, self._gemm_flags(tile128))
+        flags = self._gemm_flags(tile128)
+        args = (self._stream(), _p(x), _p(w), _p(bias), _p(rowbias), rb_div, _p(residual), _p(y), B, H, W, Cin, Cout, stride, up_code, flags)
+        if self.split_k and not tile128 and B * Ho * Wo <= 32768:
+            key = ("conv", B, H, W, Cin, Cout, stride, up_code, rb_div if rowbias is not None else 0, flags)
+            need = self._ws_plan.get(key)
+            if need is None:
+                q = c_i64(0)
+                _check(self.lib.a3d_conv3x3_ws_bf16(*args, None, 0, ctypes.byref(q)), f"a3d_conv3x3_ws_bf16 (query) B={B} H={H} W={W} Cin={Cin} Cout={Cout}")
+                need = self._ws_plan[key] = int(q.value)
+            if need > 0:
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _check(self.lib.a3d_conv3x3_ws_bf16(*args, _p(ws), need, None), f"a3d_conv3x3_ws_bf16 B={B} H={H} W={W} Cin={Cin} Cout={Cout}")
+                return y, Ho, Wo
+        rc = self.lib.a3d_conv3x3_bf16(*args)
         _check(rc, f"a3d_conv3x3_bf16 B={B} H={H} W={W} Cin={Cin} Cout={Cout} stride={stride} up={up2x}")
         return y, Ho, Wo
 

@@ -124,9 +124,9 @@ class ShardPlan:
         fl = F // self.frame_shards
         return self.frame_rank * fl, fl
 
-    def _count(self, received_bytes: int):
+    def _count(self, received_bytes: int, n: int = 1):
         self.gather_bytes += int(received_bytes)
-        self.collectives += 1
+        self.collectives += int(n)
 
     def _overlap(self, delta: int):
         """Book-keeping of asynchronous collectives in flight: the first one reserves CUs for RCCL, the last one to finish frees them."""
@@ -152,6 +152,8 @@ class ShardPlan:
         # one collective per local batch entry, each straight into its final place: rank s's rows of batch entry j land at
         # out[j][s] of the [b_l, S, per_b, width] view = unsharded (b_l N f) l order, so no re-ordering copy follows the gather
         # (b_local = 1: the single gather already is in that order)
+        if b_local <= 0 or rows % b_local != 0:
+            raise ValueError(f"all_gather_views: {rows} rows do not split into {b_local} local batch entries")
         per_b = rows // b_local
         works = []
         try:
@@ -162,7 +164,7 @@ class ShardPlan:
             for w_ in works:
                 w_.wait()
             raise
-        self._count((S - 1) * rows * width * kv.element_size())
+        self._count((S - 1) * rows * width * kv.element_size(), n=len(works))
         self._overlap(+1)
         return works, out, kv
 
@@ -237,6 +239,10 @@ def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: 
     unet.parallel = ShardPlan(group, layout)
     ops = getattr(unet, "ops", None)                                # HIP op set: reserve CUs for RCCL while a gather overlaps the GEMMs
     unet.parallel.ops = ops if hasattr(ops, "reserved_cus") else None
+    if unet.parallel.ops is not None and hasattr(ops, "split_k"):
+        # sharded ranks see different row counts than the unsharded job: keep the kernels whose results do not depend on the launch shape
+        # (split-K re-associates the K sum per shape), so that a sharded forward stays bit-comparable with the unsharded one
+        ops.split_k = False
     if shape is not None:
         unet.parallel.configure(*shape)
     return unet.parallel

@@ -49,6 +49,15 @@ class UNet3DConditionOutput:
         return (self.sample,)[i]
 
 
+def _rows(w: torch.Tensor, r0: int, r1: Optional[int] = None) -> torch.Tensor:
+    """Row range of a fused projection weight.  A packed TRAINABLE operand (autograd_ops.pack_weight) keeps its fp32 gradient sink."""
+    r1 = w.shape[0] if r1 is None else r1
+    if getattr(w, "_a3d_sink", None) is None:
+        return w[r0:r1]
+    from .autograd_ops import weight_rows
+    return weight_rows(w, r0, r1)
+
+
 class MVUNetMotionModel(nn.Module):
     def __init__(self, config: Optional[UNetConfig] = None, ops=None, num_views: Optional[int] = None,
                  device: Optional[Union[str, torch.device]] = None, **config_overrides):
@@ -666,7 +675,7 @@ class MVUNetMotionModel(nn.Module):
             x0 = par.broadcast_frame0(x0, (V * L, C), x.dtype, x.device)
             if vsh:
                 x0 = par.all_gather_views(x0, b)
-            return ops.gemm(x0, w_kvq[:2 * C]), RowMap(gdiv=F, ga=N * L, gb=0, seg_len=L, seg_stride=L)
+            return ops.gemm(x0, _rows(w_kvq, 0, 2 * C)), RowMap(gdiv=F, ga=N * L, gb=0, seg_len=L, seg_stride=L)
 
         if not vsh:
             kvq = ops.gemm(x, w_kvq)
@@ -685,13 +694,13 @@ class MVUNetMotionModel(nn.Module):
             # gather the (normalised) INPUT tokens [rows_local, C] and project K|V for all N views locally: half the
             # bytes on xGMI for S x the (cheap, HBM-bound) K|V projection
             pending = par.all_gather_views_start(x, b)
-            qq = ops.gemm(x, w_kvq[2 * C:])                   # overlaps the gather
+            qq = ops.gemm(x, _rows(w_kvq, 2 * C))                   # overlaps the gather
             extra = overlap() if overlap is not None else None
-            kv_all = ops.gemm(par.all_gather_views_finish(pending, b), w_kvq[:2 * C])
+            kv_all = ops.gemm(par.all_gather_views_finish(pending, b), _rows(w_kvq, 0, 2 * C))
         else:
-            kv = ops.gemm(x, w_kvq[:2 * C])                   # [rows_local, 2C], contiguous
+            kv = ops.gemm(x, _rows(w_kvq, 0, 2 * C))                   # [rows_local, 2C], contiguous
             pending = par.all_gather_views_start(kv, b)       # RCCL stream
-            qq = ops.gemm(x, w_kvq[2 * C:])                   # [rows_local, C or 2C], overlaps the gather
+            qq = ops.gemm(x, _rows(w_kvq, 2 * C))                   # [rows_local, C or 2C], overlaps the gather
             extra = overlap() if overlap is not None else None
             kv_all = par.all_gather_views_finish(pending, b)  # [b * N*F*L, 2C] in unsharded (b n f) l order
         km, km0 = self._mv_maps(N, F, L)
@@ -781,9 +790,9 @@ class MVUNetMotionModel(nn.Module):
                 qkv = ops.gemm(nt, a.qkv)
                 return ops.temporal_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], V, F, L, a.heads, **blk(0))
             # frame-sharded: every rank needs the keys / values of ALL frames of its pixels; queries stay local
-            kv = ops.gemm(nt, a.qkv[C:])                      # [rows_local, 2C], contiguous
+            kv = ops.gemm(nt, _rows(a.qkv, C))                      # [rows_local, 2C], contiguous
             pending = par.all_gather_frames_start(kv)
-            q = ops.gemm(nt, a.qkv[:C])                       # overlaps the gather
+            q = ops.gemm(nt, _rows(a.qkv, 0, C))                       # overlaps the gather
             kv_all = par.all_gather_frames_finish(pending)    # [Sf, (v f_l) l, 2C], read in place
             return ops.temporal_attn(q, kv_all[:, :C], kv_all[:, C:], V, F_all, L, a.heads, q_f0=f0, q_frames=F, **blk(0))
         if a.spatial:
@@ -801,8 +810,8 @@ class MVUNetMotionModel(nn.Module):
             qm = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
             if fsh:                       # frame 0's tokens from the rank that holds them
                 x0 = nimg.view(V, F, L, C)[:, 0].reshape(V * L, C) if par.frame_rank == 0 else None
-                kv0 = ops.gemm(par.broadcast_frame0(x0, (V * L, C), nimg.dtype, nimg.device), a.qkv_img[:2 * C])
-                qi = ops.gemm(nimg, a.qkv_img[2 * C:])
+                kv0 = ops.gemm(par.broadcast_frame0(x0, (V * L, C), nimg.dtype, nimg.device), _rows(a.qkv_img, 0, 2 * C))
+                qi = ops.gemm(nimg, _rows(a.qkv_img, 2 * C))
                 ai = ops.flash_attn(qi, kv0[:, :C], kv0[:, C:], qm, RowMap(gdiv=F, ga=L, gb=0, seg_len=L, seg_stride=0), V * F, a.heads, L, L,
                                     **blk(nblk - 1))
             else:

@@ -26,6 +26,9 @@ Rank 0 prints ONE JSON line.  It carries
   cpu_baseline — the CPU oracle (plain-PyTorch fp32 restatement of the reference forward; the reference itself cannot be
                  imported offline) timed on this host on BASELINE config 1: seeded weights, 1 warm-up + 3 timed forwards
                  (fewer only past a 150-s budget), thread count chosen by a 2-second matmul probe over the CPUs this process may use.
+  box          — calibration kernels outside the timed region (8192^3 GEMM, the level-0 attention launch on zero-filled and on random
+                 inputs, a 336 MB LayerNorm, the shader clock if rocm-smi answers): compute-bound kernels run at a power-limited clock
+                 that differs by several per cent between boxes, so round-over-round deltas are quoted against these.
 ``--dtype`` selects the storage type of the kernels; the default is the dtype BASELINE.json states for the configuration (2: bf16, 4 and
 5: fp16) and the line's ``dtype`` reports what ran.  ``--graph`` adds the same steps replayed from a HIP graph (capture_graph).
 """
@@ -84,6 +87,14 @@ class TimedOps:
         self._ops, self._hd, self._min_kv = ops, head_dim, min_kv
         self.events, self.flops, self.enabled = [], [], False
         self.profile, self.records = False, []
+
+    _PASS_THROUGH = ("reserved_cus", "split_k")      # per-call launch options that animate3d_amd.parallel sets on the op set it is handed
+
+    def __setattr__(self, name, value):
+        if name in TimedOps._PASS_THROUGH:
+            setattr(self._ops, name, value)
+        else:
+            object.__setattr__(self, name, value)
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
@@ -248,6 +259,54 @@ def cpu_baseline(threads, budget_s=150.0):
             "config2_equivalent_steps_per_s": (1.0 / dt) * f_cfg1 / f_cfg2}
 
 
+def box_calibration(ops, dev):
+    """Fixed kernels outside the timed region that tell this box from the next one (compute-bound kernels run at a power-limited clock that
+    differs by several per cent between boxes and between hours on one box): the 8192^3 GEMM on uniform random operands, the level-0
+    attention launch of config 2 on ZERO-filled inputs (no data-dependent switching power: the clock ceiling), the same launch on
+    random inputs, and a 336 MB LayerNorm (HBM).  Round-over-round deltas in DESIGN.md are quoted against these."""
+    from animate3d_amd.hip_ops import RowMap
+    dt = ops.act_dtype
+
+    def med(fn, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    g = torch.Generator(device=dev).manual_seed(7)
+    a = (torch.rand(8192, 8192, device=dev, generator=g) - 0.5).to(dt)
+    b = (torch.rand(8192, 8192, device=dev, generator=g) - 0.5).to(dt)
+    t_gemm = med(lambda: ops.gemm(a, b), 9)
+    del a, b
+    n, F, L, bb, C, heads = 4, 16, 4096, 2, 320, 8
+    qm = RowMap(F, n * F * L, L, L, F * L)
+    S, G = n * L, bb * F
+    qkv = torch.zeros(bb * n * F * L, 3 * C, device=dev, dtype=dt)
+    attn = lambda: ops.flash_attn(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qm, qm, G, heads, S, S)
+    t_zero = med(attn, 3, warm=1)
+    qkv.copy_(torch.randn(qkv.shape, device=dev, generator=g))
+    t_rand = med(attn, 3, warm=1)
+    x = qkv[:, :C].contiguous()
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    t_ln = med(lambda: ops.layer_norm(x, gam, bet, 1e-5), 9)
+    box = {"gemm8192_tflops": round(2.0 * 8192 ** 3 / t_gemm / 1e9, 1), "attn_zero_ms": round(t_zero, 3), "attn_randn_ms": round(t_rand, 3),
+           "layer_norm_336MB_gbs": round(2.0 * x.numel() * 2 / t_ln / 1e6), "device": torch.cuda.get_device_name(dev)}
+    try:       # shader clock right after the calibration kernels, if the SMI tool answers in time (informational)
+        import re
+        import subprocess
+        txt = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz", txt, re.I)
+        box["sclk_mhz"] = int(m.group(1)) if m else None
+    except Exception:
+        box["sclk_mhz"] = None
+    return box
+
+
 def _pmc_traffic(S0, groups, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass, if it matches this kernel and launch shape."""
     for name in ("r4_flash_pmc_traffic.json", "r3_flash_pmc_traffic.json"):      # newest pass first; the kernel is unchanged since round 3
@@ -276,19 +335,17 @@ def main():
     ap.add_argument("--graph", action="store_true", help="also time the same steps replayed from a HIP graph (capture_graph)")
     ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 40 by time)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration kernels behind the 'box' object")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run on a free local port; the
         # ranks are this same script (WORLD_SIZE set), rank 0 prints the one JSON line on the inherited stdout
-        import socket
         import subprocess
-        with socket.socket() as s_:
-            s_.bind(("127.0.0.1", 0))
-            port = s_.getsockname()[1]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        # --standalone: the c10d rendezvous picks its own free port (no bind-then-close probe that another process can win on a busy box)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__), *sys.argv[1:]]
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -463,6 +520,8 @@ def main():
             line["groups"] = groups
         if comm is not None:
             line["communication"] = comm
+        if world == 1 and not args.no_box:
+            line["box"] = box_calibration(ops._ops, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         print(json.dumps(line), flush=True)

@@ -76,6 +76,18 @@ int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags);
 
+/* a3d_gemm with a caller-owned workspace for SPLIT-K (round 5).  The persistent kernel works on 256-row tiles: at the small token
+ * matrices of UNet levels 2 / 3 (M <= 8192 at the 4D-SDS shape, animatemv_guidance.py:339-346) a launch is 32-160 tiles on 256 compute
+ * units.  With a workspace the K-tiles of one output tile are dealt to up to 16 work items that leave fp32 partial accumulators in `ws`;
+ * a second kernel adds them in index order (deterministic) and applies the epilogue.  Results agree with a3d_gemm to fp32 summation
+ * order (NOT bit for bit: callers that compare runs bit for bit use a3d_gemm).  Two calls: first with ws_needed != NULL — nothing is
+ * launched, *ws_needed receives the bytes a split launch of exactly this call would use (0: the shape does not split, call a3d_gemm) —
+ * then with ws (16-byte aligned, >= that many bytes) and ws_needed == NULL.  The library still never allocates. */
+int a3d_gemm_ws_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                     const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                     void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags,
+                     void* ws, int64_t ws_bytes, int64_t* ws_needed);
+
 /* Same contraction with an fp32 result: Y[M,N] (float, row stride ldy floats) = alpha * (X W^T + bias).  For logits that must
  * not be rounded to bf16: the single-head 512-wide self-attention of the VAE mid block (diffusers AutoencoderKL, used by
  * pipeline.py:566-579 decode_latents) computes S = Q K^T / sqrt(512) with this, a3d_softmax_rows_f32_bf16, and two more GEMMs.
@@ -102,6 +114,13 @@ int a3d_gemm_geglu_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const v
 int a3d_conv3x3_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
                      const void* rowbias, int64_t rb_div, const void* R, void* Y,
                      int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags);
+
+/* a3d_conv3x3 with a split-K workspace (see a3d_gemm_ws_bf16): the 8 x 8 and 4 x 4 feature maps of the mid block (K = 9 Cin = 11 520 ... 23 040 over
+ * 128 or fewer output tiles; cuDNN under nn.Conv2d picks a split-K algorithm there too).  Work items hold whole 64-channel slices. */
+int a3d_conv3x3_ws_bf16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                        const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                        int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags,
+                        void* ws, int64_t ws_bytes, int64_t* ws_needed);
 
 /* softmax(Q K^T * scale) V per (group, head), flash-style (no score matrix in memory).
  *   O[row_o(g,s), h*D + d] = out_scale * attn(...)   (+ previous O contents if accumulate)
@@ -321,6 +340,10 @@ int a3d_adamw_f32(a3d_stream_t stream, float* p, const float* g, float* m, float
 int a3d_gemm_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags);
+int a3d_gemm_ws_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
+                    const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
+                    void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags,
+                    void* ws, int64_t ws_bytes, int64_t* ws_needed);
 int a3d_gemm_f32out_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
 int a3d_gemm_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
@@ -328,6 +351,10 @@ int a3d_gemm_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, const vo
 int a3d_conv3x3_f16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
                      const void* rowbias, int64_t rb_div, const void* R, void* Y,
                      int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags);
+int a3d_conv3x3_ws_f16(a3d_stream_t stream, const void* X, const void* Wp, const float* bias,
+                       const void* rowbias, int64_t rb_div, const void* R, void* Y,
+                       int B, int H, int W, int Cin, int Cout, int stride, int up2x, int flags,
+                       void* ws, int64_t ws_bytes, int64_t* ws_needed);
 int a3d_flash_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,

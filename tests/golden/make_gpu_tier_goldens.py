@@ -9,7 +9,11 @@ and the tests re-draw weights and inputs from the same seeds through the functio
   raw UNet output, reconstruction, latent gradient, loss.
 * ``config1`` — BASELINE config 1: 1 view x 4 frames x 64 x 64 latent, no CFG: UNet output.
 
-    python tests/golden/make_gpu_tier_goldens.py          # ~6 min on 8 cores
+    python tests/golden/make_gpu_tier_goldens.py [--out FILE]         # ~6 min on 8 cores
+
+The file also records a fingerprint of the oracle's code (tests/golden/seeded.py::oracle_fingerprint) and a float64 checksum of each
+weight set; tests/test_oracle_golden.py asserts both on the CPU tier, so an oracle edit or a changed draw order cannot leave the
+stored outputs silently stale: re-run this script (and make_config2_golden.py) in the same commit as any change of oracle/unet_ref.py.
 """
 import os
 import sys
@@ -21,6 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import unet_ref as O  # noqa: E402
+from tests.golden.seeded import oracle_fingerprint, weight_checksum  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_tier_oracle.npz")
 SDS5 = dict(n=4, F=16, hw=(32, 32), b=1, seed_w=0, seed_in=2, t=500, guidance_scale=7.5, recon_std_rescale=0.5)
@@ -56,8 +61,9 @@ def config1_inputs():
 def main():
     from animate3d_amd.sds import sds_recon_loss
     t0 = time.time()
-    out = {}
+    out = {"oracle_sha256": np.array(oracle_fingerprint())}
     ref = sds5_weights()
+    out["sds5_w_checksum"] = np.float64(weight_checksum(ref))
     lat, noise, t, text, emb, c2w = sds5_inputs()
     seen = {}
 
@@ -79,13 +85,15 @@ def main():
                sds5_loss=np.float64(loss.item()), sds5_in_checksum=np.float64(lat.double().sum().item() + text.double().sum().item()))
     del ref
     ref = config1_weights()
+    out["config1_w_checksum"] = np.float64(weight_checksum(ref))
     inp = config1_inputs()
     with torch.no_grad():
         y = ref(**inp).sample
     print(f"config1 done at {time.time() - t0:.0f} s: |y| max {y.abs().max():.3f}", flush=True)
     out.update(config1_sample=y.numpy().astype(np.float16), config1_in_checksum=np.float64(inp["sample"].double().sum().item()))
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    dst = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
 if __name__ == "__main__":

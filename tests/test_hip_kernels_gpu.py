@@ -115,16 +115,21 @@ def _first(t):
 
 
 def _both_paths(ops, fn):
-    """fn(tile128) -> output.  Returns (default dispatch, 128 x 128-tile kernel, default dispatch with 16 CUs reserved)."""
-    classic = fn(True)
-    got = fn(False)
-    for _ in range(2):                              # the counted-wait pipeline must be deterministic run to run
-        assert torch.equal(_first(fn(False)), _first(got))
+    """fn(tile128) -> output.  Returns (default dispatch, 128 x 128-tile kernel, default dispatch with 16 CUs reserved).  Split-K is off: it
+    re-associates the K sum (its own tests: test_split_k_*)."""
+    split, ops.split_k = ops.split_k, False
     try:
-        ops.reserved_cus = 16                       # a smaller persistent grid walks the same tiles
-        reserved = fn(False)
+        classic = fn(True)
+        got = fn(False)
+        for _ in range(2):                              # the counted-wait pipeline must be deterministic run to run
+            assert torch.equal(_first(fn(False)), _first(got))
+        try:
+            ops.reserved_cus = 16                       # a smaller persistent grid walks the same tiles
+            reserved = fn(False)
+        finally:
+            ops.reserved_cus = 0
     finally:
-        ops.reserved_cus = 0
+        ops.split_k = split
     return got, classic, reserved
 
 
@@ -155,14 +160,61 @@ def test_gemm_persistent_path_repeatable_under_memory_traffic(ops):
     show up as rare wrong tiles.  Hammer it next to unrelated HBM traffic: every launch must reproduce the 128x128 kernel bit for
     bit (2 200 launches over ten shapes were clean when this test was written)."""
     junk = torch.empty(32 << 20, device="cuda", dtype=torch.uint8)
-    for (M, N, K) in [(65536, 320, 320), (32768, 1280, 1280), (8192, 1280, 1280)]:
-        x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5)
-        bias, res = rnd(N, seed=43, dtype=torch.float32), rnd(M, N, seed=44)
-        want = ops.gemm(x, w, bias, residual=res, alpha=0.7, tile128=True)
-        for it in range(40):
-            if it % 3 == 0:
-                junk.add_(1)
-            assert torch.equal(ops.gemm(x, w, bias, residual=res, alpha=0.7), want), (M, N, K, it)
+    split, ops.split_k = ops.split_k, False           # (bit-for-bit against the 128x128 kernel: the unsplit persistent kernel)
+    try:
+        for (M, N, K) in [(65536, 320, 320), (32768, 1280, 1280), (8192, 1280, 1280)]:
+            x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5)
+            bias, res = rnd(N, seed=43, dtype=torch.float32), rnd(M, N, seed=44)
+            want = ops.gemm(x, w, bias, residual=res, alpha=0.7, tile128=True)
+            for it in range(40):
+                if it % 3 == 0:
+                    junk.add_(1)
+                assert torch.equal(ops.gemm(x, w, bias, residual=res, alpha=0.7), want), (M, N, K, it)
+    finally:
+        ops.split_k = split
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 1280, 1280), (2048, 3840, 1280), (2048, 1280, 5120), (8192, 1280, 2560), (4096, 640, 2304)])
+def test_split_k_gemm(ops, ref, request, M, N, K):
+    """Small M, long K (UNet levels 2 / 3; every GEMM of the 4D-SDS shape's mid block): a3d_gemm_ws deals the K-tiles of an output tile to
+    several work items and a second kernel adds the fp32 slices in index order.  Against the fp32 reference at the usual bar, against the
+    unsplit kernel to fp32 summation order (<= 1 storage ulp on a few elements), bit-reproducible run to run, every epilogue operand."""
+    x, w = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5)
+    bias, res, rb = rnd(N, seed=53, dtype=torch.float32), rnd(M, N, seed=54), rnd(M // 256, N, seed=55)
+    ops.split_k_gemm = True            # (off by default: split-K pays for the mid-block convolutions, not for the level-2 / 3 linears)
+    request.addfinalizer(lambda: setattr(ops, "split_k_gemm", False))
+    for name, kw in (("plain", {}), ("residual", dict(residual=res, alpha=0.37, beta=0.9)), ("rowbias+res", dict(rowbias=rb, rb_div=256, residual=res))):
+        got = ops.gemm(x, w, bias, **kw)
+        check(f"split-K gemm {name} {M}x{N}x{K}", got, ref.gemm(x, w, bias, **kw))
+        assert torch.equal(got, ops.gemm(x, w, bias, **kw)), "split-K must be deterministic"
+        split, ops.split_k = ops.split_k, False
+        try:
+            unsplit = ops.gemm(x, w, bias, **kw)
+        finally:
+            ops.split_k = split
+        d = (got.float() - unsplit.float()).abs()
+        assert d.max().item() <= 2.0 ** -7 * max(1.0, unsplit.float().abs().max().item()) and (d > 0).float().mean().item() < 0.2, (name, d.max().item())
+    assert any(v > 0 for k, v in ops._ws_plan.items() if k[0] == "gemm" and k[1:4] == (M, N, K)), "the shape was expected to split"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(128, 8, 8, 1280, 1280), (32, 8, 8, 2560, 1280), (128, 4, 4, 1280, 1280), (16, 16, 16, 640, 640)])
+def test_split_k_conv3x3(ops, ref, B, H, W, Cin, Cout):
+    """The 8 x 8 / 4 x 4 mid-block convolutions (K = 9 Cin over <= 128 output tiles): work items hold whole 64-channel slices."""
+    x, w = rnd(B * H * W, Cin, seed=61), rnd(Cout, 9 * Cin, seed=62, scale=(9 * Cin) ** -0.5)
+    bias, res, rb = rnd(Cout, seed=63, dtype=torch.float32), rnd(B * H * W, Cout, seed=64), rnd(B * H * W // 256, Cout, seed=65)
+    for name, kw in (("plain", {}), ("residual", dict(residual=res)), ("rowbias", dict(rowbias=rb, rb_div=256))):
+        got, _, _ = ops.conv3x3(x, B, H, W, w, bias, **kw)
+        want, _, _ = ref.conv3x3(x, B, H, W, w, bias, **kw)
+        check(f"split-K conv {name} B{B} {H}x{W} {Cin}->{Cout}", got, want)
+        assert torch.equal(got, ops.conv3x3(x, B, H, W, w, bias, **kw)[0])
+        split, ops.split_k = ops.split_k, False
+        try:
+            unsplit, _, _ = ops.conv3x3(x, B, H, W, w, bias, **kw)
+        finally:
+            ops.split_k = split
+        d = (got.float() - unsplit.float()).abs()
+        assert d.max().item() <= 2.0 ** -7 * max(1.0, unsplit.float().abs().max().item()), (name, d.max().item())
+    assert any(v > 0 for k, v in ops._ws_plan.items() if k[0] == "conv" and k[1:6] == (B, H, W, Cin, Cout)), "the shape was expected to split"
 
 
 @pytest.mark.parametrize("M,N2,K", [(65536, 512, 64), (49152, 2560, 320)])

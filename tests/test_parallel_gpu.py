@@ -41,6 +41,7 @@ def _worker(rank, world, port, n, F, hw, videos, layout, q, backend="gloo"):
         cfg = UNetConfig()
         model = MVUNetMotionModel(cfg, num_views=n, device="cuda")
         model.init_synthetic(seed=0)
+        model.ops.split_k = False      # the unsharded reference on the kernels the sharded ranks use (shard_unet turns split-K off: it re-associates the K sum per launch shape)
         # frame layouts re-associate the GroupNorm sums, which re-draws the roundings of everything behind them: in bf16 storage two
         # such runs are ~1e-2 apart (the size of the bf16 error against the oracle itself), which would hide a layout bug of that
         # size.  They are therefore compared in fp16 storage, where rounding noise is 8x smaller and a wrong row is not.
@@ -188,3 +189,22 @@ def test_bench_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["communication"]["layout"] == {"cfg": 2, "views": 1, "frames": 1}
     assert rec["metric"].startswith("UNet denoise-steps/sec")
+
+
+@pytest.mark.parametrize("gpus,layout,expect", [(4, "1,4,1", {"cfg": 1, "views": 4, "frames": 1}), (8, "2,2,2", {"cfg": 2, "views": 2, "frames": 2})])
+def test_bench_launcher_rehearses_the_baseline_layouts(gpus, layout, expect):
+    """BASELINE configs 3 and 4 name their layouts (views over 4 GPUs; view x frame over 8): the exact `bench.py --gpus N --layout ...`
+    command lines go through the self-launcher, the rank plan and every collective at a tiny latent, all ranks sharing this box's one GPU
+    (A3D_BENCH_SHARE_GPU=1, gloo).  No scaling number is derived from this — it proves that the first 8-GPU node produces a line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(A3D_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--layout", layout, "--steps", "1", "--warmup", "0",
+                        "--latent", "16", "--frames", "4", "--no-cpu-baseline", "--no-groups"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == gpus and rec["value"] > 0 and rec["communication"]["layout"] == expect
+    assert rec["communication"]["collectives_per_step"] > 0 and rec["communication"]["received_bytes_per_rank_per_step"] > 0
