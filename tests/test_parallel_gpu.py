@@ -41,12 +41,14 @@ def _worker(rank, world, port, n, F, hw, videos, layout, q, backend="gloo"):
         cfg = UNetConfig()
         model = MVUNetMotionModel(cfg, num_views=n, device="cuda")
         model.init_synthetic(seed=0)
-        model.ops.split_k = False      # the unsharded reference on the kernels the sharded ranks use (shard_unet turns split-K off: it re-associates the K sum per launch shape)
         # frame layouts re-associate the GroupNorm sums, which re-draws the roundings of everything behind them: in bf16 storage two
         # such runs are ~1e-2 apart (the size of the bf16 error against the oracle itself), which would hide a layout bug of that
         # size.  They are therefore compared in fp16 storage, where rounding noise is 8x smaller and a wrong row is not.
         frames_sharded = layout is not None and layout[2] > 1
         model = model.to(torch.float16 if frames_sharded else torch.bfloat16).eval()
+        # the unsharded reference on the kernels the sharded ranks use: shard_unet turns split-K off (it re-associates the K sum per launch
+        # shape).  After .to(): the automatic op set follows the model's dtype and is re-created by it.
+        model.ops.split_k = False
         inp = O.synthetic_inputs(O.UNetConfig(), videos, n, F, hw, seed=11, cfg_doubled=videos >= 2 * n)
         inp = {k: (v.cuda() if torch.is_tensor(v) else ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v)) for k, v in inp.items()}
         full = model(**inp).sample
