@@ -469,7 +469,11 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
       float m_off[QT];
       if constexpr (DM_SAMPLED) {
         const bool wide = first_scores(sA, m_off, DM_BIAS, (uint32_t)DM_SAMPLE);      // offset from the sample keys (now in Q's pad slot)
-        if (__syncthreads_or(wide ? 1 : 0)) return false;           // a row too peaked for fp16's window: exact pass right away
+        // a VOTE, not an OR (round 5): the variance of 32 samples scatters by +-25 %, so at a true spread well inside the window (score sd 3:
+        // variance 19 of 28) 2-3 % of the queries still read above the threshold and an OR over the workgroup's 512 queries sent EVERY workgroup
+        // to the 20 % slower exact pass (profiles/r5_flash_score_spread.log).  The workgroup goes exact right away when more than a quarter of
+        // its queries predict an overflow; a row that does overflow in the max-free pass is still caught by its row sum at the end.
+        if (__syncthreads_count(wide ? 1 : 0) * 4 > NT) return false;
         read_k(0u);                                                 // ... then S(0) of keys 0..31 under it
 #pragma unroll
         for (int qs = 0; qs < QT; ++qs) {

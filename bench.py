@@ -440,7 +440,9 @@ def main():
                                          "41->48 (16x16x32 MFMA); the exp ceiling is the v_exp rate measured next to the "
                                          "kernel's MFMA / cvt mix (tools/ubench_exp.hip); the kernel is clock-limited by power: zero inputs run the shipped variant 13-14 % faster, "
                                          "removing its per-tile barrier changes nothing on random data, and a one-wave-per-SIMD re-instantiation (round 4) lands on "
-                                         "the same 10.8 ms (profiles/README.md)"},
+                                         "the same 10.8 ms (profiles/README.md).  Score spread: the seeded synthetic weights give a nearly flat softmax (score sd ~0.3); "
+                                         "the same launch on q, k with score sd 1 / 3 / 6 takes +1.5 / +3.4 / +3.3 % in bf16 storage (10.96 -> 11.13 / 11.33 / 11.32 ms, no "
+                                         "exact re-runs: tools/microbench.py flashspread, profiles/r5_flash_score_spread.log)"},
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                     "traffic_source": (pmc or {}).get("source", "no committed PMC pass for this launch shape"),
                     "algorithmic_bytes_per_launch": 4.0 * (V // n) * F * S0 * D * 8 * 2,      # Q, K, V read + O written once, bf16

@@ -2,8 +2,10 @@
 costs in accuracy and when the kernel leaves it.
 
 The kernel fixes one offset per query before the key loop — maximum of 32 sample scores (keys 0, kv/32, 2 kv/32, ...) + 4 log2 units —,
-stores P = 2^(s - offset) in fp16 (2^-24 .. 65504, subnormals kept) and accumulates P and P·V in fp32.  A workgroup skips that pass when
-the variance of a query's sample scores exceeds 28 (predicted overflow) and re-runs exactly when a row sum comes out non-finite.  This
+stores P = 2^(s - offset) in fp16 (2^-24 .. 65504, subnormals kept) and accumulates P and P·V in fp32.  A query predicts an overflow when
+the variance of its sample scores exceeds 28; a workgroup (512 queries at head_dim 40) skips the max-free pass when MORE THAN A QUARTER of
+its queries do (round 5: a vote — the sample variance scatters by +-25 %, an OR sent every workgroup to the exact pass at score spreads
+well inside the window) and re-runs exactly when a row sum comes out non-finite.  This
 file checks the arithmetic of that plan on synthetic score rows, in numpy-like torch on the CPU; the GPU tests
 (tests/test_hip_kernels_gpu.py::test_fp16_flash_attn_dma_kernel*) check the kernels."""
 import math
@@ -92,3 +94,25 @@ def test_flat_background_under_a_spike_keeps_its_mass():
     want = _exact(s, v)
     assert not overflow.any()
     assert float((out - want).norm() / want.norm()) <= 2e-3
+
+
+@pytest.mark.parametrize("sd_nat,expect_exact", [(1.0, False), (3.0, False), (3.4, False), (4.5, True), (6.0, True)])
+def test_workgroup_vote_follows_the_true_spread(sd_nat, expect_exact):
+    """The workgroup-level decision of the kernels (``__syncthreads_count(wide) * 4 > threads``) on 512 Gaussian rows of 16 384 keys with
+    natural-log score sd ``sd_nat`` (what tools/microbench.py flashspread sweeps): up to sd 3.4 (variance 24 in log2 units, threshold 28)
+    the max-free pass runs although a few per cent of the rows read above the threshold; from sd 4.5 the workgroup goes exact right away.
+    Rows of an accepted workgroup that do overflow are caught by their row sum (non-finite), never silently wrong."""
+    g = torch.Generator().manual_seed(int(sd_nat * 100))
+    s = torch.randn(512, 16384, generator=g) * (sd_nat / math.log(2.0))
+    v = torch.randn(16384, 40, generator=g)
+    out, l, wide, overflow = _window_attention(s, v)
+    frac = float(wide.float().mean())
+    goes_exact = frac * 4 > 1.0
+    print(f"[parity] fp16 window, score sd {sd_nat} (natural log): {100 * frac:.1f} % of the rows predict an overflow, "
+          f"{100 * float(overflow.float().mean()):.2f} % overflow in the max-free pass -> workgroup takes the {'exact' if goes_exact else 'max-free'} pass")
+    assert goes_exact == expect_exact
+    if not goes_exact:
+        ok = ~overflow
+        want = _exact(s, v)
+        assert float((out[ok] - want[ok]).norm() / want[ok].norm()) <= 6e-4          # accepted rows are right whatever their own predictor said
+        assert float(overflow.float().mean()) <= 0.01                                # and a re-run for an overflowing row stays rare
