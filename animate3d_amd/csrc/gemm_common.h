@@ -419,8 +419,6 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
   }
 }
 
-// gemm_ring.hip: the four-stage ring variant of the persistent kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller
-// (try_launch_persist) has filled tiles_m / tiles_n / vm_counted and checked the shape
 // gemm_pp.hip: the persistent 256 x (nb * 64) tile kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller (try_launch_persist,
-// gemm_conv.hip) has filled tiles_m / tiles_n and checked the shape
+// gemm_conv.hip) has filled tiles_m / tiles_n (and ksplit / nk_item / ws for a split-K launch) and checked the shape
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_pp)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
