@@ -24,6 +24,9 @@ struct GemmParams {
   // the slices in index order and applies the epilogue arithmetic (splitk_reduce_kernel, gemm_pp.hip).  ksplit <= 1: off.
   int ksplit, nk_item;   // K-tiles (64 wide) per work item
   float* ws; int64_t ws_bytes;
+  // two-source A operand of the dense persistent kernel (a3d_gemm2: the 1x1 shortcut convolution of an up-block ResNet reads [hidden | skip]
+  // without a torch.cat): columns [0, K1) of the contraction come from X (row stride ldx), [K1, K) from X2 (row stride ldx2).  X2 == nullptr: off.
+  const uint16_t* X2; int64_t ldx2; int64_t K1;
 };
 
 constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;

@@ -512,6 +512,25 @@ extern "C" int A3D_FN(a3d_gemm_ws)(a3d_stream_t stream, const void* X, int64_t l
   return gemm_entry(stream, X, ldx, W, ldw, bias, rowbias, rb_div, R, ldr, Y, ldy, M, N, K, alpha, beta, flags, ws, ws_bytes, ws_needed);
 }
 
+// Y = [X | X2] W^T + bias with the A operand in two pieces (columns [0, K1) from X, [K1, K) from X2): persistent kernel only — the caller
+// concatenates and calls a3d_gemm when this returns A3D_EUNSUPPORTED (small or ragged M, unaligned rows)
+extern "C" int A3D_FN(a3d_gemm2)(a3d_stream_t stream, const void* X, int64_t ldx, const void* X2, int64_t ldx2, int64_t K1,
+                              const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int flags) {
+  if (!X || !X2 || !W || !Y || M <= 0 || N <= 0 || K <= 0 || K1 <= 0 || K1 >= K) return A3D_EINVAL;
+  if (K % 64 != 0 || K1 % 64 != 0 || N % 8 != 0) return A3D_EINVAL;
+  if (ldx % 8 != 0 || ldx2 % 8 != 0 || ldw % 8 != 0 || ldy % 8 != 0) return A3D_EINVAL;
+  if (!aligned16(X) || !aligned16(X2) || !aligned16(W) || !aligned16(Y)) return A3D_EINVAL;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)) return A3D_EINVAL;
+  if (flags & ~(A3D_GEMM_RESERVED_CUS_MASK | A3D_GEMM_KERNEL_MASK)) return A3D_EINVAL;
+  if (ldx2 % 64 != 0 || (uint64_t)ldx2 * 16u >= (1ull << 31)) return A3D_EUNSUPPORTED;      // (32-bit DMA offsets, as for X)
+  GemmParams p{};
+  p.X = (const uint16_t*)X; p.ldx = ldx; p.X2 = (const uint16_t*)X2; p.ldx2 = ldx2; p.K1 = K1;
+  p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias; p.rb_div = 1; p.Y = (uint16_t*)Y; p.ldy = ldy;
+  p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.beta = 0.f; p.vec16 = 1;
+  const int rc = try_launch_persist<0, EPI_LINEAR>((hipStream_t)stream, p, flags);
+  return rc == -1000 ? A3D_EUNSUPPORTED : rc;
+}
+
 extern "C" int A3D_FN(a3d_gemm_f32out)(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                                     const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return A3D_EINVAL;

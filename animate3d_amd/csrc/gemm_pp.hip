@@ -74,8 +74,10 @@ A3D_DEV void pp_barrier() {
 // CONV: 0 = dense A, 1 = 3x3 conv gather (pad 1, stride 1|2), 2 = 3x3 conv over a nearest-2x upsampled input
 // SPLIT: split-K work items (GemmParams::ksplit > 1) — a separate instantiation: the item bookkeeping and the fp32 partial stores cost the
 // unsplit kernels registers they do not have (the conv instantiations sit at 256)
-template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false>
+// TWO: two-source A operand (GemmParams::X2; dense only) — its own instantiation for the same reason
+template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false, bool TWO = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
+  static_assert(!TWO || CONV == 0, "the two-source A operand is a dense-GEMM feature");
   using PC = PPCfg<NB>;
   constexpr int PH = 1, NPH = 4;              // k-steps per phase, phases per K-tile
   constexpr int NP = 4 + NB;                  // DMA pieces per wave and K-tile: X 0..3, W 0..NB-1
@@ -133,6 +135,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   // instructions per piece — 180 per wave and K-tile — in front of the first MFMA of every K-tile.)
   uint64_t xk = 0, wk = 0, rbk = 0;
   const uint32_t sx8 = (uint32_t)(p.ldx * 16), sw8 = (uint32_t)(p.ldw * 16);      // bytes between two pieces (8 rows)
+  // second A source (TWO): its own per-lane offset, piece stride and running base; the K-tile at position ik0 >= K1 reads it
+  uint64_t xk2 = 0;
+  const uint32_t vx0b = TWO ? (uint32_t)(lr * p.ldx2 * 2 + ((pos ^ (lr >> 1)) << 4)) : 0u;
+  const uint32_t sx8b = TWO ? (uint32_t)(p.ldx2 * 16) : 0u;
   auto setup_tile = [&](int64_t tt) {
     int64_t tile_n, tile_m;
     const int64_t tile_id = SPLIT ? (int64_t)((uint32_t)tt / (uint32_t)S) : tt;
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
     ld_par ^= 1;
     if constexpr (CONV != 0) xck = (uint64_t)(uintptr_t)p.X - (uint64_t)cbias * 2u + (uint64_t)kofs * 2u;
     if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx + kofs);
+    if constexpr (TWO) xk2 = (uint64_t)(uintptr_t)(p.X2 + (ld_m0 + wid * 32) * p.ldx2);
     wk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw + kofs);
     if (EPI == EPI_LINEAR && p.rowbias) rbk = (uint64_t)(uintptr_t)(p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0);
     if constexpr (CONV != 0) {
@@ -227,11 +234,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
         }
       }
     } else {
+      const bool sec = TWO && ik0 >= (int)p.K1;              // wave-uniform: this K-tile comes from the second source
+      const uint32_t vxs = sec ? vx0b : vx0, sxs = sec ? sx8b : sx8;
+      const uint64_t xks = sec ? xk2 : xk;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < A || i >= B) continue;
         const int pc = wid * 4 + i;
-        glds16_s(vx0 ^ (uint32_t)((i & 1) << 6), (const void*)(uintptr_t)(xk + (uint64_t)(uint32_t)(i * sx8)), dst + (uint32_t)pc * 1024u);
+        glds16_s(vxs ^ (uint32_t)((i & 1) << 6), (const void*)(uintptr_t)(xks + (uint64_t)(uint32_t)(i * sxs)), dst + (uint32_t)pc * 1024u);
       }
     }
 #pragma unroll
@@ -258,7 +268,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
           xck += ikx == 0 ? ((uint64_t)(uint32_t)p.Wd - 2u) * cin2 : cin2;
         }
       } else {
-        xk += 128; wk += 128;
+        if (TWO && ik0 >= (int)p.K1) xk2 += 128; else xk += 128;
+        wk += 128;
       }
       ik0 += 64;
     }
@@ -444,16 +455,16 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
-template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false>
+template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false, bool TWO = false>
 int launch_pp(hipStream_t stream, const GemmParams& p, int cus) {
   using PC = PPCfg<NB>;
   static uint64_t attr_done = 0;
   if (int rc = a3d_once_per_device(attr_done, [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT, TWO>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
   const int64_t ntiles = p.tiles_m * p.tiles_n * (SPLIT ? p.ksplit : 1);
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
+  gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT, TWO><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
   if (int rc = a3d_launch_status()) return rc;
   if constexpr (SPLIT) {
     splitk_reduce_kernel<NB><<<dim3((unsigned)(p.tiles_m * p.tiles_n), NB), dim3(512), 0, stream>>>(p);
@@ -467,6 +478,14 @@ int launch_pp_conv(int epi, int nb, hipStream_t stream, const GemmParams& p, int
   if (epi == EPI_GEGLU) {
     if constexpr (CONV == 0) { if (nb == 4) return launch_pp<0, EPI_GEGLU, 4, false>(stream, p, cus); }
     return A3D_EUNSUPPORTED;
+  }
+  if constexpr (CONV == 0) {
+    if (p.X2 != nullptr) {     // two-source A operand: plain linear epilogue (bias), no split
+      if (p.R || p.ksplit > 1) return A3D_EUNSUPPORTED;
+      if (nb == 5) return launch_pp<0, EPI_LINEAR, 5, false, false, true>(stream, p, cus);
+      if (nb == 4) return launch_pp<0, EPI_LINEAR, 4, false, false, true>(stream, p, cus);
+      return A3D_EUNSUPPORTED;
+    }
   }
   if (p.ksplit > 1) {        // (the residual is applied by the reduce kernel)
     if (nb == 5) return launch_pp<CONV, EPI_LINEAR, 5, false, true>(stream, p, cus);

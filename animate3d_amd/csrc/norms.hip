@@ -9,6 +9,9 @@ constexpr int GN_ROWS_PER_BLOCK = 128;   // rows of one instance handled by one 
 // threads: x = 16-byte channel chunk (C/8 of them), y = row lane
 struct GNParams {
   const uint16_t* X; uint16_t* Y; const float* gamma; const float* beta;
+  // two-source input (a3d_group_norm2: the up blocks' torch.cat([hidden, skip], 1) never materialised): channels [0, C1) come from X (row
+  // stride C1), channels [C1, C) from Xb (row stride C - C1); Xb == nullptr: one source with row stride C
+  const uint16_t* Xb; int C1;
   float* partial;   // [B][nchunk][groups][2]
   float* stats;     // [B][groups][2]  (mean, rstd)
   double* sums;     // [B][groups][2]  (sum, sum of squares): written INSTEAD of stats when non-null (split call, frame-sharded 3-D norm)
@@ -27,7 +30,9 @@ __global__ void gn_partial_kernel(const GNParams p) {
   const int g_lo = ch0 / p.cg;                              // a chunk touches at most 2 groups (cg >= 4)
   const int split = (g_lo + 1) * p.cg - ch0;                // first `split` channels belong to g_lo
   float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
-  const uint16_t* base = p.X + ((int64_t)b * p.rows) * p.C + ch0;
+  const bool second = p.Xb != nullptr && ch0 >= p.C1;
+  const int64_t ldsrc = p.Xb == nullptr ? p.C : (second ? p.C - p.C1 : p.C1);
+  const uint16_t* base = (second ? p.Xb + (ch0 - p.C1) : p.X + ch0) + ((int64_t)b * p.rows) * ldsrc;
   auto accum = [&](const u32x4_t& v) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -39,11 +44,11 @@ __global__ void gn_partial_kernel(const GNParams p) {
   for (; r + 3 * ny < r1; r += 4 * ny) {          // four independent row loads in flight per thread, accumulated in row order
     u32x4_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = ld_stream(base + (r + (int64_t)k * ny) * p.C);
+    for (int k = 0; k < 4; ++k) v[k] = ld_stream(base + (r + (int64_t)k * ny) * ldsrc);
 #pragma unroll
     for (int k = 0; k < 4; ++k) accum(v[k]);
   }
-  for (; r < r1; r += ny) accum(ld_stream(base + r * p.C));
+  for (; r < r1; r += ny) accum(ld_stream(base + r * ldsrc));
   float* mine = spart + ((size_t)ry * nx + c8) * 4;
   mine[0] = s_lo; mine[1] = q_lo; mine[2] = s_hi; mine[3] = q_hi;
   __syncthreads();
@@ -112,6 +117,9 @@ __global__ void gn_apply_kernel(const GNParams p) {
     sh[j] = be - mean * rstd * ga;
   }
   const int64_t off = ((int64_t)b * p.rows) * p.C + ch0;
+  const bool second = p.Xb != nullptr && ch0 >= p.C1;
+  const int64_t ldsrc = p.Xb == nullptr ? p.C : (second ? p.C - p.C1 : p.C1);
+  const uint16_t* const src = (second ? p.Xb + (ch0 - p.C1) : p.X + ch0) + ((int64_t)b * p.rows) * ldsrc;
   auto apply = [&](const u32x4_t& v, int64_t r) {
     float f[8];
 #pragma unroll
@@ -128,11 +136,11 @@ __global__ void gn_apply_kernel(const GNParams p) {
   for (; r + 3 * ny < r1; r += 4 * ny) {          // four independent row loads in flight per thread
     u32x4_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = ld_stream(p.X + off + (r + (int64_t)k * ny) * p.C);
+    for (int k = 0; k < 4; ++k) v[k] = ld_stream(src + (r + (int64_t)k * ny) * ldsrc);
 #pragma unroll
     for (int k = 0; k < 4; ++k) apply(v[k], r + (int64_t)k * ny);
   }
-  for (; r < r1; r += ny) apply(ld_stream(p.X + off + r * p.C), r);
+  for (; r < r1; r += ny) apply(ld_stream(src + r * ldsrc), r);
 }
 
 // ---------------- LayerNorm: one wave per row, up to 3 16-byte chunks per lane (C <= 1536)
@@ -336,8 +344,10 @@ extern "C" int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups) {
 
 // mode 0: whole GroupNorm; 1: statistics only (raw fp64 sums); 2: apply only (stats = [B][groups][2] mean, rstd)
 static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
-                             float* ws, double* sums, const float* stats_in, int B, int64_t rows, int C, int groups, float eps, int silu) {
+                             float* ws, double* sums, const float* stats_in, int B, int64_t rows, int C, int groups, float eps, int silu,
+                             const void* Xb = nullptr, int C1 = 0) {
   if (!X || B <= 0 || rows <= 0 || C <= 0 || groups <= 0) return A3D_EINVAL;
+  if (Xb && (C1 <= 0 || C1 >= C || C1 % 8 != 0 || (reinterpret_cast<uintptr_t>(Xb) & 15u))) return A3D_EINVAL;
   if (mode != 1 && (!Y || !gamma || !beta)) return A3D_EINVAL;
   if ((mode != 2 && !ws) || (mode == 1 && !sums) || (mode == 2 && !stats_in)) return A3D_EINVAL;
   if (C % 8 != 0 || C % groups != 0 || C / 8 > 1024 || groups > 1024) return A3D_EINVAL;
@@ -348,6 +358,7 @@ static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void*
   if (B > 65535) return A3D_EINVAL;
   GNParams p{};
   p.X = (const uint16_t*)X; p.Y = (uint16_t*)Y; p.gamma = gamma; p.beta = beta;
+  p.Xb = (const uint16_t*)Xb; p.C1 = C1;
   p.B = B; p.rows = rows; p.C = C; p.groups = groups; p.cg = C / groups; p.nchunk = gn_nchunk(rows);
   p.eps = eps; p.silu = silu;
   p.partial = ws; p.stats = mode == 2 ? const_cast<float*>(stats_in) : ws + (int64_t)B * p.nchunk * groups * 2;
@@ -370,6 +381,12 @@ static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void*
 extern "C" int A3D_FN(a3d_group_norm)(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                                    float* ws, int B, int64_t rows, int C, int groups, float eps, int silu) {
   return group_norm_launch(0, stream, X, Y, gamma, beta, ws, nullptr, nullptr, B, rows, C, groups, eps, silu);
+}
+
+extern "C" int A3D_FN(a3d_group_norm2)(a3d_stream_t stream, const void* Xa, int Ca, const void* Xb, int Cb, void* Y, const float* gamma,
+                                    const float* beta, float* ws, int B, int64_t rows, int groups, float eps, int silu) {
+  if (!Xb || Ca <= 0 || Cb <= 0) return A3D_EINVAL;
+  return group_norm_launch(0, stream, Xa, Y, gamma, beta, ws, nullptr, nullptr, B, rows, Ca + Cb, groups, eps, silu, Xb, Ca);
 }
 
 extern "C" int A3D_FN(a3d_group_norm_sums)(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups) {

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "a3d_gemm_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_int]),
     "a3d_gemm_ws_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_int,
                                  c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    "a3d_gemm2_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int]),
     "a3d_gemm_geglu_bf16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int]),
     "a3d_conv3x3_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "a3d_conv3x3_ws_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -57,6 +58,7 @@ _SIGNATURES = {
                                                c_int, c_int, c_int, c_i64]),
     "a3d_group_norm_ws_floats": (c_i64, [c_int, c_i64, c_int]),
     "a3d_group_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_f32, c_int]),
+    "a3d_group_norm2_bf16": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_f32, c_int]),
     "a3d_group_norm_sums_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int]),
     "a3d_group_norm_apply_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int]),
     "a3d_layer_norm_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64]),
@@ -102,6 +104,7 @@ for _name in list(_SIGNATURES):
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+A3D_EUNSUPPORTED = -2          # include/animate3d_hip.h
 
 
 def lib_path() -> str:
@@ -250,6 +253,24 @@ class HipOps:
         _check(rc, f"a3d_gemm_bf16 M={M} N={N} K={K}")
         return y
 
+    def gemm2(self, xa, xb, w, bias=None):
+        """``[xa | xb] w^T + bias`` without the concatenation (a3d_gemm2: the 1x1 shortcut conv of an up-block ResNet).  None when the
+        persistent kernel does not take the shape — the caller then concatenates and calls ``gemm``."""
+        xa, xb, w = self._act(xa, "gemm2.xa"), self._act(xb, "gemm2.xb"), self._act(w, "gemm2.w")
+        M, K1 = xa.shape
+        K = K1 + xb.shape[1]
+        N = w.shape[0]
+        assert xb.shape[0] == M and w.shape[1] == K
+        if K1 % 64 or K % 64 or N % 8:
+            return None
+        y = self.empty(M, N)
+        rc = self.lib.a3d_gemm2_bf16(self._stream(), _p(xa), xa.stride(0), _p(xb), xb.stride(0), K1, _p(w), w.stride(0), _p(bias), _p(y), y.stride(0),
+                                     M, N, K, self._gemm_flags(False))
+        if rc == A3D_EUNSUPPORTED:
+            return None
+        _check(rc, f"a3d_gemm2_bf16 M={M} N={N} K={K1}+{K - K1}")
+        return y
+
     @staticmethod
     def interleave_geglu(w: torch.Tensor) -> torch.Tensor:
         """[2N, ...] = [h rows | gate rows] -> rows interleaved in blocks of 32 (layout a3d_gemm_geglu_bf16 expects)."""
@@ -382,6 +403,17 @@ class HipOps:
         ws = torch.empty(int(self.lib.a3d_group_norm_ws_floats(B, rows, groups)), dtype=torch.float32, device=self.device)
         rc = self.lib.a3d_group_norm_bf16(self._stream(), _p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, rows, C, groups, eps, 1 if silu else 0)
         _check(rc, f"a3d_group_norm_bf16 B={B} rows={rows} C={C}")
+        return y
+
+    def group_norm2(self, xa, xb, B: int, rows: int, gamma, beta, groups: int, eps: float, silu: bool):
+        """GroupNorm (+ SiLU) of ``cat([xa, xb], 1)`` read from its two parts (a3d_group_norm2)."""
+        xa, xb = self._act(xa, "gn2.xa"), self._act(xb, "gn2.xb")
+        assert xa.is_contiguous() and xb.is_contiguous() and xa.shape[0] == B * rows == xb.shape[0]
+        Ca, Cb = xa.shape[1], xb.shape[1]
+        y = self.empty(xa.shape[0], Ca + Cb)
+        ws = torch.empty(int(self.lib.a3d_group_norm_ws_floats(B, rows, groups)), dtype=torch.float32, device=self.device)
+        rc = self.lib.a3d_group_norm2_bf16(self._stream(), _p(xa), Ca, _p(xb), Cb, _p(y), _p(gamma), _p(beta), _p(ws), B, rows, groups, eps, 1 if silu else 0)
+        _check(rc, f"a3d_group_norm2_bf16 B={B} rows={rows} C={Ca}+{Cb}")
         return y
 
     def group_norm_sums(self, x, B: int, rows: int, groups: int) -> torch.Tensor:

@@ -628,13 +628,27 @@ class MVUNetMotionModel(nn.Module):
 
     # ------------------------------------------------------------------ forward pieces
     def _resnet(self, x, B2, H, W, pk, semb, rb_rows):
+        """``x``: token rows, or (up blocks, inference) the pair (hidden, skip) whose channel concatenation the reference feeds in
+        (unet_motion_mv_model.py:826-827 / diffusers ``torch.cat([hidden_states, res_hidden_states], dim=1)``): norm1 and the 1x1 shortcut
+        read the two parts in place (a3d_group_norm2 / a3d_gemm2), the concatenated tensor is never written."""
         ops, g = self.ops, self.config.norm_num_groups
         L = H * W
-        h = ops.group_norm(x, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
+        sc = None
+        if isinstance(x, tuple):
+            xa, xb = x
+            sc = ops.gemm2(xa, xb, pk.sc[0], pk.sc[1]) if pk.sc is not None else None
+            if sc is None:                      # shape outside the persistent kernel (or no shortcut conv): concatenate after all
+                x = ops.concat(xa, xb)
+                h = ops.group_norm(x, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
+            else:
+                h = ops.group_norm2(xa, xb, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
+        else:
+            h = ops.group_norm(x, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
         tp = ops.gemm(semb, pk.temb[0], pk.temb[1])                       # time_emb_proj(SiLU(temb))
         h, _, _ = ops.conv3x3(h, B2, H, W, pk.c1[0], pk.c1[1], rowbias=tp, rb_div=rb_rows * L)
         h = ops.group_norm(h, B2, L, pk.n2[0], pk.n2[1], g, pk.eps, True)
-        sc = x if pk.sc is None else ops.gemm(x, pk.sc[0], pk.sc[1])
+        if sc is None:
+            sc = x if pk.sc is None else ops.gemm(x, pk.sc[0], pk.sc[1])
         out, _, _ = ops.conv3x3(h, B2, H, W, pk.c2[0], pk.c2[1], residual=sc)
         return out
 
@@ -1196,8 +1210,11 @@ class MVUNetMotionModel(nn.Module):
         lvl = len(sizes) - 1
         for blk, pk in zip(self.up_blocks, P.up):
             for j, rp in enumerate(pk.resnets):
-                x = ops.concat(x, skips.pop())
-                x = layer(x, rp, pk.t2d[j] if pk.t2d is not None else None, pk.motion[j], h_, w_)
+                skip = skips.pop()
+                # inference on an op set with the two-source kernels: no concatenation pass (the pair goes to _resnet); training forwards
+                # (autograd op set, checkpointed layers take one tensor) keep the concat
+                pair = self._active_ops is None and hasattr(ops, "gemm2") and hasattr(ops, "group_norm2")
+                x = layer((x, skip) if pair else ops.concat(x, skip), rp, pk.t2d[j] if pk.t2d is not None else None, pk.motion[j], h_, w_)
             if pk.up is not None:
                 # the reference passes the next skip's size whenever a latent side is not a multiple of 2^(levels-1);
                 # when it is, that size is the plain 2x, so always naming it is the same arithmetic

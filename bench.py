@@ -114,6 +114,10 @@ class TimedOps:
     def _shape(name, a, k):
         if name in ("gemm", "gemm_geglu"):
             return f"{name} M={a[0].shape[0]} N={a[1].shape[0]} K={a[0].shape[1]}" + (" +res" if k.get("residual") is not None else "") + (" +rowbias" if k.get("rowbias") is not None else "")
+        if name == "gemm2":
+            return f"gemm M={a[0].shape[0]} N={a[2].shape[0]} K={a[0].shape[1]}+{a[1].shape[1]} (two-source A)"
+        if name == "group_norm2":
+            return f"group_norm ({a[0].shape[0]}, {a[0].shape[1]}+{a[1].shape[1]}) (two-source)"
         if name == "conv3x3":
             return f"conv3x3 B={a[1]} {a[2]}x{a[3]} Cin={a[0].shape[1]} Cout={a[4].shape[0]}" + (f" stride={k['stride']}" if k.get("stride", 1) != 1 else "") + (" up2x" if k.get("up2x") else "") + (" +res" if k.get("residual") is not None else "")
         if name in ("group_norm", "layer_norm", "concat", "temporal_attn"):
@@ -122,8 +126,10 @@ class TimedOps:
 
     @staticmethod
     def _family(name, a, k):
-        if name == "gemm":
+        if name in ("gemm", "gemm2"):
             return "gemm"
+        if name == "group_norm2":
+            return "group_norm"
         if name == "conv3x3":
             return "conv3x3 (nearest-2x up)" if k.get("up2x") else "conv3x3"
         return name
@@ -135,6 +141,13 @@ class TimedOps:
         if name in ("gemm", "gemm_geglu", "gemm_f32out"):
             x, w = a[0], a[1]
             return 2.0 * x.shape[0] * w.shape[0] * x.shape[1], by(x, w, out, k.get("residual"))
+        if name == "gemm2":
+            xa, xb, w = a[0], a[1], a[2]
+            if out is None:
+                return 0.0, 0.0
+            return 2.0 * xa.shape[0] * w.shape[0] * (xa.shape[1] + xb.shape[1]), by(xa, xb, w, out)
+        if name == "group_norm2":
+            return 0.0, 3.0 * by(a[0], a[1])
         if name == "conv3x3":
             x, B, H, W, w = a[:5]
             y = out[0]

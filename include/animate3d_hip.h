@@ -88,6 +88,14 @@ int a3d_gemm_ws_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void
                      void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags,
                      void* ws, int64_t ws_bytes, int64_t* ws_needed);
 
+/* Y[M,N] = [X | X2] W^T + bias with the A operand in two pieces: contraction columns [0, K1) are read from X (row stride ldx), [K1, K) from
+ * X2 (row stride ldx2) — the 1x1 shortcut convolution of an up-block ResnetBlock2D over torch.cat([hidden, skip], dim=1)
+ * (unet_motion_mv_model.py:826-827 / diffusers CrossAttnUpBlockMotion) without materialising the concatenation (round 5).  Served by the
+ * persistent kernel only: A3D_EUNSUPPORTED (M % 256 != 0, too few tiles, ldx / ldx2 / ldw not multiples of 64) means "concatenate and call
+ * a3d_gemm".  K1 % 64 == 0, K % 64 == 0, N % 8 == 0, 16-byte aligned rows.  Bit-identical to a3d_gemm on the concatenated operand. */
+int a3d_gemm2_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* X2, int64_t ldx2, int64_t K1,
+                   const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int flags);
+
 /* Same contraction with an fp32 result: Y[M,N] (float, row stride ldy floats) = alpha * (X W^T + bias).  For logits that must
  * not be rounded to bf16: the single-head 512-wide self-attention of the VAE mid block (diffusers AutoencoderKL, used by
  * pipeline.py:566-579 decode_latents) computes S = Q K^T / sqrt(512) with this, a3d_softmax_rows_f32_bf16, and two more GEMMs.
@@ -175,6 +183,13 @@ int a3d_temporal_attn_sharded_bf16(a3d_stream_t stream, const void* Q, int64_t l
 int64_t a3d_group_norm_ws_floats(int B, int64_t rows, int groups);
 int a3d_group_norm_bf16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                         float* ws, int B, int64_t rows, int C, int groups, float eps, int silu);
+
+/* a3d_group_norm_bf16 over a TWO-SOURCE input: channels [0, Ca) of a row come from Xa ([B*rows, Ca]), channels [Ca, Ca + Cb) from Xb
+ * ([B*rows, Cb]); Y is the normalised [B*rows, Ca + Cb] tensor.  norm1 of an up-block ResnetBlock2D over torch.cat([hidden, skip], dim=1)
+ * (diffusers CrossAttnUpBlockMotion / UpBlockMotion, unet_motion_mv_model.py:826-827) without the concatenation pass (round 5).  A group may
+ * straddle the two sources (1280 + 640 channels in 32 groups of 60); Ca % 8 == 0.  ws as for a3d_group_norm_bf16 with C = Ca + Cb. */
+int a3d_group_norm2_bf16(a3d_stream_t stream, const void* Xa, int Ca, const void* Xb, int Cb, void* Y, const float* gamma,
+                         const float* beta, float* ws, int B, int64_t rows, int groups, float eps, int silu);
 
 /* The two halves of a3d_group_norm_bf16 for a norm whose instance is spread over ranks (the motion module's 3-D GroupNorm of
  * diffusers TransformerTemporalModel.norm under frame sharding): `sums` receives fp64 [B][groups][2] = (sum, sum of squares)
@@ -344,6 +359,8 @@ int a3d_gemm_ws_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void*
                     const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                     void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags,
                     void* ws, int64_t ws_bytes, int64_t* ws_needed);
+int a3d_gemm2_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* X2, int64_t ldx2, int64_t K1,
+                  const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int flags);
 int a3d_gemm_f32out_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                          const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha);
 int a3d_gemm_geglu_f16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
@@ -372,6 +389,8 @@ int a3d_temporal_attn_sharded_f16(a3d_stream_t stream, const void* Q, int64_t ld
                                    int64_t kv_block_stride);
 int a3d_group_norm_f16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                         float* ws, int B, int64_t rows, int C, int groups, float eps, int silu);
+int a3d_group_norm2_f16(a3d_stream_t stream, const void* Xa, int Ca, const void* Xb, int Cb, void* Y, const float* gamma,
+                        const float* beta, float* ws, int B, int64_t rows, int groups, float eps, int silu);
 int a3d_group_norm_sums_f16(a3d_stream_t stream, const void* X, float* ws, double* sums, int B, int64_t rows, int C, int groups);
 int a3d_group_norm_apply_f16(a3d_stream_t stream, const void* X, void* Y, const float* gamma, const float* beta,
                               const float* stats, int B, int64_t rows, int C, int groups, int silu);

@@ -689,3 +689,37 @@ def test_fp16_storage_norms_and_elementwise(ops16, ref):
         xr = rnd(2 * 3 * 8 * 8, 4, seed=9, dtype=H16)
         out = ops16.unpack_out(xr, 2, 4, 3, 8, 8, src)
         assert out.dtype == src and ulp(out, ref.unpack_out(xr, 2, 4, 3, 8, 8, src), 3)
+
+
+@pytest.mark.parametrize("M,Ka,Kb,N", [(32768, 1280, 640, 640), (65536, 640, 320, 320), (8192, 1280, 1280, 1280), (65536, 320, 320, 320)])
+def test_gemm_two_source_a_operand(ops, ref, M, Ka, Kb, N):
+    """a3d_gemm2: [xa | xb] w^T + bias read from the two parts (the 1x1 shortcut conv of an up-block ResNet over cat([hidden, skip], 1),
+    unet_motion_mv_model.py:826-827) — same K order as a3d_gemm on the concatenated operand, so BIT-identical to it; a shape the persistent
+    kernel does not take returns None (the caller concatenates)."""
+    xa, xb = rnd(M, Ka, seed=71), rnd(M, Kb, seed=72)
+    w, bias = rnd(N, Ka + Kb, seed=73, scale=(Ka + Kb) ** -0.5), rnd(N, seed=74, dtype=torch.float32)
+    cat = ops.concat(xa, xb)
+    want = ops.gemm(cat, w, bias)
+    got = ops.gemm2(xa, xb, w, bias)
+    assert got is not None, "expected the persistent kernel to take this shape"
+    check(f"gemm2 {M}x{N}x({Ka}+{Kb})", got, ref.gemm(cat, w, bias))
+    assert torch.equal(got, want), "two-source GEMM differs from the GEMM over the concatenated operand"
+    assert torch.equal(ops.gemm2(xa, xb, w, None), ops.gemm(cat, w, None))
+    assert ops.gemm2(xa[:300], xb[:300], w, bias) is None          # M % 256 != 0: not the persistent kernel's -> caller falls back
+    if N == 320:
+        assert ops.gemm2(xa[:16384], xb[:16384], w, bias) is None  # 64 tiles on 256 CUs: under the persistent kernel's fill threshold
+
+
+@pytest.mark.parametrize("B,rows,Ca,Cb", [(8, 1024, 1280, 640), (16, 4096, 640, 320), (4, 256, 1280, 1280), (8, 4096, 320, 320)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_group_norm_two_source(ops, ref, B, rows, Ca, Cb, silu):
+    """a3d_group_norm2: GroupNorm(+SiLU) of cat([xa, xb], 1) read from its parts — groups that straddle the boundary included (1280 + 640
+    channels: 32 groups of 60) — bit-identical to a3d_group_norm of the concatenated tensor (same partial sums in the same order)."""
+    xa, xb = rnd(B * rows, Ca, seed=81), rnd(B * rows, Cb, seed=82)
+    C = Ca + Cb
+    gamma, beta = rnd(C, seed=83, dtype=torch.float32), rnd(C, seed=84, dtype=torch.float32)
+    cat = ops.concat(xa, xb)
+    want = ops.group_norm(cat, B, rows, gamma, beta, 32, 1e-5, silu)
+    got = ops.group_norm2(xa, xb, B, rows, gamma, beta, 32, 1e-5, silu)
+    check(f"group_norm2 B{B} rows{rows} {Ca}+{Cb} silu={silu}", got, ref.group_norm(cat, B, rows, gamma, beta, 32, 1e-5, silu))
+    assert torch.equal(got, want)

@@ -48,6 +48,12 @@ class TorchRefOps:
             return out
         return y
 
+    def gemm2(self, xa, xb, w, bias=None):
+        return self.gemm(torch.cat([xa, xb], dim=1), w, bias)
+
+    def group_norm2(self, xa, xb, B, rows, gamma, beta, groups, eps, silu):
+        return self.group_norm(torch.cat([xa, xb], dim=1), B, rows, gamma, beta, groups, eps, silu)
+
     @staticmethod
     def interleave_geglu(w):
         n = w.shape[0] // 2
