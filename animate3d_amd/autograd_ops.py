@@ -19,6 +19,7 @@ class over ``tests/torch_ops.TorchRefOps`` to check every formula against autogr
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import torch
@@ -69,6 +70,34 @@ class _SinkRows:
 _PLACEHOLDERS = {}
 
 
+class _Deferred:
+    """Weight gradients parked by ``PackW.backward`` while ``deferred_param_grads()`` is active."""
+    active = False
+    dst: list = []
+    src: list = []
+
+
+@contextlib.contextmanager
+def deferred_param_grads():
+    """Around ``loss.backward()`` of a loop that owns its gradient buffers (``train.training_step`` with ``FlatAdamW``): the fp32 gradient
+    slices that ``PackW.backward`` would hand to autograd's AccumulateGrad nodes — one small ``grad.add_`` launch per trainable weight, ~850 per
+    step in the reference's configuration, launch-bound — are parked and added to the parameters' ``.grad`` in ONE multi-tensor call when
+    the backward pass is over.  Not for loops that hang hooks on gradient accumulation (torch DDP): leave those on the plain path."""
+    st = _Deferred
+    prev, st.active = st.active, True
+    try:
+        yield
+    except BaseException:
+        st.dst, st.src = [], []
+        raise
+    finally:
+        st.active = prev
+    dst, src, st.dst, st.src = st.dst, st.src, [], []
+    if dst:
+        with torch.no_grad():
+            torch._foreach_add_(dst, src)
+
+
 def _placeholder(w: torch.Tensor) -> torch.Tensor:
     """A zero of w's dtype expanded to its shape (no memory, no kernel): keeps autograd's edge to PackW alive while the real gradient travels in the sink."""
     key = (w.dtype, w.device)
@@ -87,10 +116,18 @@ class PackW(torch.autograd.Function):
     def forward(ctx, dtype, interleave, sink, *masters):
         ctx.interleave, ctx.sink = interleave, sink
         ctx.rows = [m.shape[0] for m in masters]
-        w = masters[0] if len(masters) == 1 else torch.cat(masters, 0)
-        if interleave:
+        ctx.masters = masters
+        if len(masters) == 1:
+            w = masters[0].to(dtype)
+        else:                        # cast while concatenating: no fp32 copy of the fused operand in between
+            w = torch.empty((sum(ctx.rows), *masters[0].shape[1:]), dtype=dtype, device=masters[0].device)
+            r = 0
+            for m in masters:
+                w[r:r + m.shape[0]].copy_(m)
+                r += m.shape[0]
+        if interleave:               # a row permutation: the same bits whether it runs before or after the cast
             w = _interleave32(w)
-        return w.to(dtype).contiguous()
+        return w.contiguous()
 
     @staticmethod
     def backward(ctx, dw):
@@ -108,7 +145,14 @@ class PackW(torch.autograd.Function):
             g = _deinterleave32(g)
         outs, r = [], 0
         for i, n in enumerate(ctx.rows):
-            outs.append(g[r:r + n] if ctx.needs_input_grad[3 + i] else None)
+            gi = g[r:r + n] if ctx.needs_input_grad[3 + i] else None
+            if gi is not None and _Deferred.active:
+                m = ctx.masters[i]
+                if m.is_leaf and m.grad is not None and m.grad.dtype == gi.dtype and m.grad.shape == gi.shape:
+                    _Deferred.dst.append(m.grad)          # deferred_param_grads(): added after the pass, all weights in one launch
+                    _Deferred.src.append(gi)
+                    gi = None
+            outs.append(gi)
             r += n
         return (None, None, None, *outs)
 
@@ -120,8 +164,7 @@ def _interleave32(w):          # hip_ops.HipOps.interleave_geglu: [h rows | gate
 
 def _deinterleave32(w):
     n = w.shape[0] // 2
-    blk = w.reshape(n // 32, 2, 32, *w.shape[1:])
-    return torch.cat([blk[:, 0].reshape(n, *w.shape[1:]), blk[:, 1].reshape(n, *w.shape[1:])], 0)
+    return w.reshape(n // 32, 2, 32, *w.shape[1:]).transpose(0, 1).reshape(w.shape)          # one copy: [h rows | gate rows]
 
 
 def pack_weight(dtype, masters, interleave: bool = False) -> torch.Tensor:
@@ -129,6 +172,17 @@ def pack_weight(dtype, masters, interleave: bool = False) -> torch.Tensor:
     w = PackW.apply(dtype, interleave, sink, *masters)
     w._a3d_sink = sink
     return w
+
+
+def _param_grad(p, g):
+    """Gradient of a bias / affine vector as a backward returns it: parked under ``deferred_param_grads()`` when ``p`` is the fp32 parameter
+    itself (its ``.grad`` then takes it in the multi-tensor add after the pass), handed to autograd otherwise."""
+    if (g is not None and _Deferred.active and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
+            and p.grad.dtype == g.dtype and p.grad.shape == g.shape):
+        _Deferred.dst.append(p.grad)
+        _Deferred.src.append(g)
+        return None
+    return g
 
 
 def _weight_grad(ctx_sink, w, dw32: torch.Tensor) -> torch.Tensor:
@@ -150,6 +204,52 @@ def weight_rows(w: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
     if sink is not None:
         v._a3d_sink = _SinkRows(sink, r0, w.shape[0])
     return v
+
+
+class _GradCols:
+    """The gradient of a fused projection output [rows, total] whose column pieces feed different kernels (K | V | Q | Q_i2v of one GEMM):
+    ONE buffer, allocated by the first backward that writes a piece.  An attention backward that is the only consumer of a piece writes
+    its dQ / dK / dV straight into that piece's columns (``hip_ops.flash_attn_bwd(dq_out=...)``); ``_SplitCols.backward`` copies in whatever
+    arrives as a separate tensor (a piece with several consumers: autograd has summed their gradients) and zeroes pieces nobody used.
+    Plain slicing costs, per piece, a zero-filled full-width tensor plus a copy, and a full-width add per extra piece."""
+    __slots__ = ("base", "rows", "bounds", "uses", "buf")
+
+    def __init__(self, base, rows: int, bounds):
+        self.base, self.rows, self.bounds = base, rows, tuple(bounds)
+        self.uses = [0] * (len(bounds) - 1)          # consumers that can write in place (counted in their forward)
+        self.buf = None
+
+    def piece(self, i: int, buf=None) -> torch.Tensor:
+        if buf is None:
+            if self.buf is None:
+                self.buf = self.base.empty(self.rows, self.bounds[-1])
+            buf = self.buf
+        return buf[:, self.bounds[i]:self.bounds[i + 1]]
+
+
+class _SplitCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hold, x):
+        ctx.hold = hold
+        ctx.set_materialize_grads(False)
+        b = hold.bounds
+        return tuple(x[:, b[i]:b[i + 1]] for i in range(len(b) - 1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        hold = ctx.hold
+        buf, hold.buf = hold.buf, None
+        if buf is None:
+            if all(g is None for g in gs):
+                return None, None
+            buf = hold.base.empty(hold.rows, hold.bounds[-1])
+        for i, g in enumerate(gs):
+            dst = hold.piece(i, buf)
+            if g is None:
+                dst.zero_()
+            elif not (g.data_ptr() == dst.data_ptr() and g.shape == dst.shape and g.stride() == dst.stride()):
+                dst.copy_(g)             # (else: written in place by the piece's only consumer)
+        return None, buf
 
 
 class _Gemm(torch.autograd.Function):
@@ -197,7 +297,7 @@ class _Gemm(torch.autograd.Function):
             db = base.colsum(dy, ctx.alpha)
         if need[4]:
             dres = dy if ctx.beta == 1.0 else base.scaled(_c(dy), ctx.beta)
-        return None, dx, dw, db, dres, None, dalpha, None, None, None
+        return None, dx, dw, _param_grad(bias, db), dres, None, dalpha, None, None, None
 
 
 class _GemmGeglu(torch.autograd.Function):
@@ -218,7 +318,7 @@ class _GemmGeglu(torch.autograd.Function):
         dx = base.gemm(dp, aops.transposed_weight(w_il)) if need[1] else None
         dw = _weight_grad(ctx.w_sink, w_il, base.wgrad(dp, x)) if need[2] else None
         db = base.colsum(dp) if need[3] else None
-        return None, dx, dw, db
+        return None, dx, dw, _param_grad(b_il, db)
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -264,6 +364,10 @@ class _FlashAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, aops, q, k, v, out_in, qmap, kmap, groups, heads, q_len, kv_len, out_scale, may_keep_out=True):
         ctx.aops, ctx.args = aops, (qmap, kmap, groups, heads, q_len, kv_len, out_scale)
+        ctx.pieces = tuple(getattr(t, "_a3d_gcols", None) for t in (q, k, v))
+        for tag in ctx.pieces:
+            if tag is not None:
+                tag[0].uses[tag[1]] += 1
         if out_in is None:
             # the forward hands its log-sum-exp to the backward (and autograd keeps the output anyway, as the next GEMM's input): the
             # backward's statistics pass — a third of its time at head_dim 40 — is not run
@@ -296,8 +400,16 @@ class _FlashAttn(torch.autograd.Function):
             # query groups that differ only in g % gdiv read the same K/V rows when the map ignores that index (gb == 0):
             # the F frames of a video in the first-frame branches
             g_share = kmap.gdiv if (kmap.gb == 0 and kmap.gdiv > 1 and groups % kmap.gdiv == 0) else 1
+            # pieces of a fused projection output that only this attention reads: their gradient is written into the columns of the
+            # projection output's gradient buffer (_GradCols) instead of a tensor of its own
+            inplace = {}
+            pq, pk_, pv_ = (tag if tag is not None and tag[0].uses[tag[1]] == 1 else None for tag in ctx.pieces)
+            if pq is not None and need[1]:
+                inplace["dq_out"] = pq[0].piece(pq[1])
+            if pk_ is not None and pv_ is not None and (need[2] or need[3]):
+                inplace["dk_out"], inplace["dv_out"] = pk_[0].piece(pk_[1]), pv_[0].piece(pv_[1])
             dq, dk, dv = base.flash_attn_bwd(q, k, v, _c(dy), qmap, kmap, groups, heads, q_len, kv_len, q_per_kv=g_share, do_scale=out_scale,
-                                             need_dq=need[1], need_dkv=need[2] or need[3], **({} if lse is None else dict(o=o, lse=lse)))
+                                             need_dq=need[1], need_dkv=need[2] or need[3], **({} if lse is None else dict(o=o, lse=lse)), **inplace)
         return None, dq, dk, dv, (dy if need[4] else None), None, None, None, None, None, None, None, None
 
 
@@ -348,13 +460,14 @@ class _GroupNorm(torch.autograd.Function):
         need = ctx.needs_input_grad
         stats = base.group_norm_stats(x, B, rows, groups, eps)
         dx, dg, db = base.group_norm_bwd(x, _c(dy), B, rows, gamma, beta, groups, stats, silu, need_param=need[2] or need[3])
-        return None, (dx if need[1] else None), (dg if need[2] else None), (db if need[3] else None), None, None, None, None, None
+        return (None, (dx if need[1] else None), _param_grad(gamma, dg if need[2] else None), _param_grad(beta, db if need[3] else None),
+                None, None, None, None, None)
 
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, aops, x, gamma, beta, eps, pe1, pe1_div, pe2, pe2_div, two):
-        ctx.aops, ctx.eps = aops, eps
+        ctx.aops, ctx.eps, ctx.beta = aops, eps, beta
         ctx.save_for_backward(x, gamma)
         ctx.set_materialize_grads(False)
         out = aops.base.layer_norm(x, gamma, beta, eps, pe1=pe1, pe1_div=pe1_div, pe2=pe2, pe2_div=pe2_div, two=two)
@@ -369,10 +482,11 @@ class _LayerNorm(torch.autograd.Function):
         if not dys:
             return (None,) * 10
         d = _c(dys[0])
-        if len(dys) > 1:                     # both outputs of a two-encoding call were used: their gradients add
-            d = base.axpby_(_c(dys[1]), d.clone(), 1.0, 1.0)
+        if len(dys) > 1:                     # both outputs of a two-encoding call were used: their gradients add (fp32 sum, one rounding)
+            d = d + dys[1]
         dx, dg, db = base.layer_norm_bwd(x, d, gamma, ctx.eps, need_param=need[2] or need[3])
-        return None, (dx if need[1] else None), (dg if need[2] else None), (db if need[3] else None), None, None, None, None, None, None
+        return (None, (dx if need[1] else None), _param_grad(gamma, dg if need[2] else None), _param_grad(ctx.beta, db if need[3] else None),
+                None, None, None, None, None, None)
 
 
 class _Concat(torch.autograd.Function):
@@ -464,6 +578,17 @@ class AutogradOps:
             raise NotImplementedError("gemm(out=...) has no autograd form")
         alpha_t = alpha if torch.is_tensor(alpha) else None
         return _Gemm.apply(self, x, w, bias, residual, rowbias, alpha_t, self._scalar(alpha) if alpha_t is not None else float(alpha), beta, rb_div)
+
+    def split_cols(self, x, *bounds):
+        """Column pieces [bounds[i], bounds[i+1]) of a fused projection output (``bounds`` from 0 to its width) whose gradients meet again
+        in ONE buffer (_GradCols) instead of one zero-padded full-width tensor per piece summed by autograd."""
+        if not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()) or bounds[0] != 0 or bounds[-1] != x.shape[1]:
+            return tuple(x[:, a:b] for a, b in zip(bounds[:-1], bounds[1:]))
+        hold = _GradCols(self.base, x.shape[0], bounds)
+        outs = _SplitCols.apply(hold, x)
+        for i, o in enumerate(outs):
+            o._a3d_gcols = (hold, i)
+        return outs
 
     def gemm_geglu(self, x, w_il, bias_il):
         return _GemmGeglu.apply(self, x, w_il, bias_il)

@@ -181,7 +181,8 @@ class HipOps:
         if act_dtype not in (torch.bfloat16, torch.float16):
             raise ValueError(f"storage type {act_dtype} is not supported (bfloat16 or float16)")
         self.raw_lib = load_library()
-        self._kv_row_cache = {}      # _shared_kv_rows
+        self._kv_row_cache = {}
+        self._kv_cover_cache = {}      # _shared_kv_rows
         self.act_dtype = act_dtype
         self.lib = _Entry(self.raw_lib, act_dtype == torch.float16)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -213,6 +214,11 @@ class HipOps:
         if t.dtype != self.act_dtype or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
             raise RuntimeError(f"{name}: expected a 2-D {self.act_dtype} CUDA tensor with contiguous rows, got {t.dtype} {tuple(t.shape)} {t.device} strides {t.stride()}")
         return t
+
+    def split_cols(self, x, *bounds):
+        """The column pieces [bounds[i], bounds[i+1]) of a fused projection output as views (the differentiable op set overrides
+        this: autograd_ops.AutogradOps.split_cols collects the pieces' gradients in one buffer)."""
+        return tuple(x[:, a:b] for a, b in zip(bounds[:-1], bounds[1:]))
 
     def empty(self, rows: int, cols: int) -> torch.Tensor:
         return torch.empty((rows, cols), dtype=self.act_dtype, device=self.device)
@@ -538,21 +544,35 @@ class HipOps:
 
     # ---- training path: backward kernels (reference: torch autograd behind train.py:576-590) and the optimiser step
     def flash_attn_bwd(self, q, k, v, do, qmap: RowMap, kmap: RowMap, groups: int, heads: int, q_len: int, kv_len: int, *,
-                       q_per_kv: int = 1, do_scale: float = 1.0, need_dq: bool = True, need_dkv: bool = True, o=None, lse=None):
+                       q_per_kv: int = 1, do_scale: float = 1.0, need_dq: bool = True, need_dkv: bool = True, o=None, lse=None,
+                       dq_out=None, dk_out=None, dv_out=None):
         """Gradients of ``flash_attn`` (same maps): ``do`` = gradient of the output buffer (rows as q), scaled by ``do_scale`` (= the
         forward's out_scale).  Returns (dq [q rows, C] | None, dk, dv [k rows, C] | None); rows of dk / dv that the K/V map never
         reads (e.g. frames > 0 in the first-frame branch) are zero.  ``o`` / ``lse`` (the un-accumulated output and the log-sum-exp of
-        ``flash_attn(with_lse=True)``): the statistics pass is replaced by one elementwise kernel (delta = rowsum(dO * O) per head)."""
+        ``flash_attn(with_lse=True)``): the statistics pass is replaced by one elementwise kernel (delta = rowsum(dO * O) per head).
+        ``dq_out`` / ``dk_out`` + ``dv_out``: [rows, C] views with their own row stride (the column blocks of the gradient of a fused
+        Q|K|V projection output) that the kernel writes instead of fresh tensors; they are returned."""
         q, k, v, do = self._act(q, "attn_bwd.q"), self._act(k, "attn_bwd.k"), self._act(v, "attn_bwd.v"), self._act(do, "attn_bwd.do")
         C = q.shape[1]
         D = C // heads
         assert k.stride(0) == v.stride(0) and do.shape == q.shape
-        # rows the query map never reaches (none in the model's calls) must still come back defined
-        dq = (self.empty(q.shape[0], C) if q.shape[0] == groups * q_len else torch.zeros((q.shape[0], C), dtype=self.act_dtype, device=self.device)) if need_dq else None
-        dk = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
-        dv = torch.zeros((k.shape[0], C), dtype=self.act_dtype, device=self.device) if need_dkv else None
+        def grad_buf(out, rows, covered):
+            # rows the map never reaches must still come back defined (zero): the query map reaches all of them in the model's calls, the
+            # K / V map does not in the first-frame branches
+            if out is not None:
+                assert out.shape == (rows, C) and out.stride(1) == 1 and out.dtype == self.act_dtype and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0
+                if not covered:
+                    out.zero_()
+                return out
+            return self.empty(rows, C) if covered else torch.zeros((rows, C), dtype=self.act_dtype, device=self.device)
+        assert (dk_out is None) == (dv_out is None)
+        dq = grad_buf(dq_out, q.shape[0], q.shape[0] == groups * q_len) if need_dq else None
+        kv_covered = need_dkv and self._kv_map_covers(kmap, groups, q_per_kv, kv_len, k.shape[0])
+        dk = grad_buf(dk_out, k.shape[0], kv_covered) if need_dkv else None
+        dv = grad_buf(dv_out, k.shape[0], kv_covered) if need_dkv else None
+        assert dk is None or dk.stride(0) == dv.stride(0)
         qm, km, dom = qmap.c(q.stride(0)), kmap.c(k.stride(0)), qmap.c(do.stride(0))
-        dqm, dkm = qmap.c(C), kmap.c(C)
+        dqm, dkm = qmap.c(dq.stride(0) if dq is not None else C), kmap.c(dk.stride(0) if dk is not None else C)
         flags = 0
         if lse is not None:
             assert o is not None and lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == groups * heads * q_len
@@ -589,6 +609,18 @@ class HipOps:
             return dq, dk, dv
         run(dq, dk, dv, dkm, q_per_kv, flags)
         return dq, dk, dv
+
+    def _kv_map_covers(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int, rows: int) -> bool:
+        """True when the keys the attention reads are ALL ``rows`` rows of K / V, each once: then the backward kernel writes every row
+        of dK / dV and they need no zero fill (decided once per map on the device, cached)."""
+        if (groups // q_per_kv) * kv_len != rows:
+            return False
+        key = (kmap.gdiv, kmap.ga, kmap.gb, kmap.seg_len, kmap.seg_stride, groups, q_per_kv, kv_len, rows)
+        hit = self._kv_cover_cache.get(key)
+        if hit is None:
+            idx = self._shared_kv_rows(kmap, groups, q_per_kv, kv_len)
+            hit = self._kv_cover_cache[key] = bool(int(idx.min()) >= 0 and int(idx.max()) < rows and torch.unique(idx).numel() == rows)
+        return hit
 
     def _shared_kv_rows(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int) -> torch.Tensor:
         """Rows of the K / V tensor that the first query group of every sharing set reads, in (set, key) order (cached per map)."""

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .autograd_ops import deferred_param_grads
 from .denoise import randn_like_reference
 
 TRAINABLE_MODULES = ("i2v.", "motion_modules.")        # configs/training/train.yaml: trainable_modules
@@ -208,7 +209,8 @@ def training_step(unet, optimizer: FlatAdamW, latents: torch.Tensor, text_embeds
     noisy, t, ehs, noise = _sample_batch(latents, text_embeds, alphas_cumprod, generator, noise, timesteps)
     optimizer.zero_grad()
     loss = _loss(unet, noisy, t, ehs, cameras, image_embeds, noise, latents.shape, num_views, i2v_cond_time_zero)
-    optimizer.scale(loss).backward()
+    with deferred_param_grads():          # weight gradients land in the flat buffer in one multi-tensor add after the pass
+        optimizer.scale(loss).backward()
     world = optimizer.all_reduce_grads(group)
     info = optimizer.step(world)
     info["loss"] = float(loss.detach())

@@ -693,16 +693,16 @@ class MVUNetMotionModel(nn.Module):
 
         if not vsh:
             kvq = ops.gemm(x, w_kvq)
-            k, v, q = kvq[:, :C], kvq[:, C:2 * C], kvq[:, 2 * C:3 * C]
+            k, v, q, *qi = ops.split_cols(kvq, *range(0, kvq.shape[1] + 1, C))
             oa = {} if out_a is None else {"out": out_a}
             oi = {} if out_ai is None else {"out": out_ai}
             a = ops.flash_attn(q, k, v, qm, qm, b * F, heads, n * L, n * L, **oa)
             ai = None
             if i2v and fsh:
                 kv0, km0 = first_frame_kv()
-                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, n * L, **oi)
+                ai = ops.flash_attn(qi[0], kv0[:, :C], kv0[:, C:], qm, km0, b * F, heads, n * L, n * L, **oi)
             elif i2v:
-                ai = ops.flash_attn(kvq[:, 3 * C:4 * C], k, v, qm, k0, b * F, heads, n * L, n * L, **oi)
+                ai = ops.flash_attn(qi[0], k, v, qm, k0, b * F, heads, n * L, n * L, **oi)
             return a, ai, (overlap() if overlap is not None else None)
         if par.gather_tokens:
             # gather the (normalised) INPUT tokens [rows_local, C] and project K|V for all N views locally: half the
@@ -831,7 +831,8 @@ class MVUNetMotionModel(nn.Module):
             else:
                 kvq = ops.gemm(nimg, a.qkv_img)
                 k0 = RowMap(gdiv=F, ga=F * L, gb=0, seg_len=L, seg_stride=0)
-                ai = ops.flash_attn(kvq[:, 2 * C:], kvq[:, :C], kvq[:, C:2 * C], qm, k0, V * F, a.heads, L, L, **blk(nblk - 1))
+                ki, vi, qi = ops.split_cols(kvq, 0, C, 2 * C, 3 * C)
+                ai = ops.flash_attn(qi, ki, vi, qm, k0, V * F, a.heads, L, L, **blk(nblk - 1))
             if not merged:
                 out = ops.gemm(ai, a.oimg[0], a.oimg[1], residual=out, alpha=ci, beta=1.0)
         if merged:

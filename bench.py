@@ -98,7 +98,7 @@ class TimedOps:
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
-        if not (self.profile and callable(fn)) or name.startswith("_") or name in ("empty", "interleave_geglu"):
+        if not (self.profile and callable(fn)) or name.startswith("_") or name in ("empty", "interleave_geglu", "split_cols"):
             return fn
 
         def timed(*a, **k):

@@ -542,3 +542,101 @@ def test_packed_weight_with_a_sink_consumer_and_a_sliced_consumer_keeps_both_gra
     ((x @ w_ref.t()).sum() * 2.0 + (x @ w_ref[:6].t()).sum() * 3.0).backward()
     assert torch.allclose(m1.grad, w_ref.grad[:6], atol=1e-6) and torch.allclose(m2.grad, w_ref.grad[6:], atol=1e-6)
     assert w._a3d_sink.grad32 is None
+
+
+def test_split_cols_collects_the_piece_gradients_in_one_buffer():
+    """AutogradOps.split_cols on a fused K | V | Q | Q_i2v projection output: Q and Q_i2v feed one attention each (their dQ is written
+    straight into the columns of the projection output's gradient buffer), K and V feed both (autograd sums the two dK / dV, the sum is
+    copied in), an unused piece comes back zero.  Same gradient as plain slicing."""
+    from animate3d_amd.autograd_ops import AutogradOps
+    from animate3d_amd.hip_ops import RowMap
+    torch.manual_seed(0)
+    base = TorchRefOps(torch.float32, torch.device("cpu"))
+    aops = AutogradOps(base)
+    heads, C, groups, S = 2, 16, 3, 10
+    rows = groups * S
+    m = RowMap(gdiv=1, ga=S, gb=0, seg_len=S, seg_stride=0)
+    x0 = torch.randn(rows, 5 * C)
+    wo = torch.randn(rows, C)
+
+    calls = []
+    real_bwd = base.flash_attn_bwd
+
+    def spy(*a, **k):
+        calls.append({n: k.get(n) is not None for n in ("dq_out", "dk_out", "dv_out")})
+        return real_bwd(*a, **k)
+    base.flash_attn_bwd = spy
+
+    def run(split):
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.0                                   # a non-leaf, like the projection GEMM's output
+        k, v, q, qi, unused = split(h)
+        a = aops.flash_attn(q, k, v, m, m, groups, heads, S, S)
+        ai = aops.flash_attn(qi, k, v, m, m, groups, heads, S, S)
+        ((a * wo).sum() + 2.0 * (ai * wo).sum()).backward()
+        return x.grad
+
+    g_plain = run(lambda h: tuple(h[:, i * C:(i + 1) * C] for i in range(5)))
+    assert all(not any(c.values()) for c in calls)
+    calls.clear()
+    g_split = run(lambda h: aops.split_cols(h, *range(0, 5 * C + 1, C)))
+    assert torch.allclose(g_split, g_plain, atol=1e-6)
+    assert torch.equal(g_split[:, 4 * C:], torch.zeros(rows, C))
+    # both attentions wrote their dQ in place; K / V have two consumers, so neither wrote dK / dV in place
+    assert calls == [{"dq_out": True, "dk_out": False, "dv_out": False}] * 2
+
+    # one consumer per piece (the motion module's spatial branch): dQ, dK and dV are all written in place
+    calls.clear()
+    x = x0[:, :3 * C].clone().requires_grad_(True)
+    k, v, q = aops.split_cols(x * 1.0, 0, C, 2 * C, 3 * C)
+    (aops.flash_attn(q, k, v, m, m, groups, heads, S, S) * wo).sum().backward()
+    assert calls == [{"dq_out": True, "dk_out": True, "dv_out": True}]
+    xr = x0[:, :3 * C].clone().requires_grad_(True)
+    (aops.flash_attn(xr[:, 2 * C:], xr[:, :C], xr[:, C:2 * C], m, m, groups, heads, S, S) * wo).sum().backward()
+    assert torch.allclose(x.grad, xr.grad, atol=1e-6)
+    # no gradient wanted: plain views, nothing recorded
+    with torch.no_grad():
+        assert not hasattr(aops.split_cols(x0, 0, C, 5 * C)[0], "_a3d_gcols")
+
+
+def test_deferred_param_grads_equal_autograd_accumulation():
+    """``autograd_ops.deferred_param_grads()`` (what train.training_step wraps its backward in): the weight / bias / affine gradients that
+    PackW and the kernel backwards park are added to ``.grad`` in one multi-tensor call after the pass — the same numbers AccumulateGrad
+    leaves, nothing parked outside the context, nothing left parked after it."""
+    from animate3d_amd import autograd_ops as A
+    ocfg, ref, model = _pair(2, 2, (8, 8), motion_image_attn=True)
+    inp = O.synthetic_inputs(ocfg, 2, 2, 2, (8, 8), seed=3, cfg_doubled=False)
+    target = torch.randn(2, 4, 1, 8, 8, generator=torch.Generator().manual_seed(1))
+    model.enable_training()
+    params = {k: p for k, p in model.named_parameters() if p.requires_grad}
+    _loss(model, inp, target).backward()                       # plain: AccumulateGrad creates every .grad
+    assert not A._Deferred.dst and not A._Deferred.active
+    g0 = {k: p.grad.clone() for k, p in params.items()}
+    assert len(g0) > 50 and sum(bool(v.abs().sum() > 0) for v in g0.values()) > len(g0) // 2
+    for p in params.values():
+        p.grad.zero_()
+
+    parked = []
+    real = torch._foreach_add_
+
+    def spy(dst, src, *a, **k):
+        parked.append(len(dst))
+        return real(dst, src, *a, **k)
+    torch._foreach_add_ = spy
+    try:
+        with A.deferred_param_grads():
+            _loss(model, inp, target).backward()
+            assert A._Deferred.active and len(A._Deferred.dst) > 50
+    finally:
+        torch._foreach_add_ = real
+    assert parked and parked[0] > 50 and not A._Deferred.dst and not A._Deferred.src and not A._Deferred.active
+    for k, p in params.items():
+        assert torch.equal(p.grad, g0[k]), k
+
+    # an exception inside the context drops what was parked instead of adding half a pass
+    with pytest.raises(RuntimeError, match="stop"):
+        with A.deferred_param_grads():
+            A._Deferred.dst.append(next(iter(params.values())).grad)
+            A._Deferred.src.append(torch.ones(()))
+            raise RuntimeError("stop")
+    assert not A._Deferred.dst and not A._Deferred.src and not A._Deferred.active

@@ -29,6 +29,9 @@ class TorchRefOps:
     def _o(self, t):
         return t.to(self.act_dtype)
 
+    def split_cols(self, x, *bounds):
+        return tuple(x[:, a:b] for a, b in zip(bounds[:-1], bounds[1:]))
+
     def empty(self, rows, cols):
         return torch.empty((rows, cols), dtype=self.act_dtype, device=self.device)
 
@@ -228,13 +231,22 @@ class TorchRefOps:
         o = self.flash_attn(q, k, v, qmap, kmap, groups, heads, q_len, kv_len)
         return self.flash_attn(q, k2, v2, qmap, kmap2, groups, heads, q_len, kv_len2, out=o, out_scale=out_scale2, accumulate=True)
 
-    def flash_attn_bwd(self, q, k, v, do, qmap, kmap, groups, heads, q_len, kv_len, *, q_per_kv=1, do_scale=1.0, need_dq=True, need_dkv=True):
+    def flash_attn_bwd(self, q, k, v, do, qmap, kmap, groups, heads, q_len, kv_len, *, q_per_kv=1, do_scale=1.0, need_dq=True, need_dkv=True,
+                       dq_out=None, dk_out=None, dv_out=None):
         with torch.enable_grad():
             qf, kf, vf = (t.detach().float().clone().requires_grad_(True) for t in (q, k, v))
             o = TorchRefOps(torch.float32, q.device).flash_attn(qf, kf, vf, qmap, kmap, groups, heads, q_len, kv_len, out_scale=do_scale)
             o.backward(do.float())
         z = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
-        return (self._o(z(qf)) if need_dq else None, self._o(z(kf)) if need_dkv else None, self._o(z(vf)) if need_dkv else None)
+
+        def put(g, out):          # HipOps writes the caller's [rows, C] view (own row stride) and returns it
+            g = self._o(g)
+            if out is None:
+                return g
+            out.copy_(g)
+            return out
+        assert (dk_out is None) == (dv_out is None)
+        return (put(z(qf), dq_out) if need_dq else None, put(z(kf), dk_out) if need_dkv else None, put(z(vf), dv_out) if need_dkv else None)
 
     def temporal_attn_bwd(self, q, k, v, do, videos, frames, L, heads):
         with torch.enable_grad():

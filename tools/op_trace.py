@@ -22,7 +22,7 @@ class Tracer:
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
-        if not callable(fn) or name.startswith("_") or name in ("empty", "interleave_geglu"):
+        if not callable(fn) or name.startswith("_") or name in ("empty", "interleave_geglu", "split_cols"):
             return fn
         rf = getattr(self._ref, name, None)
 
