@@ -45,6 +45,59 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
   if (ty == 0 && c < cols) atomicAdd(out + c, alpha * (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]));
 }
 
+// Widths that are multiples of 320 (every bias of the model): TPR lanes own a row of a 40 * TPR column tile, five 16-byte chunks per lane
+// (chunk = sub + TPR * i: TPR * 16 contiguous bytes per step), a wave adds 64 / TPR rows per step.  The kernel above reads 2 bytes per lane
+// and load (1.7 TB/s on [65536, 320]).
+template <int TPR>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const uint16_t* __restrict__ X, int64_t ldx, int64_t rows, int64_t rows_per_block,
+                                                           float* __restrict__ out, float alpha) {
+  constexpr int RPW = 64 / TPR;
+  __shared__ float red[4][40 * TPR];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane % TPR, rsel = lane / TPR;
+  const int64_t c0 = (int64_t)blockIdx.x * (40 * TPR);
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r_end = min(rows, r_beg + rows_per_block);
+  float acc[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+#pragma unroll 2
+  for (int64_t r = r_beg + wid * RPW + rsel; r < r_end; r += 4 * RPW) {
+    const uint16_t* xr = X + r * ldx + c0;
+    u32x4_t v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = ld_stream(xr + (sub + TPR * i) * 8);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] += (j & 1) ? hi16(v[i][j >> 1]) : lo16(v[i][j >> 1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = 32; o >= TPR; o >>= 1) acc[i][j] += __shfl_xor(acc[i][j], o);
+      if (rsel == 0) red[wid][(sub + TPR * i) * 8 + j] = acc[i][j];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 40 * TPR; c += 256) atomicAdd(out + c0 + c, alpha * ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])));
+}
+
+template <int TPR>
+int launch_colsum_rows(hipStream_t s, const uint16_t* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha) {
+  const int64_t bx = cols / (40 * TPR);
+  int64_t by = rows / (16 * (64 / TPR));                      // >= 4 steps of every wave per block
+  const int64_t cap = bx >= 1024 ? 1 : 1024 / bx;
+  if (by > cap) by = cap;
+  if (by < 1) by = 1;
+  const int64_t rpb = (rows + by - 1) / by;
+  colsum_rows_kernel<TPR><<<dim3((unsigned)bx, (unsigned)by), dim3(256), 0, s>>>(X, ldx, rows, rpb, out, alpha);
+  return a3d_launch_status();
+}
+
 // ------------------------------------------------------------------ GEGLU backward on the interleaved projection
 // P [M, 2N]: column blocks of 64 = [32 h | 32 gate] (HipOps.interleave_geglu); y = h * gelu(gate);  dP = [dY gelu(gate) | dY h gelu'(gate)]
 A3D_DEV float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
@@ -145,6 +198,136 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const LNBParams p) 
       if (c < C) { atomicAdd(p.dgamma + c, dg[k]); atomicAdd(p.dbeta + c, db[k]); }
     }
   }
+}
+
+// Sub-wave rows for the model's widths C = 320 / 640 / 1280 = 40 * LPR (the forward's layout, norms.hip layer_norm_rows_kernel): LPR lanes
+// own one row — five 16-byte chunks of X and five of dY per lane, chunk = sub + LPR * i, so a step of the wave reads LPR * 16 contiguous
+// bytes per row and ten loads per lane are in flight — and a wave handles 64 / LPR rows per batch.  The one-wave-per-row kernel above
+// reads 2 bytes per lane and load (0.8 TB/s at C = 320) and ends in 2 C atomics per wave; here the workgroup reduces its dgamma / dbeta
+// partials through LDS first (2 C atomics per workgroup, <= 512 workgroups), and frozen affines (PARAM = false) skip that part.
+template <int LPR, bool PARAM>
+__global__ __launch_bounds__(256, 2) void layer_norm_bwd_rows_kernel(const LNBParams p) {
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[PARAM ? 4 : 1][PARAM ? 2 : 1][PARAM ? 40 * LPR : 1];
+  __shared__ __attribute__((aligned(16))) float gsh[PARAM ? 40 * LPR : 4];      // PARAM: gamma is read from LDS (80 accumulator registers per lane)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const int C = p.C;
+  float gar[PARAM ? 1 : 5][8], dg[PARAM ? 5 : 1][8], db[PARAM ? 5 : 1][8];
+  if constexpr (PARAM) {
+    for (int c = threadIdx.x; c < C; c += 256) gsh[c] = p.gamma[c];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = sub + LPR * i;
+      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c * 8), g1 = *reinterpret_cast<const float4*>(p.gamma + c * 8 + 4);
+      gar[i][0] = g0.x; gar[i][1] = g0.y; gar[i][2] = g0.z; gar[i][3] = g0.w; gar[i][4] = g1.x; gar[i][5] = g1.y; gar[i][6] = g1.z; gar[i][7] = g1.w;
+    }
+  }
+  auto gamma8 = [&](int i, float (&g)[8]) {
+    if constexpr (PARAM) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gsh + (sub + LPR * i) * 8), g1 = *reinterpret_cast<const float4*>(gsh + (sub + LPR * i) * 8 + 4);
+      g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = gar[i][j];
+    }
+  };
+  const float inv_c = 1.f / (float)C;
+  const int64_t nbatch = (p.M + RPW - 1) / RPW;
+#pragma unroll 1
+  for (int64_t bt = (int64_t)blockIdx.x * 4 + wid; bt < nbatch; bt += (int64_t)gridDim.x * 4) {
+    const int64_t m = bt * RPW + rsel;
+    const bool ok = m < p.M;
+    const int64_t mm = ok ? m : p.M - 1;
+    u32x4_t xr[5], dr[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xr[i] = ld_stream(p.X + mm * C + (sub + LPR * i) * 8);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dr[i] = ld_stream(p.dY + mm * C + (sub + LPR * i) * 8);
+    float x[5][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { x[i][j] = (j & 1) ? hi16(xr[i][j >> 1]) : lo16(xr[i][j >> 1]); sum += x[i][j]; }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { x[i][j] -= mean; sq += x[i][j] * x[i][j]; }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * inv_c + p.eps);
+    const float okf = ok ? 1.f : 0.f;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float g[8];
+      gamma8(i, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dy = (j & 1) ? hi16(dr[i][j >> 1]) : lo16(dr[i][j >> 1]);
+        x[i][j] *= rstd;                                       // x-hat
+        const float gy = dy * g[j];
+        a += gy; b += gy * x[i][j];
+        if constexpr (PARAM) { dg[i][j] = fmaf(dy * okf, x[i][j], dg[i][j]); db[i][j] = fmaf(dy, okf, db[i][j]); }
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    a *= inv_c; b *= inv_c;
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        float g[8];
+        gamma8(i, g);
+        u32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)         // dY is decoded again from its packed registers instead of keeping 40 products alive
+          o[j] = pack16(rstd * (lo16(dr[i][j]) * g[2 * j] - a - x[i][2 * j] * b), rstd * (hi16(dr[i][j]) * g[2 * j + 1] - a - x[i][2 * j + 1] * b));
+        st_stream(p.dX + m * C + (sub + LPR * i) * 8, o);
+      }
+    }
+  }
+  if constexpr (PARAM) {
+    // rows of the wave (lanes with the same sub), then the four waves through LDS, then one atomic per channel and workgroup
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = 32; o >= LPR; o >>= 1) { dg[i][j] += __shfl_xor(dg[i][j], o); db[i][j] += __shfl_xor(db[i][j], o); }
+        if (rsel == 0) { red[wid][0][(sub + LPR * i) * 8 + j] = dg[i][j]; red[wid][1][(sub + LPR * i) * 8 + j] = db[i][j]; }
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      atomicAdd(p.dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
+      atomicAdd(p.dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
+    }
+  }
+}
+
+template <int LPR>
+int launch_ln_bwd_rows(hipStream_t s, const LNBParams& p) {
+  const int64_t nbatch = (p.M + 64 / LPR - 1) / (64 / LPR);
+  int64_t blocks = (nbatch + 3) / 4;
+  if (p.dgamma) {
+    if (blocks > 512) blocks = 512;
+    layer_norm_bwd_rows_kernel<LPR, true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  } else {
+    if (blocks > 4096) blocks = 4096;
+    layer_norm_bwd_rows_kernel<LPR, false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  }
+  return a3d_launch_status();
 }
 
 // ------------------------------------------------------------------ GroupNorm (+SiLU) backward, channel-last [B][rows][C]
@@ -453,6 +636,13 @@ extern "C" int A3D_FN(a3d_colsum)(a3d_stream_t stream, const void* X, int64_t ld
   if (!X || !out || rows <= 0 || cols <= 0 || ldx < cols) return A3D_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) { if (hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s); e != hipSuccess) return (int)e; }
+  if (cols % 320 == 0 && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
+    const uint16_t* x = (const uint16_t*)X;
+    if (cols % 2560 == 0) return launch_colsum_rows<64>(s, x, ldx, rows, cols, out, alpha);
+    if (cols % 1280 == 0) return launch_colsum_rows<32>(s, x, ldx, rows, cols, out, alpha);
+    if (cols % 640 == 0) return launch_colsum_rows<16>(s, x, ldx, rows, cols, out, alpha);
+    return launch_colsum_rows<8>(s, x, ldx, rows, cols, out, alpha);
+  }
   const int64_t bx = (cols + 63) / 64;
   int64_t by = (rows + 255) / 256; if (by > 512) by = 512;
   const int64_t rpb = (rows + by - 1) / by;
@@ -482,6 +672,10 @@ extern "C" int A3D_FN(a3d_layer_norm_bwd)(a3d_stream_t stream, const void* X, co
     if (hipError_t e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s); e != hipSuccess) return (int)e;
   }
   LNBParams p{(const uint16_t*)X, (const uint16_t*)dY, gamma, (uint16_t*)dX, dgamma, dbeta, M, C, eps};
+  const bool al16 = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(gamma)) & 15u) == 0;
+  if (al16 && C == 320) return launch_ln_bwd_rows<8>(s, p);
+  if (al16 && C == 640) return launch_ln_bwd_rows<16>(s, p);
+  if (al16 && C == 1280) return launch_ln_bwd_rows<32>(s, p);
   int64_t blocks = (M + 3) / 4; if (blocks > 2048) blocks = 2048;
   const int cpl = (C + 63) / 64;
   if (cpl <= 5) layer_norm_bwd_kernel<5><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);

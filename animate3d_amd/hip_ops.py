@@ -658,10 +658,10 @@ class HipOps:
     def group_norm_stats(self, x, B: int, rows: int, groups: int, eps: float) -> torch.Tensor:
         """fp32 [B, groups, 2] = (mean, rstd) from the fp64 sums kernel (the finalisation is a [B, groups] host-side expression)."""
         sums = self.group_norm_sums(x, B, rows, groups)
-        cnt = float(rows * (x.shape[1] // groups))
-        mean = sums[..., 0] / cnt
-        var = (sums[..., 1] / cnt - mean * mean).clamp_min(0.0)
-        return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).to(torch.float32).contiguous()
+        m = sums / float(rows * (x.shape[1] // groups))                         # fp64 (E[x], E[x^2]); seven small launches in all
+        mean = m[..., 0]
+        rstd = torch.addcmul(m[..., 1], mean, mean, value=-1.0).clamp_min_(0.0).add_(eps).rsqrt_()
+        return torch.stack([mean, rstd], dim=-1).to(torch.float32)
 
     def group_norm_bwd(self, x, dy, B: int, rows: int, gamma, beta, groups: int, stats, silu: bool, need_param: bool = False):
         x, dy = self._act(x, "gn_bwd.x"), self._act(dy, "gn_bwd.dy")

@@ -157,7 +157,34 @@ def test_layer_norm_bwd(ops, ref, M, C):
     check(f"layer_norm_bwd dx {M}x{C}", dx, rx, ELEM_TOL[dt])
     check("layer_norm_bwd dgamma", dg, rg, 1e-4)
     check("layer_norm_bwd dbeta", db, rb, 1e-4)
-    assert ops.layer_norm_bwd(x, dy, gamma, 1e-5, need_param=False)[1] is None
+    dx2, dg2, _ = ops.layer_norm_bwd(x, dy, gamma, 1e-5, need_param=False)            # frozen affine: its own kernel instantiation
+    assert dg2 is None
+    check(f"layer_norm_bwd dx (no parameter gradients) {M}x{C}", dx2, rx, ELEM_TOL[dt])
+
+
+@pytest.mark.parametrize("M,C", [(4099, 320), (1030, 640), (515, 1280)])
+def test_layer_norm_bwd_sub_wave_rows_kernel_tail_and_grid_stride(ops, ref, M, C):
+    """C = 40 * LPR: LPR lanes per row, 64 / LPR rows per wave step; M is not a multiple of the rows per step (masked tail rows must not
+    reach dgamma / dbeta) and, with parameter gradients, large enough that the <= 512 workgroups loop."""
+    dt = ops.act_dtype
+    x, dy = rnd(M, C, seed=11, scale=1.5, dtype=dt) + 0.25, rnd(M, C, seed=12, dtype=dt)
+    gamma = 1.0 + 0.2 * rnd(C, seed=13)
+    rx, rg, rb = ref.layer_norm_bwd(x, dy, gamma, 1e-5)
+    for need in (True, False):
+        dx, dg, db = ops.layer_norm_bwd(x, dy, gamma, 1e-5, need_param=need)
+        check(f"layer_norm_bwd dx {M}x{C} need_param={need}", dx, rx, ELEM_TOL[dt])
+        if need:
+            check("layer_norm_bwd dgamma", dg, rg, 1e-4)
+            check("layer_norm_bwd dbeta", db, rb, 1e-4)
+
+
+@pytest.mark.parametrize("M,N,pad", [(1000, 320, 0), (777, 640, 24), (300, 2560, 0), (129, 3840, 8), (50, 960, 0), (70000, 1280, 0), (3, 320, 0)])
+def test_colsum_16_byte_kernel(ops, ref, M, N, pad):
+    """Bias gradients of widths that are multiples of 320 (every Linear of the model): 16-byte loads, TPR lanes per row."""
+    dt = ops.act_dtype
+    xb = rnd(M, N + pad, seed=21, dtype=dt)
+    x = xb[:, pad:] if pad else xb
+    check(f"colsum {M}x{N} ld={x.stride(0)}", ops.colsum(x, 0.5), ref.colsum(x, 0.5), 1e-4 if M > 10000 else 1e-5)
 
 
 @pytest.mark.parametrize("B,rows,C,silu", [(2, 64, 320, True), (3, 50, 960, True), (2, 4 * 16, 640, False), (1, 33, 2560, True)])
