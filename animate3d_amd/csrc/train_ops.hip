@@ -90,7 +90,7 @@ template <int TPR>
 int launch_colsum_rows(hipStream_t s, const uint16_t* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha) {
   const int64_t bx = cols / (40 * TPR);
   int64_t by = rows / (16 * (64 / TPR));                      // >= 4 steps of every wave per block
-  const int64_t cap = bx >= 1024 ? 1 : 1024 / bx;
+  const int64_t cap = bx >= 512 ? 1 : 512 / bx;          // every workgroup ends in one atomic per column
   if (by > cap) by = cap;
   if (by < 1) by = 1;
   const int64_t rpb = (rows + by - 1) / by;
@@ -343,33 +343,63 @@ A3D_DEV float gn_upstream(float dy, float xh, float gam, float bet, int silu) {
   const float sg = 1.f / (1.f + __expf(-z));
   return dy * sg * (1.f + z * (1.f - sg));
 }
-// pass 1: per-(b, channel) sums over a chunk of rows; thread = channel (coalesced rows), atomics into ws
-__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const GNBParams p) {
-  const int b = blockIdx.z;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.C) return;
-  const int grp = c / p.cg;
-  const float mean = p.stats[((int64_t)b * p.groups + grp) * 2], rstd = p.stats[((int64_t)b * p.groups + grp) * 2 + 1];
-  const float gam = p.gamma[c], bet = p.beta[c];
-  const int64_t r_beg = (int64_t)blockIdx.y * p.rows_per_block, r_end = min(p.rows, r_beg + p.rows_per_block);
-  const uint16_t* x = p.X + ((int64_t)b * p.rows) * p.C + c;
-  const uint16_t* dy = p.dY + ((int64_t)b * p.rows) * p.C + c;
-  float sa = 0.f, sb = 0.f;
-  for (int64_t r = r_beg; r < r_end; ++r) {
-    const float xh = (h2f(x[r * p.C]) - mean) * rstd;
-    const float g = gn_upstream(h2f(dy[r * p.C]), xh, gam, bet, p.silu);
-    sa += g; sb += g * xh;
+// Both passes: a workgroup is rpb rows x (C / 8) 16-byte chunks (rpb = max(1, 256 / (C / 8)): 240 threads at C = 320 / 640 / 960), thread =
+// (row slot, chunk) with the chunk fixed, so that its eight channels' statistics and affine parameters are loop invariants and a row step of
+// the workgroup reads rpb * C * 2 contiguous bytes of X and of dY.
+struct GNChan { float mean[8], rstd[8], gam[8], bet[8]; };
+A3D_DEV void gn_chan_load(const GNBParams& p, int b, int c0, GNChan& k) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int grp = (c0 + e) / p.cg;
+    k.mean[e] = p.stats[((int64_t)b * p.groups + grp) * 2];
+    k.rstd[e] = p.stats[((int64_t)b * p.groups + grp) * 2 + 1];
+    k.gam[e] = p.gamma[c0 + e];
+    k.bet[e] = p.beta[c0 + e];
   }
-  atomicAdd(p.ws + ((int64_t)b * p.C + c) * 2, sa);
-  atomicAdd(p.ws + ((int64_t)b * p.C + c) * 2 + 1, sb);
+}
+// pass 1: per-(b, channel) sums of g and g * x-hat over the workgroup's rows.  Every thread leaves its 8 x 2 partial sums in LDS
+// ([row slot][C][2], dynamic: blockDim * 64 bytes), then consecutive threads add up the row slots of consecutive ws entries: the 2 C
+// atomics of a workgroup go out as whole cache lines (one lane per 64-byte segment, as the thread = chunk layout would issue them, is
+// what made the first version of this kernel 2.5 x slower than the 2-byte-load kernel it replaced).
+__global__ __launch_bounds__(1024) void gn_bwd_sums_kernel(const GNBParams p) {
+  extern __shared__ float red[];
+  const int nch = p.C / 8;
+  const int ch = threadIdx.x % nch, rr = threadIdx.x / nch, rpb = blockDim.x / nch;
+  const int b = blockIdx.y, c0 = ch * 8;
+  GNChan k;
+  gn_chan_load(p, b, c0, k);
+  const int64_t r_beg = (int64_t)blockIdx.x * p.rows_per_block, r_end = min(p.rows, r_beg + p.rows_per_block);
+  const uint16_t* x = p.X + ((int64_t)b * p.rows) * p.C + c0;
+  const uint16_t* dy = p.dY + ((int64_t)b * p.rows) * p.C + c0;
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+#pragma unroll 2
+  for (int64_t r = r_beg + rr; r < r_end; r += rpb) {
+    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(x + r * p.C), dv = *reinterpret_cast<const u32x4_t*>(dy + r * p.C);   // (pass 2 reads both again)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (((e & 1) ? hi16(xv[e >> 1]) : lo16(xv[e >> 1])) - k.mean[e]) * k.rstd[e];
+      const float g = gn_upstream((e & 1) ? hi16(dv[e >> 1]) : lo16(dv[e >> 1]), xh, k.gam[e], k.bet[e], p.silu);
+      sa[e] += g; sb[e] = fmaf(g, xh, sb[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) *reinterpret_cast<float2*>(red + ((int64_t)rr * p.C + c0 + e) * 2) = make_float2(sa[e], sb[e]);
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * p.C; t += blockDim.x) {
+    float v = red[t];
+    for (int q = 1; q < rpb; ++q) v += red[q * 2 * p.C + t];
+    atomicAdd(p.ws + (int64_t)b * 2 * p.C + t, v);
+  }
 }
 // pass 2: dx = rstd * (g gamma - s1/n - x-hat s2/n) with the group sums s1 = sum_c gamma_c A_c, s2 = sum_c gamma_c B_c
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNBParams p) {
+__global__ __launch_bounds__(1024) void gn_bwd_apply_kernel(const GNBParams p) {
   __shared__ float gs[2][64];
   const int b = blockIdx.y;
-  if (threadIdx.x < p.groups) {
+  if ((int)threadIdx.x < p.groups) {
     float s1 = 0.f, s2 = 0.f;
-    for (int c = threadIdx.x * p.cg; c < (threadIdx.x + 1) * p.cg; ++c) {
+    for (int c = threadIdx.x * p.cg; c < ((int)threadIdx.x + 1) * p.cg; ++c) {
       const float gam = p.gamma[c];
       s1 += gam * p.ws[((int64_t)b * p.C + c) * 2];
       s2 += gam * p.ws[((int64_t)b * p.C + c) * 2 + 1];
@@ -378,34 +408,32 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNBParams p) {
     gs[0][threadIdx.x] = s1 * inv_n; gs[1][threadIdx.x] = s2 * inv_n;
   }
   __syncthreads();
-  const int chunks = p.C / 8;
-  const int64_t total = p.rows * chunks;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t r = idx / chunks;
-    const int c0 = (int)(idx % chunks) * 8;
-    const int64_t off = ((int64_t)b * p.rows + r) * p.C + c0;
-    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(p.X + off);
-    const u32x4_t dv = *reinterpret_cast<const u32x4_t*>(p.dY + off);
+  const int nch = p.C / 8;
+  const int ch = threadIdx.x % nch, rr = threadIdx.x / nch, rpb = blockDim.x / nch;
+  const int c0 = ch * 8;
+  GNChan k;
+  gn_chan_load(p, b, c0, k);
+  float g1[8], g2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { g1[e] = gs[0][(c0 + e) / p.cg]; g2[e] = gs[1][(c0 + e) / p.cg]; }
+  const int64_t r_beg = (int64_t)blockIdx.x * p.rows_per_block, r_end = min(p.rows, r_beg + p.rows_per_block);
+  const int64_t base = ((int64_t)b * p.rows) * p.C + c0;
+#pragma unroll 2
+  for (int64_t r = r_beg + rr; r < r_end; r += rpb) {
+    const u32x4_t xv = ld_stream(p.X + base + r * p.C), dv = ld_stream(p.dY + base + r * p.C);
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c0 + e;
-      const int grp = c / p.cg;
-      const float mean = p.stats[((int64_t)b * p.groups + grp) * 2], rstd = p.stats[((int64_t)b * p.groups + grp) * 2 + 1];
-      const float xr = (e & 1) ? hi16(xv[e >> 1]) : lo16(xv[e >> 1]);
-      const float dr = (e & 1) ? hi16(dv[e >> 1]) : lo16(dv[e >> 1]);
-      const float xh = (xr - mean) * rstd;
-      const float gam = p.gamma[c];
-      const float g = gn_upstream(dr, xh, gam, p.beta[c], p.silu);
-      o[e] = rstd * (g * gam - gs[0][grp] - xh * gs[1][grp]);
+      const float xh = (((e & 1) ? hi16(xv[e >> 1]) : lo16(xv[e >> 1])) - k.mean[e]) * k.rstd[e];
+      const float g = gn_upstream((e & 1) ? hi16(dv[e >> 1]) : lo16(dv[e >> 1]), xh, k.gam[e], k.bet[e], p.silu);
+      o[e] = k.rstd[e] * (g * k.gam[e] - g1[e] - xh * g2[e]);
     }
     u32x4_t ov;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ov[j] = pack16(o[2 * j], o[2 * j + 1]);
-    *reinterpret_cast<u32x4_t*>(p.dX + off) = ov;
+    st_stream(p.dX + base + r * p.C, ov);
   }
 }
-// affine gradients: dgamma_c += sum_b B_c, dbeta_c += sum_b A_c
 __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const GNBParams p) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= p.C) return;
@@ -694,12 +722,18 @@ extern "C" int A3D_FN(a3d_group_norm_bwd)(a3d_stream_t stream, const void* X, co
   hipStream_t s = (hipStream_t)stream;
   if (hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * C * 2 * sizeof(float), s); e != hipSuccess) return (int)e;
   GNBParams p{(const uint16_t*)X, (const uint16_t*)dY, gamma, beta, stats, (uint16_t*)dX, ws, dgamma, dbeta, B, rows, C, groups, C / groups, silu, 0};
-  int64_t by = (rows + 63) / 64; if (by > 256) by = 256;
-  p.rows_per_block = (rows + by - 1) / by;
-  if (B > 65535) return A3D_EINVAL;
-  gn_bwd_sums_kernel<<<dim3((unsigned)((C + 255) / 256), (unsigned)by, (unsigned)B), dim3(256), 0, s>>>(p);
-  int64_t bx = (rows * (C / 8) + 255) / 256; if (bx > 4096) bx = 4096;
-  gn_bwd_apply_kernel<<<dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s>>>(p);
+  if (B > 65535 || C / 8 > 1024) return A3D_EINVAL;
+  const int nch = C / 8, rpb = nch >= 256 ? 1 : 256 / nch;
+  const unsigned threads = (unsigned)(nch * rpb);
+  // ~2048 workgroups over the B samples, each at least 8 row steps long
+  int64_t bx = (2048 + B - 1) / B;
+  const int64_t most = (rows + 8 * rpb - 1) / (8 * rpb);
+  if (bx > most) bx = most;
+  if (bx < 1) bx = 1;
+  p.rows_per_block = (rows + bx - 1) / bx;
+  bx = (rows + p.rows_per_block - 1) / p.rows_per_block;
+  gn_bwd_sums_kernel<<<dim3((unsigned)bx, (unsigned)B), dim3(threads), (size_t)threads * 64, s>>>(p);
+  gn_bwd_apply_kernel<<<dim3((unsigned)bx, (unsigned)B), dim3(threads), 0, s>>>(p);
   if (dgamma) gn_bwd_param_kernel<<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s>>>(p);
   return a3d_launch_status();
 }
