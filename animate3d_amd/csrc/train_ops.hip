@@ -29,6 +29,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
   }
 }
 
+// The same with 16-byte global accesses on both sides (cols, rows_pad and both leading dimensions multiples of 8): a 64 x 64 tile goes
+// into LDS row by row (pitch 66 halves = 33 words: the column gather below spreads over the banks), every thread then gathers 8 rows of
+// one column into a 16-byte store.  The per-step transposes of the trainable weights (dX = dY W needs W^T) are up to 10240 x 1280.
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ X, int64_t ldx, uint16_t* __restrict__ Y, int64_t ldy,
+                                                           int64_t rows, int64_t cols, int64_t rows_pad) {
+  __shared__ uint32_t tile[64][33];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = threadIdx.x + 256 * i, r = q >> 3, cc = (q & 7) * 8;
+    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+    if (r0 + r < rows && c0 + cc < cols) v = *reinterpret_cast<const u32x4_t*>(X + (r0 + r) * ldx + c0 + cc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[r][(cc >> 1) + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = threadIdx.x + 256 * i, c = q >> 3, rr = (q & 7) * 8;
+    if (c0 + c < cols && r0 + rr < rows_pad) {
+      uint32_t h[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const uint32_t w = tile[rr + e][c >> 1]; h[e] = (c & 1) ? (w >> 16) : (w & 0xffffu); }
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = h[2 * j] | (h[2 * j + 1] << 16);
+      *reinterpret_cast<u32x4_t*>(Y + (c0 + c) * ldy + r0 + rr) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients): out[c] += alpha * sum_r X[r][c]
 __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ X, int64_t ldx, int64_t rows, int64_t cols,
                                                       int64_t rows_per_block, float* __restrict__ out, float alpha) {
@@ -656,7 +687,10 @@ extern "C" int A3D_FN(a3d_transpose)(a3d_stream_t stream, const void* X, int64_t
   if (!X || !Y || rows <= 0 || cols <= 0 || rows_pad < rows || ldx < cols || ldy < rows_pad) return A3D_EINVAL;
   const int64_t bx = (rows_pad + 63) / 64, by = (cols + 63) / 64;
   if (bx > 0x7fffffffLL || by > 65535) return A3D_EINVAL;
-  transpose_kernel<<<dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)X, ldx, (uint16_t*)Y, ldy, rows, cols, rows_pad);
+  const bool wide = cols % 8 == 0 && rows_pad % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) == 0;
+  if (wide) transpose16_kernel<<<dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)X, ldx, (uint16_t*)Y, ldy, rows, cols, rows_pad);
+  else transpose_kernel<<<dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream>>>((const uint16_t*)X, ldx, (uint16_t*)Y, ldy, rows, cols, rows_pad);
   return a3d_launch_status();
 }
 

@@ -291,13 +291,14 @@ int a3d_temporal_attn_bwd_bf16(a3d_stream_t stream, const void* Q, const void* K
                                int videos, int frames, int64_t L, int heads, int head_dim, float scale);
 
 /* LayerNorm backward (diffusers BasicTransformerBlock.norm1/2/3): dX [M, C]; dgamma / dbeta fp32 [C] (both or neither;
- * accumulate == 0 zeroes them first).  C <= 2048. */
+ * accumulate == 0 zeroes them first; fp32 atomics: run-to-run equal to rounding).  C <= 2048; C = 320 / 640 / 1280 with 16-byte
+ * aligned X, dY, dX, gamma take the 16-byte-access kernel (8 / 16 / 32 lanes per row). */
 int a3d_layer_norm_bwd_bf16(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, void* dX,
                             float* dgamma, float* dbeta, int64_t M, int C, float eps, int accumulate);
 
 /* GroupNorm (+ fused SiLU) backward on channel-last [B][rows][C] (ResnetBlock2D.norm1/2, Transformer2DModel.norm, the 3-D norm of
  * TransformerTemporalModel): stats fp32 [B][groups][2] = (mean, rstd) as a3d_group_norm_apply takes them; ws fp32 [B*C*2] scratch;
- * dgamma / dbeta fp32 [C], ADDED to (both or neither). */
+ * dgamma / dbeta fp32 [C], ADDED to (both or neither).  C % 8 == 0, C <= 8192, X / dY / dX 16-byte aligned. */
 int a3d_group_norm_bwd_bf16(a3d_stream_t stream, const void* X, const void* dY, const float* gamma, const float* beta,
                             const float* stats, void* dX, float* ws, float* dgamma, float* dbeta,
                             int B, int64_t rows, int C, int groups, int silu);
@@ -308,7 +309,8 @@ int a3d_geglu_bwd_bf16(a3d_stream_t stream, const void* P, int64_t ldp, const vo
                        int64_t M, int64_t N);
 
 /* Y[c][r] = X[r][c] (r < rows, c < cols), Y[c][rows .. rows_pad) = 0: operands of the weight-gradient GEMM dW = dY^T X, whose
- * contraction (the token rows) must be a multiple of 64. */
+ * contraction (the token rows) must be a multiple of 64, and W^T of the trainable weights for dX = dY W.  16-byte accesses when cols,
+ * rows_pad, ldx and ldy are multiples of 8 and both pointers 16-byte aligned; any shape otherwise. */
 int a3d_transpose_bf16(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int64_t cols,
                        int64_t rows_pad);
 
@@ -320,7 +322,8 @@ int64_t a3d_wgrad_ws_floats(int64_t M, int64_t N, int64_t K);
 int a3d_wgrad_bf16(a3d_stream_t stream, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
                    float* ws, int64_t M, int64_t N, int64_t K, float alpha, int accumulate);
 
-/* out[c] (+)= alpha * sum_r X[r][c]  (bias gradients), fp32 out. */
+/* out[c] (+)= alpha * sum_r X[r][c]  (bias gradients), fp32 out (fp32 atomics over the row split).  cols % 320 == 0 with ldx % 8 == 0 and
+ * a 16-byte aligned X reads 16 bytes per lane; any shape otherwise. */
 int a3d_colsum_bf16(a3d_stream_t stream, const void* X, int64_t ldx, int64_t rows, int64_t cols, float* out, float alpha, int accumulate);
 
 /* Y = a X + b Y over n elements (n % 8 == 0): sum of the gradients of two branches. */

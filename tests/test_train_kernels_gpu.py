@@ -178,6 +178,16 @@ def test_layer_norm_bwd_sub_wave_rows_kernel_tail_and_grid_stride(ops, ref, M, C
             check("layer_norm_bwd dbeta", db, rb, 1e-4)
 
 
+@pytest.mark.parametrize("rows,cols,pad,off", [(1280, 5120, 1, 0), (2560, 320, 1, 0), (328, 320, 1, 8), (100, 72, 64, 0), (1000, 1288, 8, 16), (8, 8, 1, 0)])
+def test_transpose_16_byte_kernel(ops, ref, rows, cols, pad, off):
+    """W -> W^T of the trainable weights (every step) and the padded activations of the weight-gradient GEMM: 16-byte loads and stores when
+    cols, the padded row count and both leading dimensions are multiples of 8; bit-exact, zero padding included."""
+    xb = rnd(rows, cols + off, seed=31, dtype=ops.act_dtype)
+    x = xb[:, off:] if off else xb
+    got, want = ops.transpose(x, pad=pad), ref.transpose(x, pad=pad)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("M,N,pad", [(1000, 320, 0), (777, 640, 24), (300, 2560, 0), (129, 3840, 8), (50, 960, 0), (70000, 1280, 0), (3, 320, 0)])
 def test_colsum_16_byte_kernel(ops, ref, M, N, pad):
     """Bias gradients of widths that are multiples of 320 (every Linear of the model): 16-byte loads, TPR lanes per row."""
