@@ -38,6 +38,22 @@ class RowMap:
         return _RowMapC(self.gdiv, self.ga, self.gb, self.seg_len, self.seg_stride, ld)
 
 
+def rowmap_rows(m: RowMap, groups: int, step: int, length: int, device="cpu") -> torch.Tensor:
+    """Rows ``m`` addresses for groups 0, step, 2 step, ... < groups and positions 0 .. length-1, in (group, position) order."""
+    g = torch.arange(0, groups, step, device=device).view(-1, 1)
+    s = torch.arange(length, device=device).view(1, -1)
+    return ((g // m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (s // m.seg_len) * m.seg_stride + s % m.seg_len).reshape(-1)
+
+
+def rowmap_covers(m: RowMap, groups: int, step: int, length: int, rows: int, device="cpu") -> bool:
+    """True when those rows are ALL of 0 .. rows-1, each exactly once: an attention backward whose key map covers K / V writes every row of
+    dK / dV, so they need no zero fill (the first-frame maps, which read frame 0 only, do not cover)."""
+    if (groups + step - 1) // step * length != rows:
+        return False
+    idx = rowmap_rows(m, groups, step, length, device)
+    return bool(int(idx.min()) >= 0 and int(idx.max()) < rows and torch.unique(idx).numel() == rows)
+
+
 # symbol -> (restype, argtypes); mirrors include/animate3d_hip.h line by line
 _SIGNATURES = {
     "a3d_version": (ctypes.c_char_p, []),
@@ -611,15 +627,11 @@ class HipOps:
         return dq, dk, dv
 
     def _kv_map_covers(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int, rows: int) -> bool:
-        """True when the keys the attention reads are ALL ``rows`` rows of K / V, each once: then the backward kernel writes every row
-        of dK / dV and they need no zero fill (decided once per map on the device, cached)."""
-        if (groups // q_per_kv) * kv_len != rows:
-            return False
+        """``rowmap_covers`` for this attention's key map, decided once per map on the device and cached."""
         key = (kmap.gdiv, kmap.ga, kmap.gb, kmap.seg_len, kmap.seg_stride, groups, q_per_kv, kv_len, rows)
         hit = self._kv_cover_cache.get(key)
         if hit is None:
-            idx = self._shared_kv_rows(kmap, groups, q_per_kv, kv_len)
-            hit = self._kv_cover_cache[key] = bool(int(idx.min()) >= 0 and int(idx.max()) < rows and torch.unique(idx).numel() == rows)
+            hit = self._kv_cover_cache[key] = rowmap_covers(kmap, groups, q_per_kv, kv_len, rows, self.device)
         return hit
 
     def _shared_kv_rows(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int) -> torch.Tensor:
@@ -627,9 +639,7 @@ class HipOps:
         key = (kmap.gdiv, kmap.ga, kmap.gb, kmap.seg_len, kmap.seg_stride, groups, q_per_kv, kv_len)
         cache = self._kv_row_cache
         if key not in cache:
-            g = torch.arange(0, groups, q_per_kv, device=self.device).view(-1, 1)
-            s = torch.arange(kv_len, device=self.device).view(1, -1)
-            cache[key] = ((g // kmap.gdiv) * kmap.ga + (g % kmap.gdiv) * kmap.gb + (s // kmap.seg_len) * kmap.seg_stride + s % kmap.seg_len).reshape(-1)
+            cache[key] = rowmap_rows(kmap, groups, q_per_kv, kv_len, self.device)
         return cache[key]
 
     def temporal_attn_bwd(self, q, k, v, do, videos: int, frames: int, L: int, heads: int):

@@ -640,3 +640,30 @@ def test_deferred_param_grads_equal_autograd_accumulation():
             A._Deferred.src.append(torch.ones(()))
             raise RuntimeError("stop")
     assert not A._Deferred.dst and not A._Deferred.src and not A._Deferred.active
+
+
+def test_rowmap_coverage_decides_the_zero_fill_of_dk_dv():
+    """hip_ops.flash_attn_bwd skips the zero fill of dK / dV when the key map reaches every row of K / V exactly once: true for the
+    multi-view map "(b n f) l -> (b f) (n l)" (attention_processor.py:340), false for the first-frame maps (frame 0's keys only, :389-418),
+    for short key lengths and for maps that read a row twice."""
+    from animate3d_amd.hip_ops import RowMap, rowmap_covers, rowmap_rows
+    b, n, Fr, L = 2, 3, 4, 5
+    rows = b * n * Fr * L
+    mv = RowMap(gdiv=Fr, ga=n * Fr * L, gb=L, seg_len=L, seg_stride=Fr * L)            # unet._mv_maps: queries and keys of (b, f)
+    k0 = RowMap(gdiv=Fr, ga=n * Fr * L, gb=0, seg_len=L, seg_stride=Fr * L)            # same, frame 0 of every b
+    idx = rowmap_rows(mv, b * Fr, 1, n * L)
+    want = torch.arange(rows).view(b, n, Fr, L).permute(0, 2, 1, 3).reshape(-1)         # "(b n f) l -> (b f) (n l)"
+    assert torch.equal(idx, want)
+    assert rowmap_covers(mv, b * Fr, 1, n * L, rows)
+    assert not rowmap_covers(k0, b * Fr, 1, n * L, rows)                                # every frame's group reads frame 0: rows repeat
+    assert not rowmap_covers(k0, b * Fr, Fr, n * L, rows)                               # one reader per video: frames > 0 never read
+    assert rowmap_covers(k0, b * Fr, Fr, n * L, b * n * L) is False                     # (the rows it reads are not 0 .. b n L - 1 either)
+    assert not rowmap_covers(mv, b * Fr, 1, n * L - 1, rows)                            # ragged: fewer keys than rows
+    assert not rowmap_covers(mv, b * Fr, 1, n * L, rows + L)                            # a tensor with rows the map never reaches
+    flat = RowMap(gdiv=1, ga=7, gb=0, seg_len=7, seg_stride=0)                          # plain [groups, 7] layout
+    assert rowmap_covers(flat, 6, 1, 7, 42) and not rowmap_covers(flat, 6, 2, 7, 42)
+    # the per-view first-frame map of the motion module's image branch (unet._motion_attn): V videos, frame 0 of each
+    V = b * n
+    img0 = RowMap(gdiv=Fr, ga=Fr * L, gb=0, seg_len=L, seg_stride=0)
+    assert torch.equal(rowmap_rows(img0, V * Fr, Fr, L), (torch.arange(V).view(-1, 1) * Fr * L + torch.arange(L).view(1, -1)).reshape(-1))
+    assert not rowmap_covers(img0, V * Fr, Fr, L, V * Fr * L)
