@@ -232,6 +232,88 @@ class ShardPlan:
 ViewParallel = ShardPlan          # name of the round-1 plan (views only)
 
 
+class RankShapePlan(ShardPlan):
+    """The COMPUTE leg of rank 0 of layout (cfg, views, frames) in a single process, without a process group: the model cuts rank 0's
+    shard out of the full call and launches exactly the kernels that rank launches — local rows, the K|V projection over the gathered
+    token count, attention with q_len != kv_len through the unsharded row maps, split-K off, the CU reservation while a "gather" is in
+    flight — with every data-path collective replaced by local device copies of the right size (the peers' blocks are copies of this
+    rank's block, so the outputs are NOT the sharded job's outputs; only the launch shapes and the timing are).  ``bench.py --rank-shape
+    c,v,f`` measures a rank's compute time on the one GPU a builder has; link time is not in it."""
+
+    def __init__(self, layout: Sequence[int]):      # no super().__init__: that one needs torch.distributed
+        c, v, f = (int(s) for s in layout)
+        if min(c, v, f) < 1:
+            raise ValueError(f"rank shape {tuple(layout)} must be three positive shard counts (cfg, views, frames)")
+        self.group = None
+        self.rank = 0
+        self.world = c * v * f
+        self.layout_request = (c, v, f)
+        self._layouts = {}
+        self.cfg_shards, self.view_shards, self.frame_shards = c, v, f
+        self.cfg_rank = self.view_rank = self.frame_rank = 0
+        self.view_group = self.frame_group = None
+        self.frame_group_root = 0
+        self.gather_bytes = self.collectives = 0
+        self.gather_tokens = True
+        self.reserve_cus = 16
+        self.ops = None
+        self._in_flight = 0
+
+    def configure(self, b: int, n: int, F: Optional[int] = None):
+        self.choose_layout(self.world, b, n, F, self.layout_request)       # same divisibility errors as the real plan
+        self.release_reservation()
+        return self
+
+    @staticmethod
+    def _replicate(t: torch.Tensor, S: int, blocks: int = 1) -> torch.Tensor:
+        """[blocks, S, rows / blocks, width] filled with S copies of every block: the gathered buffer's size and layout."""
+        rows, width = t.shape
+        out = torch.empty((S * rows, width), dtype=t.dtype, device=t.device)
+        out.view(blocks, S, rows // blocks, width)[:] = t.view(blocks, 1, rows // blocks, width)
+        return out
+
+    def all_gather_views_start(self, kv: torch.Tensor, b_local: int = 1):
+        if b_local <= 0 or kv.shape[0] % b_local != 0:
+            raise ValueError(f"all_gather_views: {kv.shape[0]} rows do not split into {b_local} local batch entries")
+        kv = kv.contiguous()
+        self._count((self.view_shards - 1) * kv.numel() * kv.element_size(), n=b_local)
+        self._overlap(+1)                # the reservation lasts until *_finish, as with the asynchronous collective
+        return [], self._replicate(kv, self.view_shards, b_local), kv
+
+    def all_gather_frames_start(self, kv: torch.Tensor):
+        kv = kv.contiguous()
+        self._count((self.frame_shards - 1) * kv.numel() * kv.element_size())
+        self._overlap(+1)
+        return _NoWork(), self._replicate(kv, self.frame_shards), kv
+
+    def broadcast_frame0(self, x0, shape, dtype, device) -> torch.Tensor:
+        return x0.contiguous()          # rank 0 holds frame 0: it is the sender
+
+    def all_reduce_frames(self, t: torch.Tensor) -> torch.Tensor:
+        self._count(2 * (self.frame_shards - 1) * t.numel() * t.element_size() // self.frame_shards)
+        return t.mul_(self.frame_shards)          # sums over all frames ~ frame_shards x the local sums: keeps the statistics sane
+
+    def all_gather_output(self, y_local: torch.Tensor, V: int, n: int, F: Optional[int] = None) -> torch.Tensor:
+        C, Fl, h, w = y_local.shape[1:]
+        reps = V // y_local.shape[0]
+        return y_local.repeat(reps, 1, self.frame_shards, 1, 1).contiguous()
+
+
+class _NoWork:
+    def wait(self):
+        return True
+
+
+def rank_shape_unet(unet, layout: Sequence[int]) -> RankShapePlan:
+    """Attach a RankShapePlan (single process, no torch.distributed): see the class.  Mirrors ``shard_unet``'s op-set settings."""
+    unet.parallel = RankShapePlan(layout)
+    ops = getattr(unet, "ops", None)
+    unet.parallel.ops = ops if hasattr(ops, "reserved_cus") else None
+    if unet.parallel.ops is not None and hasattr(ops, "split_k"):
+        ops.split_k = False
+    return unet.parallel
+
+
 def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: Optional[Tuple[int, int, int]] = None) -> ShardPlan:
     """Attach a ShardPlan to a MVUNetMotionModel (every rank, same order).  ``layout`` = (cfg_shards, view_shards,
     frame_shards) or None for the default (CFG halves, then views, then frames); ``shape`` = (b, n, F) of the calls to come

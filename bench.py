@@ -332,6 +332,18 @@ def _pmc_traffic(S0, groups, kernel):
     return None
 
 
+XGMI_LINK_GBS = 153.0            # per link and direction (MI355X_MICROARCH.md); a gather among S peers uses S - 1 links of a GPU concurrently
+
+
+def _link_ms(plan, steps):
+    """Modelled link time of the gathers a rank of this layout would receive per step: bytes / ((peers of the gathering group) x one xGMI
+    link).  View gathers use view_shards - 1 links, frame gathers frame_shards - 1; the plan counts bytes only, so the split is by axis
+    share when both are cut (views move ~60 % of the bytes at config 2: DESIGN.md section 5)."""
+    by = plan.gather_bytes / max(1, steps)
+    peers = max(1, max(plan.view_shards, plan.frame_shards) - 1)
+    return by / (peers * XGMI_LINK_GBS * 1e9) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -349,6 +361,9 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 40 by time)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration kernels behind the 'box' object")
+    ap.add_argument("--rank-shape", type=str, default="", help="single process, no process group: time the COMPUTE leg of rank 0 of the multi-GPU layout "
+                    "cfg,views,frames (its local rows, K|V projections over the gathered token count, q_len != kv_len attention, split-K off, CU "
+                    "reservation while a gather would be in flight), every collective replaced by a local copy of the right size; the line's metric says so")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -398,7 +413,13 @@ def main():
     model = model.to(torch_dtype).eval()
     assert model.ops.act_dtype == torch_dtype
     dom_kernel = DOMINANT_KERNEL[dtype_name]
-    par = None
+    par = rpar = None
+    if args.rank_shape:
+        if world > 1:
+            raise SystemExit("--rank-shape emulates one rank in a single process: use it with --gpus 1")
+        from animate3d_amd.parallel import rank_shape_unet
+        rpar = rank_shape_unet(model, tuple(int(v) for v in args.rank_shape.split(",")))
+        rpar.configure(V // n, n, F)
     if world > 1:
         from animate3d_amd.parallel import shard_unet
         layout = tuple(int(v) for v in args.layout.split(",")) if args.layout else None
@@ -425,8 +446,9 @@ def main():
 
     for _ in range(args.warmup):
         model(**inp)
-    if par is not None:
-        par.gather_bytes = par.collectives = 0
+    for p_ in (par, rpar):
+        if p_ is not None:
+            p_.gather_bytes = p_.collectives = 0
     ops.enabled = True
     dt, y = timed_steps(args.steps)
     ops.enabled = False
@@ -526,7 +548,22 @@ def main():
             "whole_step_mfma_frac": work * value / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roofline,
         }
-        if args.config == 2 and (n, F, lat) == (n0, F0, lat0):
+        if rpar is not None:
+            # NOT the BASELINE metric: one rank's compute time of an N-GPU layout measured on one GPU (link time excluded)
+            P = rpar.world
+            line["metric"] = (f"compute leg of rank 0 of layout cfg{rpar.cfg_shards} x views{rpar.view_shards} x frames{rpar.frame_shards} "
+                              f"({P} GPUs), ms per denoise step, collectives replaced by local copies (single-GPU emulation; no link time)")
+            line["value"], line["unit"], line["higher_is_better"] = ms_per_step, "ms", False
+            line["config"]["parallelism"] = f"rank 0 of {P}: cfg{rpar.cfg_shards} x views{rpar.view_shards} x frames{rpar.frame_shards}, emulated in one process"
+            line["flop_per_step"] = work / P
+            line["whole_step_tflops"] = work / P / (ms_per_step * 1e-3) / 1e12
+            line["whole_step_mfma_frac"] = line["whole_step_tflops"] / PEAK_BF16_TFLOPS
+            line["rank_shape"] = {"layout": [rpar.cfg_shards, rpar.view_shards, rpar.frame_shards], "ranks": P,
+                                  "algorithmic_flop_per_rank": work / P,
+                                  "would_receive_bytes_per_step": rpar.gather_bytes / args.steps, "collectives_per_step": rpar.collectives / args.steps,
+                                  "modelled_link_ms": _link_ms(rpar, args.steps),
+                                  "reserved_cus_during_gathers": rpar.reserve_cus}
+        if rpar is None and args.config == 2 and (n, F, lat) == (n0, F0, lat0):
             line["config2_25_ddim_steps_seconds"] = 25.0 * ms_per_step / 1e3
         if graph_ms is not None:
             line["hip_graph_replay"] = {"ms_per_step": graph_ms, "eager_ms_per_step": ms_per_step,
@@ -535,9 +572,9 @@ def main():
             line["groups"] = groups
         if comm is not None:
             line["communication"] = comm
-        if world == 1 and not args.no_box:
+        if world == 1 and not args.no_box and rpar is None:
             line["box"] = box_calibration(ops._ops, dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and rpar is None:
             line["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:

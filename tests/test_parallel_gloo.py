@@ -105,3 +105,98 @@ def test_layout_choice_and_local_videos():
         ShardPlan.choose_layout(8, 1, 4, 15)                      # frames do not divide
     with pytest.raises(ValueError):
         ShardPlan.choose_layout(8, 2, 4, 16, (2, 2, 1))           # product != world
+
+
+# ---- bench.py --rank-shape: the single-process emulation of one rank must launch exactly what rank 0 of the real job launches
+class _LoggedOps:
+    """Delegates to TorchRefOps and records (op, tensor shapes, integer arguments) of every call."""
+
+    def __init__(self, ops):
+        object.__setattr__(self, "_ops", ops)
+        object.__setattr__(self, "log", [])
+        object.__setattr__(self, "reserved_log", [])
+
+    def __setattr__(self, name, value):
+        if name == "reserved_cus":
+            self.reserved_log.append(int(value))
+        setattr(self._ops, name, value)
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+        if not callable(fn) or name.startswith("_") or name in ("empty", "split_cols", "interleave_geglu"):
+            return fn
+
+        def logged(*a, **k):
+            sig = tuple(tuple(v.shape) if torch.is_tensor(v) else (v if isinstance(v, (int, bool, str)) else type(v).__name__) for v in a)
+            ksig = tuple(sorted((kk, tuple(v.shape) if torch.is_tensor(v) else (v if isinstance(v, (int, bool)) else type(v).__name__)) for kk, v in k.items()))
+            self.log.append((name, sig, ksig))
+            return fn(*a, **k)
+        return logged
+
+
+def _launch_log_worker(rank, world, port, n, F, hw, videos, layout, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from animate3d_amd.config import UNetConfig
+        from animate3d_amd.parallel import shard_unet
+        from animate3d_amd.unet import MVUNetMotionModel
+        from oracle import unet_ref as O
+        from tests.torch_ops import TorchRefOps
+        ops = _LoggedOps(TorchRefOps())
+        ops.reserved_cus = 0
+        model = MVUNetMotionModel(UNetConfig(**SMALL), ops=ops, num_views=n)
+        model.init_synthetic(seed=0)
+        inp = O.synthetic_inputs(O.UNetConfig(**SMALL), videos, n, F, hw, seed=11, cfg_doubled=True)
+        shard_unet(model, layout=layout, shape=(videos // n, n, F))
+        model(**inp)
+        del ops.log[:]
+        par = model.parallel
+        par.gather_bytes = par.collectives = 0
+        model(**inp)
+        q.put((rank, list(ops.log) if rank == 0 else None, par.gather_bytes, par.collectives))
+    except Exception as e:
+        q.put((rank, repr(e), 0, 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,F,videos,layout", [(4, 2, 2, 4, (2, 2, 1)), (4, 2, 4, 2, (1, 2, 2)), (8, 2, 4, 4, (2, 2, 2))])
+def test_rank_shape_emulation_launches_what_rank0_launches(world, n, F, videos, layout):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_launch_log_worker, args=(r, world, port, n, F, (8, 8), videos, layout, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    real = next(r for r in res if r[0] == 0)
+    assert not isinstance(real[1], str), real[1]
+
+    from animate3d_amd.config import UNetConfig
+    from animate3d_amd.parallel import rank_shape_unet
+    from animate3d_amd.unet import MVUNetMotionModel
+    from oracle import unet_ref as O
+    from tests.torch_ops import TorchRefOps
+    ops = _LoggedOps(TorchRefOps())
+    ops.reserved_cus = 0
+    model = MVUNetMotionModel(UNetConfig(**SMALL), ops=ops, num_views=n)
+    model.init_synthetic(seed=0)
+    inp = O.synthetic_inputs(O.UNetConfig(**SMALL), videos, n, F, (8, 8), seed=11, cfg_doubled=True)
+    plan = rank_shape_unet(model, layout)
+    model(**inp)                                               # first call packs the weights (folding GEMMs), as in the worker
+    del ops.log[:]
+    plan.gather_bytes = plan.collectives = 0
+    y = model(**inp).sample
+    assert tuple(y.shape) == (videos, 4, F, 8, 8) and torch.isfinite(y).all()
+    assert ops.log == real[1]                                  # same ops, same order, same shapes and integer arguments
+    assert (plan.gather_bytes, plan.collectives) == (real[2], real[3])      # and the bytes / collectives rank 0 counts
+    assert set(ops.reserved_log) == {0, plan.reserve_cus} and ops.reserved_log[-1] == 0      # reservation toggled around every "gather"
+    with pytest.raises(ValueError):
+        rank_shape_unet(model, (1, 3, 1)).configure(videos // n, n, F)      # the real plan's divisibility errors
