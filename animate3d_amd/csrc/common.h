@@ -109,6 +109,13 @@ A3D_DEV int64_t xcd_remap(int64_t bid, int64_t nblk) {
   return base + idx;
 }
 
+A3D_DEV uint32_t xcd_remap32(uint32_t bid, uint32_t nblk) {      // the same for grids below 2^32 (no 64-bit divisions)
+  const uint32_t q = nblk / 8u, r = nblk % 8u;
+  const uint32_t xcd = bid % 8u, idx = bid / 8u;
+  const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  return base + idx;
+}
+
 // Per-device one-time state (dynamic-LDS attribute, CU count): one process may drive several GPUs, so the "done" flags
 // are bit masks / tables indexed by the current HIP device, not process-wide booleans.
 static inline int a3d_current_device() {

@@ -586,7 +586,7 @@ void launch_two(bool aligned, int groups, hipStream_t s, const AttnParams& p) {
 static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
                            const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                            int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
-                           float scale, float out_scale, int accumulate, float* lse) {
+                           float scale, float out_scale, int accumulate, float* lse, unsigned int* counters = nullptr) {
   if (!Q || !K || !V || !O || groups <= 0 || heads <= 0 || q_len <= 0 || kv_len <= 0) return A3D_EINVAL;
   if (!map_ok(qmap, head_dim) || !map_ok(kmap, head_dim) || !map_ok(omap, head_dim)) return A3D_EINVAL;
   if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15u) return A3D_EINVAL;
@@ -600,6 +600,7 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
   p.scale_log2 = scale * 1.4426950408889634f; p.out_scale = out_scale; p.accumulate = accumulate & 1; p.causal = (accumulate >> 1) & 1;
   const bool exact = (accumulate & A3D_ATTN_EXACT) != 0, plain = (accumulate & A3D_ATTN_PLAIN) != 0;
   p.lse = lse;
+  p.counters = counters;
   if (p.causal && head_dim != 64 && head_dim != 160) return A3D_EUNSUPPORTED;     // offered on the raw-score (fma) kernels only
   const int bkv = head_dim == 160 ? 32 : 64;
   const bool aligned = (kmap->seg_len % bkv == 0) || (kv_len <= kmap->seg_len);
@@ -650,6 +651,17 @@ extern "C" int A3D_FN(a3d_flash_attn_lse)(a3d_stream_t stream, const void* Q, co
                                        float scale, float out_scale, int accumulate, float* lse2) {
   if (!lse2) return A3D_EINVAL;
   return flash_attn_impl(stream, Q, K, V, O, qmap, kmap, omap, groups, heads, head_dim, q_len, kv_len, scale, out_scale, accumulate, lse2);
+}
+
+// Diagnostics: a3d_flash_attn that also books, per launch of an LDS-DMA staged kernel (head_dim 40 / 80, long aligned K/V), how many
+// workgroups left the max-free fast path — counters[0] += sent to the exact pass by the fp16 spread vote, [1] += exact re-runs after an
+// overflow, [2] += workgroups launched (device words, caller-zeroed; other kernels leave them alone).  Same results as a3d_flash_attn.
+extern "C" int A3D_FN(a3d_flash_attn_counted)(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                                           const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                                           int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                                           float scale, float out_scale, int accumulate, unsigned int* counters) {
+  if (!counters || (reinterpret_cast<uintptr_t>(counters) & 3u)) return A3D_EINVAL;
+  return flash_attn_impl(stream, Q, K, V, O, qmap, kmap, omap, groups, heads, head_dim, q_len, kv_len, scale, out_scale, accumulate, nullptr, counters);
 }
 
 // Two key sets in one launch: O = out_scale * softmax(Q K^T * scale) V + out_scale2 * softmax(Q K2^T * scale) V2 (+ previous O if

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
         // variance 19 of 28) 2-3 % of the queries still read above the threshold and an OR over the workgroup's 512 queries sent EVERY workgroup
         // to the 20 % slower exact pass (profiles/r5_flash_score_spread.log).  The workgroup goes exact right away when more than a quarter of
         // its queries predict an overflow; a row that does overflow in the max-free pass is still caught by its row sum at the end.
-        if (__syncthreads_count(wide ? 1 : 0) * 4 > NT) return false;
+        if (__syncthreads_count(wide ? 1 : 0) * 4 > NT) { dm_count(p, 0); return false; }
         read_k(0u);                                                 // ... then S(0) of keys 0..31 under it
 #pragma unroll
         for (int qs = 0; qs < QT; ++qs) {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
     }
     float inv[NINV];
     const bool bad = row_sums(inv);
-    if (__syncthreads_or(bad ? 1 : 0)) return false;          // (also: every wave is done with the LDS images)
+    if (__syncthreads_or(bad ? 1 : 0)) { dm_count(p, 1); return false; }          // (also: every wave is done with the LDS images)
     store_out(inv);
     store_lse();
     return true;
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
   };
 
   __syncthreads();        // constant region written
+  dm_count(p, 2);
   if constexpr (TRY_NOMAX) {
     if (!run_fast()) run_exact();
   } else {

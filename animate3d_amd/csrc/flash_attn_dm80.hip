@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     const float l_tot = __shfl(oacc[2][8], l31);
     const bool bad = !(l_tot < E_L_BAD) || !(l_tot > 0.f);
     if (check) {
-      if (__syncthreads_or(bad ? 1 : 0)) return false;          // (also: every wave is done with the LDS images)
+      if (__syncthreads_or(bad ? 1 : 0)) { dm_count(p, 1); return false; }          // (also: every wave is done with the LDS images)
     }
     const float inv = p.out_scale / l_tot;
     if (p.lse != nullptr && q_idx < p.q_len && g == 0)      // training: log2 of the softmax denominator (minit = -offset in every lane)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
         // variance 19 of 28) 2-3 % of the queries still read above the threshold and an OR over the workgroup's 512 queries sent EVERY workgroup
         // to the 20 % slower exact pass (profiles/r5_flash_score_spread.log).  The workgroup goes exact right away when more than a quarter of
         // its queries predict an overflow; a row that does overflow in the max-free pass is still caught by its row sum at the end.
-        if (__syncthreads_count(wide ? 1 : 0) * 4 > NT) return false;
+        if (__syncthreads_count(wide ? 1 : 0) * 4 > NT) { dm_count(p, 0); return false; }
         read_k(0u);                                                // ... then S(0) of keys 0..31 under it
         sA = minit;
 #pragma unroll
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
   };
 
   __syncthreads();        // constant region written
+  dm_count(p, 2);
   if constexpr (TRY_NOMAX) {
     if (!run_fast()) run_exact();
   } else {

@@ -18,6 +18,10 @@ struct AttnParams {
   // training (a3d_flash_attn_lse): per query log2 sum_k 2^(s_qk * scale * log2 e), [groups][heads][q_len] floats, as the backward's
   // statistics pass would compute it (attn_bwd.hip); nullptr: not wanted
   float* lse;
+  // diagnostics (a3d_flash_attn_counted): device words the LDS-DMA staged kernels add to — [0] workgroups that skipped the max-free pass on
+  // the spread predictor's vote (fp16 storage), [1] workgroups that discarded a max-free result and re-ran exactly (overflow), [2] workgroups
+  // launched.  nullptr (every other entry point): nothing is counted.  Touched on the cold paths and once at kernel start only.
+  unsigned int* counters;
 };
 
 namespace {
@@ -69,6 +73,11 @@ A3D_DEV const uint16_t* dm_scalar(const uint16_t* ptr) {      // wave-uniform by
   const uint64_t a = (uint64_t)(uintptr_t)ptr;
   return (const uint16_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+}
+
+// one thread of the workgroup books an event of the diagnostics counters (cold paths only)
+A3D_DEV void dm_count(const AttnParams& p, int which) {
+  if (p.counters != nullptr && threadIdx.x == 0) atomicAdd(p.counters + which, 1u);
 }
 
 A3D_DEV uint32_t fa_lds_addr(const void* p) {

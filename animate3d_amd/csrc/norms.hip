@@ -143,6 +143,169 @@ __global__ void gn_apply_kernel(const GNParams p) {
   for (; r < r1; r += ny) apply(ld_stream(src + r * ldsrc), r);
 }
 
+// ---------------- GroupNorm in ONE launch and ONE read of the tensor (round 6): a workgroup owns a slab of `sg` whole groups of one instance
+// for ALL its rows and keeps it in registers between the statistics and the apply phase (up to 512 threads x GNF_RMAX 16-byte chunks =
+// 172 KB).  Covers the 2-D GroupNorms of levels 1-3 (80-320-channel slabs; level 0 too at a 32 x 32 latent) and the per-video 3-D norm
+// of level 3; the three-launch path above stays for the instances that do not fit (level 0 at a 64 x 64 latent: 4 096 rows, the per-video
+// norms of levels 0-2).  Traffic 1 read + 1 write instead of 2 + 1; no workspace; and the small instances of a multi-GPU rank (16 images x 256
+// rows x 1280 channels was 3 launches of 32 workgroups whose threads each walked 128 rows serially: 72 us) become one launch.
+// Statistics: per-thread fp32 sums over <= GNF_RMAX rows in row order, fixed-order LDS reduction, fp64 combine (deterministic; does not
+// depend on B, so a batch slice reproduces the full batch bit for bit).
+constexpr int GNF_RMAX = 21;             // largest instantiation: 512 threads x 21 chunks = 172 KB per workgroup (at 41 — level 0's 4 096 rows x 40
+                                         // channels — the compiler spills 155 of 256 registers)
+template <bool STREAM, int RMAX>
+__global__ __launch_bounds__(512) void gn_fused_kernel(const GNParams p, const int sg, const int nx, const int ny, const int nslab) {
+  extern __shared__ float sm[];                 // [ny][nx][4] thread partials | [8][nx][4] stage-A sums | [sg][2] (mean, rstd)
+  const int tid = threadIdx.x;
+  const int ry = tid / nx, c8 = tid - ry * nx;
+  const bool act = ry < ny;
+  const uint32_t lid = (uint32_t)xcd_remap32(blockIdx.x, gridDim.x);      // neighbouring slabs of an image share 128-byte lines: same XCD, same L2
+  const int b = (int)(lid / (uint32_t)nslab), slab = (int)(lid - (uint32_t)b * (uint32_t)nslab);
+  const int chs = slab * sg * p.cg;             // first channel of the slab
+  const int ch0 = chs + c8 * 8;
+  const int g_lo = (c8 * 8) / p.cg;             // (local group index) a chunk touches at most 2 groups
+  const int split = (g_lo + 1) * p.cg - c8 * 8;
+  const bool second = p.Xb != nullptr && ch0 >= p.C1;
+  const int64_t ldsrc = p.Xb == nullptr ? p.C : (second ? p.C - p.C1 : p.C1);
+  const uint16_t* const src = (second ? p.Xb + (ch0 - p.C1) : p.X + ch0) + ((int64_t)b * p.rows) * ldsrc;
+  // STREAM: full-line slabs (non-temporal accesses); slabs narrower than a 128-byte line share lines with their neighbours: plain accesses keep them in L2
+  // this thread's rows are row0, row0 + ny, ...: nv of them (<= RMAX); 32-bit element offsets (an instance that fits the registers is < 2^31
+  // bytes).  Branch-free loads: iterations beyond nv re-read the thread's last valid row and are zeroed.
+  const uint32_t nrows = (uint32_t)p.rows, step = (uint32_t)ny;
+  uint32_t nv = (act && (uint32_t)ry < nrows) ? (nrows - (uint32_t)ry + step - 1u) / step : 0u;
+  const uint32_t rbase = nv ? (uint32_t)ry : 0u;
+  const uint16_t* const tsrc = src + rbase * (uint32_t)ldsrc;
+  const uint32_t sstride = step * (uint32_t)ldsrc;
+  u32x4_t v[RMAX];
+  {
+    const uint32_t last = nv ? nv - 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const uint32_t idx = (uint32_t)i < last ? (uint32_t)i : last;
+      v[i] = STREAM ? ld_stream(tsrc + idx * sstride) : *reinterpret_cast<const u32x4_t*>(tsrc + idx * sstride);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+    const bool ok = (uint32_t)i < nv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = ok ? v[i][e] : 0u;
+  }
+  // per-column sums over the thread's rows in row order (rows beyond the instance are zeros: they add nothing), then the columns of the
+  // chunk go to its one or two groups
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (j & 1) ? hi16(v[i][j >> 1]) : lo16(v[i][j >> 1]);
+      cs[j] += f; cq[j] += f * f;
+    }
+    __builtin_amdgcn_sched_barrier(0);          // row by row: the scheduler otherwise converts every row up front (8 extra registers per row)
+  }
+  float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < split) { s_lo += cs[j]; q_lo += cq[j]; } else { s_hi += cs[j]; q_hi += cq[j]; }
+  }
+  // the apply phase converts the raw 16-bit words again: without this fence the compiler keeps all 8 * RMAX converted floats alive
+  // across the reduction (common subexpressions of the two phases) and spills ~480 registers
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) asm volatile("" : "+v"(v[i]));
+  asm volatile("" : "+v"(nv));                  // (likewise anything derived from the row count)
+  float* const part = sm;
+  float* const stA = sm + (size_t)ny * nx * 4;
+  float* const st = stA + (size_t)8 * nx * 4;
+  if (act) { float* mine = part + ((size_t)ry * nx + c8) * 4; mine[0] = s_lo; mine[1] = q_lo; mine[2] = s_hi; mine[3] = q_hi; }
+  __syncthreads();
+  if (tid < 8 * nx) {                           // stage A: thread (y0, c) adds rows y0, y0 + 8, ... of chunk column c
+    const int y0 = tid / nx, c = tid - y0 * nx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+    for (int y = y0; y < ny; y += 8) { const float* q = part + ((size_t)y * nx + c) * 4; a0 += q[0]; a1 += q[1]; a2 += q[2]; a3 += q[3]; }
+    float* o = stA + ((size_t)y0 * nx + c) * 4; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
+  __syncthreads();
+  if (tid < sg) {                               // stage B: one thread per group, fp64 combine
+    const int cfirst = (tid * p.cg) / 8, clast = ((tid + 1) * p.cg - 1) / 8;
+    double s = 0.0, q = 0.0;
+#pragma unroll 1
+    for (int y0 = 0; y0 < 8; ++y0)
+#pragma unroll 1
+      for (int c = cfirst; c <= clast; ++c) {
+        const float* a = stA + ((size_t)y0 * nx + c) * 4;
+        if ((c * 8) / p.cg == tid) { s += a[0]; q += a[1]; } else { s += a[2]; q += a[3]; }
+      }
+    const double n = (double)p.rows * p.cg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    st[2 * tid] = (float)mean;
+    st[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  if (!act) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gl = (c8 * 8 + j) / p.cg;
+    const float mean = st[2 * gl], rstd = st[2 * gl + 1];
+    const float ga = p.gamma[ch0 + j], be = p.beta[ch0 + j];
+    sc[j] = rstd * ga;
+    sh[j] = be - mean * rstd * ga;
+  }
+  uint16_t* const tdst = p.Y + ((int64_t)b * p.rows + rbase) * p.C + ch0;
+  const uint32_t dstride = step * (uint32_t)p.C;
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+    if ((uint32_t)i < nv) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f[j] = ((j & 1) ? hi16(v[i][j >> 1]) : lo16(v[i][j >> 1])) * sc[j] + sh[j];
+        if (p.silu) f[j] = f[j] / (1.f + __expf(-f[j]));
+      }
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack16(f[2 * j], f[2 * j + 1]);
+      if constexpr (STREAM) st_stream(tdst + (uint32_t)i * dstride, o); else *reinterpret_cast<u32x4_t*>(tdst + (uint32_t)i * dstride) = o;
+    }
+  }
+}
+
+// slab / thread plan of gn_fused_kernel; false: the instance does not fit (three-launch path)
+struct GNFPlan { int sg, nx, ny, threads, nslab, iters; };
+inline bool gn_fused_plan(int64_t rows, int C, int groups, GNFPlan& out) {
+  const int cg = C / groups;
+  int best_sg = 0;
+  for (int sg = 1; sg <= groups; ++sg) {                 // widest slab (<= 640 bytes per row) that fits the registers of 512 threads
+    if (groups % sg != 0 || (sg * cg) % 8 != 0) continue;
+    const int nx = sg * cg / 8;
+    if (nx > 64 || sg * cg * 2 > 640) break;
+    const int ny = 512 / nx;
+    if ((rows + ny - 1) / ny <= GNF_RMAX) best_sg = sg;
+  }
+  if (best_sg == 0) return false;
+  out.sg = best_sg; out.nx = best_sg * cg / 8; out.nslab = groups / best_sg;
+  out.threads = 512;
+  {                                                      // 256 threads when they still hold the slab in <= 21 chunks each
+    const int ny = 256 / out.nx;
+    if (ny >= 1 && (rows + ny - 1) / ny <= 21 && 8 * out.nx <= 256) out.threads = 256;
+  }
+  out.ny = out.threads / out.nx;
+  out.iters = (int)((rows + out.ny - 1) / out.ny);
+  return 8 * out.nx <= out.threads && out.sg <= out.threads;
+}
+
+template <bool STREAM>
+void gn_fused_launch(const GNParams& p, const GNFPlan& pl, int B, size_t smem, hipStream_t s) {
+  const dim3 grid((unsigned)(B * pl.nslab)), block(pl.threads);
+  if (pl.iters <= 11) gn_fused_kernel<STREAM, 11><<<grid, block, smem, s>>>(p, pl.sg, pl.nx, pl.ny, pl.nslab);
+  else gn_fused_kernel<STREAM, 21><<<grid, block, smem, s>>>(p, pl.sg, pl.nx, pl.ny, pl.nslab);
+}
+
 // ---------------- LayerNorm: one wave per row, up to 3 16-byte chunks per lane (C <= 1536)
 struct LNParams {
   const uint16_t* X; uint16_t* Y1; uint16_t* Y2; const float* gamma; const float* beta;
@@ -363,11 +526,21 @@ static int group_norm_launch(int mode, a3d_stream_t stream, const void* X, void*
   p.eps = eps; p.silu = silu;
   p.partial = ws; p.stats = mode == 2 ? const_cast<float*>(stats_in) : ws + (int64_t)B * p.nchunk * groups * 2;
   p.sums = mode == 1 ? sums : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) {
+    GNFPlan pl;
+    if (gn_fused_plan(rows, C, groups, pl) && (int64_t)B * pl.nslab <= 0x7fffffffLL && rows * (int64_t)C * 2 < (1ll << 31)) {
+      const size_t smem = ((size_t)pl.ny * pl.nx * 4 + (size_t)8 * pl.nx * 4 + (size_t)2 * pl.sg) * sizeof(float);
+      const bool full_lines = (pl.sg * p.cg * 2) % 128 == 0 && Xb == nullptr;      // (every slab then starts on a line: C % (sg cg) == 0)
+      if (full_lines) gn_fused_launch<true>(p, pl, B, smem, s);
+      else gn_fused_launch<false>(p, pl, B, smem, s);
+      return a3d_launch_status();
+    }
+  }
   const int c8 = C / 8;
   int ny = 256 / c8; if (ny < 1) ny = 1; if (ny > 32) ny = 32;
   if (c8 * ny < groups) return A3D_EINVAL;
   const dim3 block(c8, ny), grid(p.nchunk, B);
-  hipStream_t s = (hipStream_t)stream;
   if (mode != 2) {
     gn_partial_kernel<<<grid, block, (size_t)c8 * ny * 4 * sizeof(float), s>>>(p);
     const int gx = (groups + 31) / 32 * 32;

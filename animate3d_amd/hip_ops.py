@@ -67,6 +67,8 @@ _SIGNATURES = {
                                     c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "a3d_flash_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                     c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int]),
+    "a3d_flash_attn_counted_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
+                                            c_int, c_int, c_int, c_i64, c_i64, c_f32, c_f32, c_int, c_vp]),
     "a3d_flash_attn2_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC), ctypes.POINTER(_RowMapC),
                                      ctypes.POINTER(_RowMapC), c_int, c_int, c_int, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32, c_int]),
     "a3d_temporal_attn_bf16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_int, c_f32]),
@@ -191,7 +193,10 @@ class HipOps:
 
     has_attn_lse = True      # flash_attn(with_lse=True) / flash_attn_bwd(o=..., lse=...): see autograd_ops._FlashAttn
 
-    def __init__(self, device: Optional[torch.device] = None, act_dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, device: Optional[torch.device] = None, act_dtype: torch.dtype = torch.bfloat16, split_k: bool = True):
+        """``split_k`` = False: only kernels whose results do not depend on the launch shape (bit-for-bit batch independence, a sharded forward
+        bit-equal to the unsharded one); True (default): the small-M / long-K convolutions and linears split their K sum over idle CUs —
+        deterministic per launch shape, equal to the unsplit kernels to fp32 summation order."""
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a visible MI355X (torch.cuda.is_available() is False); no CPU fallback exists")
         if act_dtype not in (torch.bfloat16, torch.float16):
@@ -209,12 +214,23 @@ class HipOps:
         # split-K of the small-M / long-K GEMMs and convs (UNet levels 2 / 3, the whole 4D-SDS shape): on by default; results then agree
         # with the unsplit kernels to fp32 summation order only, so runs that are compared BIT FOR BIT across different row counts
         # (a sharded forward against the unsharded one: animate3d_amd.parallel turns it off) must not use it
-        self.split_k = True
+        self.split_k = bool(split_k)
         # ... of dense GEMMs too: off.  Measured (profiles/r5_microbench_splitk.log): the mid-block convolutions (K = 11 520 ... 23 040) gain
         # 13-55 %, but the level-2 / 3 linears (K <= 5 120, 35-120 us per launch) LOSE 20-100 %: 84 MB of fp32 partials written and read
         # back plus a second launch cost more than the idle CUs return.  The entry point and its tests stay (a3d_gemm_ws_*).
         self.split_k_gemm = False
+        # diagnostics (a3d_flash_attn_counted): an int32 device tensor of 3 words that every plain ``flash_attn`` call adds to while it is set —
+        # [0] workgroups of the LDS-DMA staged attention kernels sent to the exact pass by the fp16 spread vote, [1] exact re-runs after an
+        # overflow of the max-free pass, [2] workgroups launched.  None (default): the plain entry point.
+        self.attn_counters = None
         self._ws_plan = {}           # launch shape -> split-K workspace bytes (0: the shape does not split)
+        self._ws_buf = None          # ONE split-K workspace per op set, grown to the largest need (launches on one stream run in order,
+                                     # so consecutive split launches may share it; a fresh 100-MB torch.empty per call was the alternative)
+
+    def _workspace(self, need: int) -> torch.Tensor:
+        if self._ws_buf is None or self._ws_buf.numel() < need:
+            self._ws_buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws_buf
 
     def _gemm_flags(self, tile128: bool) -> int:
         r = int(self.reserved_cus)
@@ -268,7 +284,7 @@ class HipOps:
                 _check(self.lib.a3d_gemm_ws_bf16(*args, None, 0, ctypes.byref(q)), f"a3d_gemm_ws_bf16 (query) M={M} N={N} K={K}")
                 need = self._ws_plan[key] = int(q.value)
             if need > 0:
-                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws = self._workspace(need)
                 _check(self.lib.a3d_gemm_ws_bf16(*args, _p(ws), need, None), f"a3d_gemm_ws_bf16 M={M} N={N} K={K}")
                 return y
         rc = self.lib.a3d_gemm_bf16(*args)
@@ -343,7 +359,7 @@ class HipOps:
                 _check(self.lib.a3d_conv3x3_ws_bf16(*args, None, 0, ctypes.byref(q)), f"a3d_conv3x3_ws_bf16 (query) B={B} H={H} W={W} Cin={Cin} Cout={Cout}")
                 need = self._ws_plan[key] = int(q.value)
             if need > 0:
-                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws = self._workspace(need)
                 _check(self.lib.a3d_conv3x3_ws_bf16(*args, _p(ws), need, None), f"a3d_conv3x3_ws_bf16 B={B} H={H} W={W} Cin={Cin} Cout={Cout}")
                 return y, Ho, Wo
         rc = self.lib.a3d_conv3x3_bf16(*args)
@@ -372,6 +388,13 @@ class HipOps:
                                                   flags, _p(lse))
             _check(rc, f"a3d_flash_attn_lse_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
             return o, lse
+        if self.attn_counters is not None:
+            cnt = self.attn_counters
+            assert cnt.dtype == torch.int32 and cnt.is_cuda and cnt.numel() >= 3 and cnt.is_contiguous()
+            rc = self.lib.a3d_flash_attn_counted_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
+                                                      groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, flags, _p(cnt))
+            _check(rc, f"a3d_flash_attn_counted_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")
+            return o
         rc = self.lib.a3d_flash_attn_bf16(self._stream(), _p(q), _p(k), _p(v), _p(o), ctypes.byref(qm), ctypes.byref(km), ctypes.byref(om),
                                           groups, heads, D, q_len, kv_len, float(D) ** -0.5, out_scale, flags)
         _check(rc, f"a3d_flash_attn_bf16 groups={groups} heads={heads} D={D} q_len={q_len} kv_len={kv_len}")

@@ -235,7 +235,7 @@ ViewParallel = ShardPlan          # name of the round-1 plan (views only)
 class RankShapePlan(ShardPlan):
     """The COMPUTE leg of rank 0 of layout (cfg, views, frames) in a single process, without a process group: the model cuts rank 0's
     shard out of the full call and launches exactly the kernels that rank launches — local rows, the K|V projection over the gathered
-    token count, attention with q_len != kv_len through the unsharded row maps, split-K off, the CU reservation while a "gather" is in
+    token count, attention with q_len != kv_len through the unsharded row maps, the CU reservation while a "gather" is in
     flight — with every data-path collective replaced by local device copies of the right size (the peers' blocks are copies of this
     rank's block, so the outputs are NOT the sharded job's outputs; only the launch shapes and the timing are).  ``bench.py --rank-shape
     c,v,f`` measures a rank's compute time on the one GPU a builder has; link time is not in it."""
@@ -305,26 +305,41 @@ class _NoWork:
 
 
 def rank_shape_unet(unet, layout: Sequence[int]) -> RankShapePlan:
-    """Attach a RankShapePlan (single process, no torch.distributed): see the class.  Mirrors ``shard_unet``'s op-set settings."""
+    """Attach a RankShapePlan (single process, no torch.distributed): see the class.  Same op-set settings as ``shard_unet``."""
     unet.parallel = RankShapePlan(layout)
     ops = getattr(unet, "ops", None)
     unet.parallel.ops = ops if hasattr(ops, "reserved_cus") else None
-    if unet.parallel.ops is not None and hasattr(ops, "split_k"):
-        ops.split_k = False
+    unet.parallel._restore_split_k = None
     return unet.parallel
 
 
-def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: Optional[Tuple[int, int, int]] = None) -> ShardPlan:
+def shard_unet(unet, group=None, layout: Optional[Sequence[int]] = None, shape: Optional[Tuple[int, int, int]] = None,
+               bit_exact: bool = False) -> ShardPlan:
     """Attach a ShardPlan to a MVUNetMotionModel (every rank, same order).  ``layout`` = (cfg_shards, view_shards,
     frame_shards) or None for the default (CFG halves, then views, then frames); ``shape`` = (b, n, F) of the calls to come
-    creates the process groups now instead of inside the first forward."""
+    creates the process groups now instead of inside the first forward.  ``bit_exact``: sharded ranks see other row counts than the
+    unsharded job, and split-K (HipOps.split_k: the 8 x 8 / 4 x 4 convolutions and small-M linears of levels 2 / 3) re-associates the K
+    sum per launch shape — True turns it off for this op set until ``unshard_unet`` so that a CFG- / view-sharded forward equals the
+    unsharded one (run with split_k off as well) BIT FOR BIT; the default keeps it: a rank of 8 runs its level-3 convolutions 4-10 x
+    faster with it (profiles/README.md, round 6) and agrees with the unsharded job to fp32 summation order."""
     unet.parallel = ShardPlan(group, layout)
     ops = getattr(unet, "ops", None)                                # HIP op set: reserve CUs for RCCL while a gather overlaps the GEMMs
     unet.parallel.ops = ops if hasattr(ops, "reserved_cus") else None
-    if unet.parallel.ops is not None and hasattr(ops, "split_k"):
-        # sharded ranks see different row counts than the unsharded job: keep the kernels whose results do not depend on the launch shape
-        # (split-K re-associates the K sum per shape), so that a sharded forward stays bit-comparable with the unsharded one
+    unet.parallel._restore_split_k = None
+    if bit_exact and unet.parallel.ops is not None and hasattr(ops, "split_k"):
+        unet.parallel._restore_split_k = bool(ops.split_k)
         ops.split_k = False
     if shape is not None:
         unet.parallel.configure(*shape)
     return unet.parallel
+
+
+def unshard_unet(unet) -> None:
+    """Detach the plan: drops any CU reservation and gives the op set its split-K setting back (the op set may be shared with other models)."""
+    par = getattr(unet, "parallel", None)
+    if par is None:
+        return
+    par.release_reservation()
+    if getattr(par, "_restore_split_k", None) is not None and par.ops is not None:
+        par.ops.split_k = par._restore_split_k
+    unet.parallel = None

@@ -149,6 +149,16 @@ int a3d_flash_attn_bf16(a3d_stream_t stream, const void* Q, const void* K, const
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
                         float scale, float out_scale, int accumulate);
 
+/* a3d_flash_attn plus diagnostics of the LDS-DMA staged kernels (head_dim 40 / 80 on long aligned K/V): `counters` = 3 caller-zeroed
+ * device words; [0] += workgroups sent straight to the exact pass by the fp16 spread vote, [1] += workgroups that discarded a max-free
+ * result and re-ran exactly (overflow), [2] += workgroups launched.  Launches of the other kernels leave the words alone.  The reference has
+ * no counterpart (xformers.ops.memory_efficient_attention, attention_processor.py:405,416,656, always keeps a running maximum); this
+ * exists so that parity tests on peaked softmax inputs can assert how much of a launch left the fast path.  Same results as a3d_flash_attn. */
+int a3d_flash_attn_counted_bf16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                                const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                                int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                                float scale, float out_scale, int accumulate, unsigned int* counters);
+
 /* Two key sets in one launch, each with its own softmax:
  *   O = out_scale * attn(Q, K, V) + out_scale2 * attn(Q, K2, V2)   (+ previous O contents if accumulate)
  * Replaces the text-token attention, the per-adapter image-token attention and `hidden_states = hidden_states + scale * ip` of the
@@ -379,6 +389,10 @@ int a3d_flash_attn_f16(a3d_stream_t stream, const void* Q, const void* K, const 
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
                         float scale, float out_scale, int accumulate);
+int a3d_flash_attn_counted_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, void* O,
+                               const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* omap,
+                               int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len,
+                               float scale, float out_scale, int accumulate, unsigned int* counters);
 int a3d_flash_attn2_f16(a3d_stream_t stream, const void* Q, const void* K, const void* V, const void* K2, const void* V2, void* O,
                         const a3d_rowmap* qmap, const a3d_rowmap* kmap, const a3d_rowmap* kmap2, const a3d_rowmap* omap,
                         int groups, int heads, int head_dim, int64_t q_len, int64_t kv_len, int64_t kv_len2,

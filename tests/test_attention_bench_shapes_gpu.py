@@ -119,3 +119,45 @@ def test_level2_launch_shape_head_dim_160(dtype, tol, gain, L):
         assert torch.isfinite(got).all() and err <= (tol if gain < 10 else 1e-2), (name, err)
         assert worst <= 0.25, (name, worst)
         assert torch.equal(got, ops.flash_attn(q, k, v, qm, km, 2, heads, S, S).float()), "run-to-run reproducible"
+
+
+@pytest.mark.parametrize("D,S", [(40, 2048), (80, 2048)])
+@pytest.mark.parametrize("frac", [0.125, 0.5])
+def test_fp16_mixed_workgroup_minority_of_wide_rows(D, S, frac):
+    """the fp16 spread predictor is a VOTE (> 25 % of a workgroup's queries must predict an overflow of the 20-binade window for
+    the workgroup to skip the max-free pass).  A workgroup in which a MINORITY of the queries is genuinely wide (score sd ~12 nats) while
+    the rest is flat is accepted by the vote; its wide rows then rely on the row-sum check alone.  frac = 1/8: every workgroup is such a
+    mix -> nothing is voted exact, the overflowing workgroups must re-run exactly (counter [1]) and the result must match the exact-only
+    launch; frac = 1/2: the vote sends the workgroups straight to the exact pass (counter [0])."""
+    ops = _ops(torch.float16)
+    heads, C = 8, 8 * D
+    g = torch.Generator(device="cuda").manual_seed(77 + D)
+    q = torch.randn(S, C, generator=g, device="cuda") * 0.5            # flat rows: score sd ~0.5 nats
+    k = torch.randn(S, C, generator=g, device="cuda")
+    v = torch.randn(S, C, generator=g, device="cuda")
+    wide = torch.zeros(S, dtype=torch.bool, device="cuda")
+    step = int(round(1 / frac))
+    wide[::step] = True                                                # spread over every workgroup's query tile
+    q[wide] *= 24.0                                                    # score sd ~12 nats = ~17 log2 units: the row maximum over 2 048 keys sits ~1.35 sd
+                                                                       # = ~23 units above the maximum of the 32 samples, beyond the 20-unit window
+    q, k, v = q.to(torch.float16), k.to(torch.float16), v.to(torch.float16)
+    m = RowMap(1, S, 0, S, 0)
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ops.attn_counters = cnt
+    got = ops.flash_attn(q, k, v, m, m, 1, heads, S, S).float()
+    ops.attn_counters = None
+    voted, rerun, launched = (int(x) for x in cnt[:3].tolist())
+    exact = ops.flash_attn(q, k, v, m, m, 1, heads, S, S, exact=True).float()
+    want = chunked_attention_fp32(q, k, v, m, m, 1, heads, S, S)
+    err = ((got - want).norm() / want.norm()).item()
+    err_exact = ((exact - want).norm() / want.norm()).item()
+    worst = ((got - want).norm(dim=1) / (want.norm(dim=1) + 1e-6)).max().item()
+    print(f"[parity] fp16 mixed workgroups D={D} wide fraction {frac}: rel L2 {err:.3e} (exact-only launch {err_exact:.3e}), worst row {worst:.3e}; "
+          f"workgroups {launched}, voted exact {voted}, re-ran after overflow {rerun}")
+    assert torch.isfinite(got).all() and err <= 1.5e-3 and worst <= 0.05, (err, worst)
+    assert launched > 0
+    if frac < 0.25:
+        assert voted == 0, "a 12.5 % minority must not win the vote"
+        assert rerun > 0, "score sd 12 overflows fp16's window above the sampled offset: the row-sum check has to catch it"
+    else:
+        assert voted == launched and rerun == 0, "half the rows wide: every workgroup goes exact on the vote"

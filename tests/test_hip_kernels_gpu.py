@@ -500,7 +500,11 @@ def test_group_norm_split_halves(ops, ref, B, rows, C, shards):
         want = fused.reshape(B, shards, rl, C)[:, r].reshape(B * rl, C)
         check(f"group_norm split shard {r}/{shards} C{C}", got, want, tol=4e-3, max_ulps=2)
 
-@pytest.mark.parametrize("B,rows,C", [(3, 64, 320), (2, 300, 640), (2, 256, 960), (1, 1000, 1280), (2, 64, 1920), (2, 16, 2560), (1, 4, 1280)])
+# round 6: instances that fit a workgroup's registers (norms.hip: gn_fused_kernel, <= 21 16-byte chunks per thread) take the one-launch kernel —
+# every shape of the first line, 2000 x 1280 and 1024 x 640 (21 chunks per thread, 512 threads), 1024 x 320 (BASELINE config 5's level 0);
+# 4096 x 320 / 4096 x 1280 / 2100 x 640 stay on the three-launch path (statistics workspace)
+@pytest.mark.parametrize("B,rows,C", [(3, 64, 320), (2, 300, 640), (2, 256, 960), (1, 1000, 1280), (2, 64, 1920), (2, 16, 2560), (1, 4, 1280),
+                                      (1, 2000, 1280), (2, 1024, 640), (3, 1024, 320), (2, 4096, 320), (1, 4096, 1280), (2, 2100, 640), (9, 256, 1280)])
 @pytest.mark.parametrize("silu", [False, True])
 def test_group_norm(ops, ref, B, rows, C, silu):
     x = rnd(B * rows, C, seed=C) + 0.5
@@ -508,6 +512,21 @@ def test_group_norm(ops, ref, B, rows, C, silu):
     beta = 0.1 * rnd(C, seed=2, dtype=torch.float32)
     check(f"group_norm B{B} rows{rows} C{C} silu{int(silu)}", ops.group_norm(x, B, rows, gamma, beta, 32, 1e-5, silu),
           ref.group_norm(x, B, rows, gamma, beta, 32, 1e-5, silu), tol=4e-3, max_ulps=3)
+
+
+@pytest.mark.parametrize("rows,C", [(256, 1280), (1024, 640), (64, 1920), (4096, 320)])
+def test_group_norm_does_not_depend_on_the_batch(ops, rows, C):
+    """An instance's result must not depend on how many instances the launch holds (a CFG- / view-sharded rank normalises a slice of the
+    batch and has to reproduce the unsharded job bit for bit): one-launch and three-launch paths alike."""
+    x = rnd(5 * rows, C, seed=C + rows) + 0.25
+    gamma = 1 + 0.1 * rnd(C, seed=1, dtype=torch.float32)
+    beta = 0.1 * rnd(C, seed=2, dtype=torch.float32)
+    full = ops.group_norm(x, 5, rows, gamma, beta, 32, 1e-5, True)
+    for b in (0, 3):
+        one = ops.group_norm(x[b * rows:(b + 1) * rows].contiguous(), 1, rows, gamma, beta, 32, 1e-5, True)
+        assert torch.equal(one, full[b * rows:(b + 1) * rows])
+    two = ops.group_norm(x[rows:3 * rows].contiguous(), 2, rows, gamma, beta, 32, 1e-5, True)
+    assert torch.equal(two, full[rows:3 * rows])
 
 
 # M >= 4096 with C in {320, 640, 1280} takes the sub-wave-rows kernel (ragged last batch: M not a multiple of the rows per block)

@@ -46,13 +46,13 @@ def _worker(rank, world, port, n, F, hw, videos, layout, q, backend="gloo"):
         # size.  They are therefore compared in fp16 storage, where rounding noise is 8x smaller and a wrong row is not.
         frames_sharded = layout is not None and layout[2] > 1
         model = model.to(torch.float16 if frames_sharded else torch.bfloat16).eval()
-        # the unsharded reference on the kernels the sharded ranks use: shard_unet turns split-K off (it re-associates the K sum per launch
+        # the unsharded reference on the kernels the sharded ranks use: shard_unet(bit_exact=True) turns split-K off (it re-associates the K sum per launch
         # shape).  After .to(): the automatic op set follows the model's dtype and is re-created by it.
         model.ops.split_k = False
         inp = O.synthetic_inputs(O.UNetConfig(), videos, n, F, hw, seed=11, cfg_doubled=videos >= 2 * n)
         inp = {k: (v.cuda() if torch.is_tensor(v) else ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v)) for k, v in inp.items()}
         full = model(**inp).sample
-        par = shard_unet(model, layout=layout, shape=(videos // n, n, F))
+        par = shard_unet(model, layout=layout, shape=(videos // n, n, F), bit_exact=True)
         sharded = model(**inp).sample
         par.gather_tokens = False
         sharded_kv = model(**inp).sample

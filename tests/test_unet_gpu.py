@@ -361,3 +361,67 @@ def test_controlnet_residual_inputs_on_the_gpu():
     e, mx, sc = _rel(y, y_ref)
     print(f"[parity] ControlNet residual inputs, fp16 storage vs oracle: rel_l2={e:.3e} (residuals move the output by {_rel(y_plain, y_ref)[0]:.3e})")
     assert e < 6e-3 and _rel(y_plain, y_ref)[0] > 10 * e
+
+
+def _peaked(sd, gain):
+    """A copy of the state dict with every query / key projection of the multi-view, first-frame and spatial motion attentions scaled by
+    ``gain``: the seeded Kaiming-uniform weights give attention scores of sd ~0.33 nats (a nearly flat softmax, the max-free kernels never
+    leave their fast path); gain 3 on both sides gives sd ~3 — the peaked softmax of trained MV-VDM weights."""
+    out, hit = {}, 0
+    for k, v in sd.items():
+        t2d = k.endswith(("attn1.to_q.weight", "attn1.to_k.weight")) and "motion_modules" not in k
+        if t2d or k.endswith(("to_q_i2v.weight", "to_q_sp.weight", "to_k_sp.weight")):
+            v = v * gain
+            hit += 1
+        out[k] = v
+    assert hit > 0
+    return out
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.bfloat16, 3e-2), (torch.float16, 6e-3)], ids=["bf16", "fp16"])
+def test_forward_parity_on_a_peaked_softmax(dtype, bar):
+    """VERDICT r5 weak spot 2: every other end-to-end test draws Kaiming weights (score sd ~0.3), so the spike / overflow / exact-re-run
+    machinery of the LDS-DMA staged attention kernels was only ever covered at kernel level.  Here the q / k projections are scaled so
+    that level-0 scores have sd ~3 (natural-log units), two real-width levels at a 32 x 32 latent so that BOTH staged kernels run
+    (head_dim 40 over 2 048 keys, head_dim 80 over 512 keys), against the fp32 oracle with the same weights; bars unchanged.  The
+    diagnostics counters (a3d_flash_attn_counted) say how many workgroups left the max-free fast path."""
+    arch = dict(block_out_channels=(320, 640), down_has_attn=(True, True), layers_per_block=1)
+    n, F, hw, V = 2, 2, (32, 32), 2
+    ocfg = O.UNetConfig(**arch)
+    base = O.build_dense(ocfg, n, F, hw, seed=0)
+    sd = _peaked(base.state_dict(), 3.0)
+    ref = O.build_dense(ocfg, n, F, hw, state_dict=sd)
+    hip = MVUNetMotionModel(UNetConfig(**arch), num_views=n, device="cuda")
+    missing, unexpected = hip.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    hip = hip.to(dtype).eval()
+    inp = O.synthetic_inputs(ocfg, V, n, F, hw, seed=21)
+    y_ref = ref(**inp).sample
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    hip.ops.attn_counters = cnt
+    try:
+        y = hip(**_cuda(inp)).sample
+    finally:
+        hip.ops.attn_counters = None
+    voted, rerun, launched = (int(v) for v in cnt[:3].tolist())
+    e, mx, sc = _rel(y, y_ref)
+    # the same model on flat scores, as a reference point for the error and the counters
+    hip0 = MVUNetMotionModel(UNetConfig(**arch), num_views=n, device="cuda")
+    hip0.load_state_dict(base.state_dict(), strict=True)
+    hip0 = hip0.to(dtype).eval()
+    cnt0 = torch.zeros(4, dtype=torch.int32, device="cuda")
+    hip0.ops.attn_counters = cnt0
+    y0 = hip0(**_cuda(inp)).sample
+    e0, _, _ = _rel(y0, base(**inp).sample)
+    voted0, rerun0, launched0 = (int(v) for v in cnt0[:3].tolist())
+    print(f"[parity] peaked softmax ({dtype}): hip-vs-oracle rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e}); staged-kernel workgroups {launched}, "
+          f"sent exact by the spread vote {voted}, exact re-runs after overflow {rerun}; flat scores: rel_l2={e0:.3e}, {launched0} / {voted0} / {rerun0}")
+    assert torch.isfinite(y).all() and e <= bar, f"HIP vs fp32 oracle on a peaked softmax: {e:.3e}"
+    assert launched > 0 and launched == launched0, "the LDS-DMA staged attention kernels did not run"
+    assert voted0 == 0 and rerun0 == 0, "flat scores must stay on the max-free fast path"
+    if dtype == torch.bfloat16:
+        assert voted == 0 and rerun == 0, "bf16 storage: sd 3 is far inside the 2^100 window, nothing may leave the fast path"
+    else:
+        # fp16 storage: P has a 20-binade window above the sampled offset; at sd 3 a minority of workgroups may go exact (profiles/README.md,
+        # round 5: the OR-predictor sent EVERY workgroup there and nobody noticed because the results stayed right)
+        assert (voted + rerun) * 2 <= launched, f"{voted} + {rerun} of {launched} workgroups left the fast path at score sd 3"

@@ -152,6 +152,50 @@ def bench_conv(ops):
         print(f"B={B} {H}x{W} {Cin:4d}->{Cout:4d} s{st} up{int(up)}: " + "  ||  ".join(out))
 
 
+def bench_smallm(ops):
+    """The small-M shapes of a multi-GPU rank / BASELINE config 5: level 2 / 3 linears (M = 1024 ... 16384), GroupNorm
+    instances of a few hundred rows, mid-block convolutions of 16 images.  Linears: default dispatch | 128 x 128 kernel | split-K."""
+    print("== small-M linears: default | tile128 | split-K (HipOps.split_k_gemm); median ms / TFLOP/s")
+    shapes = [(1024, 1280, 1280, 0), (1024, 1280, 2560, 1), (1024, 1280, 5120, 1), (1024, 3840, 1280, 0), (1024, 10240, 1280, 0),
+              (2048, 1280, 1280, 0), (2048, 1280, 2560, 1), (2048, 1280, 5120, 1), (2048, 3840, 1280, 0),
+              (4096, 1280, 1280, 0), (4096, 1280, 2560, 1), (4096, 1280, 5120, 1), (4096, 2560, 1280, 0), (4096, 3840, 1280, 0),
+              (8192, 1280, 1280, 1), (8192, 1280, 2560, 1), (8192, 1280, 5120, 1), (8192, 3840, 1280, 0),
+              (16384, 640, 640, 1), (16384, 640, 1280, 1), (16384, 640, 2560, 1), (16384, 1920, 640, 0), (16384, 2560, 1280, 0),
+              (32768, 640, 640, 1), (65536, 320, 320, 1), (65536, 960, 320, 0), (131072, 320, 320, 1)]
+    for (M, N, K, r) in shapes:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N) if r else None
+        fl = 2.0 * M * N * K
+        out = []
+        for name, kw, sk in (("default", {}, False), ("tile128", dict(tile128=True), False), ("split-K", {}, True)):
+            ops.split_k_gemm = sk
+            med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res, **kw), reps=15, warm=3)
+            out.append(f"{name} {med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s")
+        ops.split_k_gemm = False
+        print(f"M={M:6d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + "  |  ".join(out), flush=True)
+    print("== GroupNorm (+SiLU) instances: B x rows x C; median us / GB/s (algorithmic: read + write)")
+    for (B, rows, C) in [(16, 256, 1280), (16, 64, 1280), (1, 1024, 1280), (1, 4096, 1280), (16, 1024, 640), (16, 4096, 320), (32, 256, 1280), (32, 64, 1280),
+                         (128, 256, 1280), (128, 64, 1280), (128, 1024, 640), (128, 4096, 320), (8, 4096, 1280), (8, 1024, 1280), (16, 256, 2560), (16, 256, 1920)]:
+        x = rnd(B * rows, C)
+        gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        med, mn = timeit(lambda: ops.group_norm(x, B, rows, gam, bet, 32, 1e-5, True), reps=15, warm=3)
+        print(f"group_norm B={B:3d} rows={rows:5d} C={C:4d}: {med * 1e3:7.1f} us  {2.0 * x.numel() * 2 / med / 1e6:7.0f} GB/s", flush=True)
+    print("== mid-block convolutions of a rank of 8 (B = 16 images): split-K on | off")
+    for (B, H, W, Cin, Cout) in [(16, 8, 8, 1280, 1280), (16, 8, 8, 2560, 1280), (16, 16, 16, 1280, 1280), (16, 16, 16, 2560, 1280), (16, 32, 32, 640, 640),
+                                 (32, 8, 8, 1280, 1280), (32, 16, 16, 1280, 1280), (128, 4, 4, 1280, 1280)]:
+        x, w = rnd(B * H * W, Cin), rnd(Cout, 9 * Cin, scale=(9 * Cin) ** -0.5)
+        bias = torch.randn(Cout, device="cuda")
+        fl = 2.0 * B * H * W * 9 * Cin * Cout
+        out = []
+        for sk in (True, False):
+            ops.split_k = sk
+            med, mn = timeit(lambda: ops.conv3x3(x, B, H, W, w, bias), reps=15, warm=3)
+            out.append(f"split_k={sk}: {med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s")
+        ops.split_k = True
+        print(f"conv3x3 B={B:3d} {H}x{W} {Cin}->{Cout}: " + "  |  ".join(out), flush=True)
+
+
 def bench_gemmscale(ops):
     """Per-K-tile time of the persistent GEMM against the number of active CUs: G output tiles of 256 x 320 (one per workgroup),
     K = 5120 (80 K-tiles per tile), so the time of a launch is 80 x the K-tile period (+ one epilogue).  Flat in G = latency /
@@ -338,7 +382,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "smallm": bench_smallm, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "flash160": lambda o: bench_flash(o, ((160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
