@@ -77,7 +77,9 @@ A3D_DEV const uint16_t* dm_scalar(const uint16_t* ptr) {      // wave-uniform by
 
 // one thread of the workgroup books an event of the diagnostics counters (cold paths only)
 A3D_DEV void dm_count(const AttnParams& p, int which) {
+#ifndef A3D_EXP_R5_PATHS          // (measurement build: the round-5 kernels without the counters, for the same-box A/B of the level-0 launch)
   if (p.counters != nullptr && threadIdx.x == 0) atomicAdd(p.counters + which, 1u);
+#endif
 }
 
 A3D_DEV uint32_t fa_lds_addr(const void* p) {

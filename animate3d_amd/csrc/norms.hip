@@ -265,19 +265,23 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const GNParams p, const i
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         f[j] = ((j & 1) ? hi16(v[i][j >> 1]) : lo16(v[i][j >> 1])) * sc[j] + sh[j];
-        if (p.silu) f[j] = f[j] / (1.f + __expf(-f[j]));
+        if (p.silu) f[j] = f[j] * __builtin_amdgcn_rcpf(1.f + __expf(-f[j]));      // (v_rcp_f32: 1 ulp; the IEEE division is ~20 instructions per element)
       }
       u32x4_t o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = pack16(f[2 * j], f[2 * j + 1]);
       if constexpr (STREAM) st_stream(tdst + (uint32_t)i * dstride, o); else *reinterpret_cast<u32x4_t*>(tdst + (uint32_t)i * dstride) = o;
     }
+    __builtin_amdgcn_sched_barrier(0);          // row by row (registers: the data alone are 4 RMAX)
   }
 }
 
 // slab / thread plan of gn_fused_kernel; false: the instance does not fit (three-launch path)
 struct GNFPlan { int sg, nx, ny, threads, nslab, iters; };
 inline bool gn_fused_plan(int64_t rows, int C, int groups, GNFPlan& out) {
+#ifdef A3D_EXP_R5_PATHS
+  return false;          // measurement build (tools/microbench.py, A3D_LIB=...): the round-5 three-launch GroupNorm for every instance
+#endif
   const int cg = C / groups;
   int best_sg = 0;
   for (int sg = 1; sg <= groups; ++sg) {                 // widest slab (<= 640 bytes per row) that fits the registers of 512 threads

@@ -174,13 +174,7 @@ def bench_smallm(ops):
             out.append(f"{name} {med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s")
         ops.split_k_gemm = False
         print(f"M={M:6d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + "  |  ".join(out), flush=True)
-    print("== GroupNorm (+SiLU) instances: B x rows x C; median us / GB/s (algorithmic: read + write)")
-    for (B, rows, C) in [(16, 256, 1280), (16, 64, 1280), (1, 1024, 1280), (1, 4096, 1280), (16, 1024, 640), (16, 4096, 320), (32, 256, 1280), (32, 64, 1280),
-                         (128, 256, 1280), (128, 64, 1280), (128, 1024, 640), (128, 4096, 320), (8, 4096, 1280), (8, 1024, 1280), (16, 256, 2560), (16, 256, 1920)]:
-        x = rnd(B * rows, C)
-        gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
-        med, mn = timeit(lambda: ops.group_norm(x, B, rows, gam, bet, 32, 1e-5, True), reps=15, warm=3)
-        print(f"group_norm B={B:3d} rows={rows:5d} C={C:4d}: {med * 1e3:7.1f} us  {2.0 * x.numel() * 2 / med / 1e6:7.0f} GB/s", flush=True)
+    bench_gn(ops)
     print("== mid-block convolutions of a rank of 8 (B = 16 images): split-K on | off")
     for (B, H, W, Cin, Cout) in [(16, 8, 8, 1280, 1280), (16, 8, 8, 2560, 1280), (16, 16, 16, 1280, 1280), (16, 16, 16, 2560, 1280), (16, 32, 32, 640, 640),
                                  (32, 8, 8, 1280, 1280), (32, 16, 16, 1280, 1280), (128, 4, 4, 1280, 1280)]:
@@ -194,6 +188,17 @@ def bench_smallm(ops):
             out.append(f"split_k={sk}: {med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s")
         ops.split_k = True
         print(f"conv3x3 B={B:3d} {H}x{W} {Cin}->{Cout}: " + "  |  ".join(out), flush=True)
+
+
+def bench_gn(ops):
+    print("== GroupNorm (+SiLU) instances: B x rows x C; median us / GB/s (algorithmic: read + write)")
+    for (B, rows, C) in [(16, 256, 1280), (16, 64, 1280), (1, 1024, 1280), (1, 4096, 1280), (16, 1024, 640), (16, 4096, 320), (32, 256, 1280), (32, 64, 1280),
+                         (128, 256, 1280), (128, 64, 1280), (128, 1024, 640), (128, 4096, 320), (8, 4096, 1280), (8, 1024, 1280), (16, 256, 2560), (16, 256, 1920),
+                         (64, 256, 1280), (64, 1024, 640), (64, 64, 1280), (128, 1024, 320), (128, 256, 640), (128, 64, 2560), (128, 256, 1920), (128, 1024, 960)]:
+        x = rnd(B * rows, C)
+        gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        med, mn = timeit(lambda: ops.group_norm(x, B, rows, gam, bet, 32, 1e-5, True), reps=15, warm=3)
+        print(f"group_norm B={B:3d} rows={rows:5d} C={C:4d}: {med * 1e3:7.1f} us  {2.0 * x.numel() * 2 / med / 1e6:7.0f} GB/s", flush=True)
 
 
 def bench_gemmscale(ops):
@@ -382,7 +387,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "smallm": bench_smallm, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "flash160": lambda o: bench_flash(o, ((160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
