@@ -425,3 +425,6 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
 // gemm_pp.hip: the persistent 256 x (nb * 64) tile kernel (conv 0 | 1 | 2, epi EPI_*, nb 4 | 5); the caller (try_launch_persist,
 // gemm_conv.hip) has filled tiles_m / tiles_n (and ksplit / nk_item / ws for a split-K launch) and checked the shape
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_pp)(int conv, int epi, int nb, hipStream_t stream, const GemmParams& p, int cus);
+// gemm_ring.hip: the LDS-DMA ring kernel for small dense GEMMs (128 x (64 nb) tiles, nb = 2 | 4 | 5; EPI_LINEAR); the caller has checked the
+// shape and filled tiles_m / tiles_n
+__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_gemm_ring)(int nb, hipStream_t stream, const GemmParams& p, int cus);

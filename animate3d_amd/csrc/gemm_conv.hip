@@ -359,6 +359,9 @@ constexpr int PERSIST_MIN_FILL = 50;     // minimum average CU fill (per cent) o
 // a workspace, EPI_LINEAR, 16-bit output) must beat S = 1 by 15 % and leave >= 9 K-tiles per item, conv items hold whole 64-channel slices.
 struct PPPlan { int nb, S, cus; int64_t tiles_m, tiles_n; };
 constexpr int SPLITK_MAX = 16;
+#ifndef A3D_EXP_SPLITK_MINK
+#define A3D_EXP_SPLITK_MINK 9          // fewest K-tiles a split-K work item may hold (measurement builds override it)
+#endif
 template <int CONV, int EPI>
 bool plan_persist(const GemmParams& p, int flags, bool allow_split, PPPlan& out) {
   if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || p.out_f32) return false;
@@ -393,7 +396,7 @@ bool plan_persist(const GemmParams& p, int flags, bool allow_split, PPPlan& out)
     if (p.N % (nb * 64) != 0) continue;
     const int64_t tiles = tm * (p.N / (nb * 64));
     for (int S = 1; S <= (allow_split && EPI == EPI_LINEAR ? SPLITK_MAX : 1); ++S) {
-      if ((nk / unit) % S != 0 || (S > 1 && nk / S < 9)) continue;
+      if ((nk / unit) % S != 0 || (S > 1 && nk / S < A3D_EXP_SPLITK_MINK)) continue;
       const int64_t items = tiles * S;
       const int64_t rounds = (items + cus_plan - 1) / cus_plan;
       if (items * 100 < rounds * cus_plan * PERSIST_MIN_FILL) continue;             // average fill of the rounds (per cent)
@@ -410,6 +413,36 @@ bool plan_persist(const GemmParams& p, int flags, bool allow_split, PPPlan& out)
   out.nb = bnb; out.S = bS; out.cus = cus;
   out.tiles_m = tm; out.tiles_n = p.N / (bnb * 64);
   return true;
+}
+
+// Tile width of a ring-kernel launch (gemm_ring.hip).  A lone workgroup per CU is bound by the CU's LDS-DMA fill rate, so a launch costs
+// rounds x (128 + BN) per K-tile: the widest tile that keeps the number of rounds lowest wins.  The choice may depend on anything (CU
+// reservation included): every width walks K in the same order, results are bit-identical.
+struct RingPlan { int nb, cus, cus_plan; int64_t cost; };
+#ifndef A3D_RING_VS_PP_PCT
+#define A3D_RING_VS_PP_PCT 75           // a persistent-kernel tile costs ~0.75 x (256 + BN) of the ring kernel's units per K-tile and round (measured: at equal
+                                        // CU fill the two tie at M = 8192, N = 1280 although the ring tile is 128 rows; profiles/r6_microbench_smallm_ring.log)
+#endif
+constexpr int RING_VS_PP_PCT = A3D_RING_VS_PP_PCT;
+inline bool plan_ring(const GemmParams& p, int flags, RingPlan& out) {
+  if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || p.out_f32 || !p.vec16 || p.X2 != nullptr) return false;
+  if (p.M % 128 != 0 || p.K % 64 != 0 || p.K < 256 || p.ldx % 64 != 0 || p.ldw % 64 != 0) return false;
+  if ((uint64_t)p.ldx * 16u >= (1ull << 31) || (uint64_t)p.ldw * 16u >= (1ull << 31)) return false;
+  if (p.rowbias && p.rb_div % 128 != 0) return false;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, a3d_current_device()) != hipSuccess || n <= 0) n = 256;
+  const int reserved = a3d_gemm_reserved_cus_of(flags);
+  out.cus_plan = n;
+  out.cus = n - reserved > 32 ? n - reserved : 32;
+  out.nb = 0; out.cost = 0;
+  for (int nb : {5, 4, 2}) {
+    if (p.N % (64 * nb) != 0) continue;
+    const int64_t tiles = (p.M / 128) * (p.N / (64 * nb));
+    const int64_t rounds = (tiles + out.cus - 1) / out.cus;
+    const int64_t cost = rounds * (128 + 64 * nb);
+    if (out.nb == 0 || cost < out.cost) { out.nb = nb; out.cost = cost; }
+  }
+  return out.nb != 0;
 }
 
 template <int CONV, int EPI>
@@ -445,6 +478,23 @@ template <int CONV, int EPI = EPI_LINEAR>
 int launch(hipStream_t stream, GemmParams& p, int flags) {
   if (flags & ~(A3D_GEMM_RESERVED_CUS_MASK | A3D_GEMM_KERNEL_MASK)) return A3D_EINVAL;
   if (a3d_gemm_kernel_of(flags) > A3D_GEMM_TILE128) return A3D_EINVAL;
+  if constexpr (CONV == 0 && EPI == EPI_LINEAR) {
+    // small token matrices: the LDS-DMA ring kernel (gemm_ring.hip) when the persistent grid would be under-filled or lose to it
+    RingPlan rp;
+    if (plan_ring(p, flags, rp)) {
+      PPPlan pl;
+      bool ring = true;
+      if (plan_persist<CONV, EPI>(p, flags, p.ws != nullptr, pl)) {
+        const int64_t tiles = pl.tiles_m * pl.tiles_n * pl.S;
+        const int64_t pp_cost = ((tiles + rp.cus_plan - 1) / rp.cus_plan) * (256 + 64 * pl.nb) * RING_VS_PP_PCT;
+        ring = pl.S == 1 && rp.cost * 100 < pp_cost;
+      }
+      if (ring) {
+        p.tiles_m = p.M / 128; p.tiles_n = p.N / (64 * rp.nb);
+        return A3D_FN(a3d_launch_gemm_ring)(rp.nb, stream, p, rp.cus);
+      }
+    }
+  }
   {
     const int rc = try_launch_persist<CONV, EPI>(stream, p, flags);
     if (rc != -1000) return rc;

@@ -155,6 +155,52 @@ def test_gemm_persistent_path(ops, ref, M, N, K):
     assert (out[:, :N] == 0).all()
 
 
+# Round 6: small token matrices (M % 128 == 0, N % 128 == 0, K >= 256, too few 256-row tiles to fill the persistent kernel's grid) take the
+# LDS-DMA ring kernel (csrc/gemm_ring.hip; 128 x 128 / 128 x 256 / 128 x 320 tiles chosen by plan_ring): same K order and epilogue arithmetic
+# => bit-equal to the 128 x 128 kernel.  Shapes: 128 x 128 tiles, one per workgroup (80 - 160 tiles); 128 x 256 (M = 4096, N = 1280; 2048 x 3840;
+# 1152 x 2560: a row count that is a multiple of 128 but not of 256); 128 x 320 (5120 x 960: 120 tiles; 38528 x 960: 903 tiles, three or four per
+# workgroup — the K-tile stream and the bias parity run across tiles); more 128 x 128 tiles than CUs (40960 x 128); the shortest K, a long K
+# (80 K-tiles through a ring of four), N = 128 (one column of tiles); 8192 x 1280 / 16384 x 640 are a toss-up between the persistent and the
+# ring kernel (plan_ring's cost model currently keeps them on the persistent one).
+@pytest.mark.parametrize("M,N,K", [(1024, 1280, 1280), (2048, 1280, 2560), (4096, 1280, 1280), (5120, 960, 320), (1024, 1280, 5120), (2048, 3840, 1280),
+                                   (128, 128, 256), (384, 640, 256), (16384, 128, 640), (1152, 2560, 704), (8192, 1280, 640), (16384, 640, 320),
+                                   (40960, 128, 256), (2048, 1280, 256), (38528, 960, 256)])
+def test_gemm_ring_path(ops, ref, M, N, K):
+    x, w = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5)
+    bias = rnd(N, seed=23, dtype=torch.float32)
+    res = rnd(M, N, seed=24)
+    rb = rnd(M // 128, N, seed=25)
+    for name, kw in (("plain", {}), ("nobias", dict(nobias=True)), ("residual", dict(residual=res, alpha=0.37, beta=1.0)), ("residual beta", dict(residual=res, alpha=0.63, beta=0.9)),
+                     ("rowbias+res", dict(rowbias=rb, rb_div=128, residual=res)), ("rowbias", dict(rowbias=rb, rb_div=128))):
+        kw = dict(kw)
+        b = None if kw.pop("nobias", False) else bias
+        got, classic, pinned = _both_paths(ops, lambda t128: ops.gemm(x, w, b, tile128=t128, **kw))
+        check(f"gemm ring {name} {M}x{N}x{K}", got, ref.gemm(x, w, b, **kw))
+        assert torch.equal(got, classic), f"ring vs 128x128 kernel differ ({name})"
+        assert torch.equal(got, pinned), f"ring kernel with reserved CUs differs ({name})"
+    big = rnd(M, 3 * K, seed=26)
+    xs = big[:, K:2 * K]                                       # strided A: a column block of a fused projection output (row stride 3 K)
+    out = torch.zeros(M, 2 * N, device="cuda", dtype=BF)
+    ops.gemm(xs, w, bias, out=out[:, N:])
+    assert torch.equal(out[:, N:], ops.gemm(xs.contiguous(), w, bias, tile128=True))
+    assert (out[:, :N] == 0).all()
+    wrows = rnd(2 * N, K, seed=27, scale=K ** -0.5)            # a row slice of a fused weight (animate3d_amd.unet._rows)
+    assert torch.equal(ops.gemm(x, wrows[N:], bias), ops.gemm(x, wrows[N:].contiguous(), bias, tile128=True))
+
+
+def test_gemm_ring_path_repeatable_under_memory_traffic(ops):
+    """As for the persistent kernel: counted vmcnt waits behind LDS-DMA loads; every launch must reproduce the 128 x 128 kernel bit for bit."""
+    junk = torch.empty(32 << 20, device="cuda", dtype=torch.uint8)
+    for (M, N, K) in [(1024, 1280, 1280), (4096, 1280, 2560), (2048, 640, 320), (8192, 640, 640)]:
+        x, w = rnd(M, K, seed=45), rnd(N, K, seed=46, scale=K ** -0.5)
+        bias, res = rnd(N, seed=47, dtype=torch.float32), rnd(M, N, seed=48)
+        want = ops.gemm(x, w, bias, residual=res, alpha=0.7, tile128=True)
+        for it in range(60):
+            if it % 3 == 0:
+                junk.add_(1)
+            assert torch.equal(ops.gemm(x, w, bias, residual=res, alpha=0.7), want), (M, N, K, it)
+
+
 def test_gemm_persistent_path_repeatable_under_memory_traffic(ops):
     """The persistent kernel keeps LDS-DMA loads and epilogue stores in flight behind hand-counted vmcnt waits; a miscount would
     show up as rare wrong tiles.  Hammer it next to unrelated HBM traffic: every launch must reproduce the 128x128 kernel bit for

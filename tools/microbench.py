@@ -34,6 +34,30 @@ def timeit(fn, reps=5, warm=1):
     return statistics.median(ts), min(ts)
 
 
+def graph_time(fn, n=20, reps=7):
+    """GPU time per call without host gaps: n consecutive calls captured in a HIP graph, replayed; median over reps (us)."""
+    fn(); fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / n)
+    return statistics.median(ts)
+
+
 ATTN_MODES = (("default", {}), ("exact", dict(exact=True)), ("plain", dict(plain=True)))
 
 
@@ -171,7 +195,8 @@ def bench_smallm(ops):
         for name, kw, sk in (("default", {}, False), ("tile128", dict(tile128=True), False), ("split-K", {}, True)):
             ops.split_k_gemm = sk
             med, mn = timeit(lambda: ops.gemm(x, w, bias, residual=res, **kw), reps=15, warm=3)
-            out.append(f"{name} {med * 1e3:7.1f} us {fl / med / 1e9:6.1f} TF/s")
+            gt = graph_time(lambda: ops.gemm(x, w, bias, residual=res, **kw))
+            out.append(f"{name} {med * 1e3:6.1f} us eager, {gt:6.1f} us in a graph = {fl / gt / 1e6:6.1f} TF/s")
         ops.split_k_gemm = False
         print(f"M={M:6d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + "  |  ".join(out), flush=True)
     bench_gn(ops)
@@ -198,7 +223,8 @@ def bench_gn(ops):
         x = rnd(B * rows, C)
         gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
         med, mn = timeit(lambda: ops.group_norm(x, B, rows, gam, bet, 32, 1e-5, True), reps=15, warm=3)
-        print(f"group_norm B={B:3d} rows={rows:5d} C={C:4d}: {med * 1e3:7.1f} us  {2.0 * x.numel() * 2 / med / 1e6:7.0f} GB/s", flush=True)
+        gt = graph_time(lambda: ops.group_norm(x, B, rows, gam, bet, 32, 1e-5, True))
+        print(f"group_norm B={B:3d} rows={rows:5d} C={C:4d}: {med * 1e3:7.1f} us eager, {gt:7.1f} us in a graph = {2.0 * x.numel() * 2 / gt / 1e3:7.0f} GB/s", flush=True)
 
 
 def bench_gemmscale(ops):
