@@ -27,6 +27,7 @@ struct GemmParams {
   // two-source A operand of the dense persistent kernel (a3d_gemm2: the 1x1 shortcut convolution of an up-block ResNet reads [hidden | skip]
   // without a torch.cat): columns [0, K1) of the contraction come from X (row stride ldx), [K1, K) from X2 (row stride ldx2).  X2 == nullptr: off.
   const uint16_t* X2; int64_t ldx2; int64_t K1;
+  int direct;           // persistent dense kernel: the direct epilogue (A3D_GEMM_DIRECT; gemm_common.h: direct_epilogue)
 };
 
 constexpr int EPI_LINEAR = 0, EPI_GEGLU = 1;
@@ -419,6 +420,72 @@ A3D_DEV void persist_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], float
       }
     }
     wave_lds_fence();
+  }
+}
+
+// ---- Direct epilogue (round 6): no LDS transposition.  The kernel stages W so that MFMA row i = 8 b + 4 g + c of a
+//      32-row block is output column 16 g + 4 b + c of that block (a permutation of the DMA SOURCE rows, gemm_pp.hip: issue_pieces): register
+//      r of a lane is then column 16 g + r of ONE output row (l31) — 16 consecutive columns, two 16-byte stores per lane and 32 x 32 tile; bias
+//      (fp32, broadcast LDS reads), rowbias and the residual are read in the same layout.  Arithmetic per element exactly as in
+//      persist_epilogue (((acc + bias) + rowbias) * alpha, then + beta * r, one rounding): bit-identical outputs.
+template <int NB, bool RES>
+A3D_DEV void direct_epilogue(const GemmParams& p, f32x16_t (&acc)[NB][2], const float* const bias_lds, const uint16_t* const rowbias_lds,
+                             const int64_t m0, const int64_t n0, const int wm, const int wblk, const int wblk_last, const int lane) {
+  const int l31 = lane & 31, g = lane >> 5;
+  const bool with = p.bias || p.rowbias;            // launch-uniform: the bias-free Q|K|V projections skip the operand reads
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int64_t m = m0 + wm * 64 + tm * 32 + l31;
+    uint16_t* const yrow = p.Y + m * p.ldy + n0;
+    u32x4_t rr[RES ? NB : 1][2];
+    if constexpr (RES) {
+      const uint16_t* const rrow = p.R + m * p.ldr + n0;
+#pragma unroll
+      for (int tn = 0; tn < NB; ++tn) {
+        const int col = (tn < NB - 1 ? wblk + tn : wblk_last) * 32 + 16 * g;
+        rr[tn][0] = *reinterpret_cast<const u32x4_t*>(rrow + col);
+        rr[tn][1] = *reinterpret_cast<const u32x4_t*>(rrow + col + 8);
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < NB; ++tn) {
+      const int col = (tn < NB - 1 ? wblk + tn : wblk_last) * 32 + 16 * g;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[tn][tm][r];
+      if (with) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32x4_t b = lds_vload128(bias_lds + col + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] += __uint_as_float(b[e]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4_t tb = lds_vload128(rowbias_lds + col + 8 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[8 * h + 2 * e] += lo16(tb[e]); v[8 * h + 2 * e + 1] += hi16(tb[e]); }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = epi_scale(v[r], p.alpha);
+      if constexpr (RES) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[8 * h + 2 * e] = epi_axpy(v[8 * h + 2 * e], p.beta, lo16(rr[tn][h][e]));
+            v[8 * h + 2 * e + 1] = epi_axpy(v[8 * h + 2 * e + 1], p.beta, hi16(rr[tn][h][e]));
+          }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack16(v[8 * h + 2 * e], v[8 * h + 2 * e + 1]);
+        *reinterpret_cast<u32x4_t*>(yrow + col + 8 * h) = o;
+      }
+    }
   }
 }
 

@@ -425,7 +425,7 @@ struct RingPlan { int nb, cus, cus_plan; int64_t cost; };
 #endif
 constexpr int RING_VS_PP_PCT = A3D_RING_VS_PP_PCT;
 inline bool plan_ring(const GemmParams& p, int flags, RingPlan& out) {
-  if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || p.out_f32 || !p.vec16 || p.X2 != nullptr) return false;
+  if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || a3d_gemm_kernel_of(flags) == A3D_GEMM_DIRECT || p.out_f32 || !p.vec16 || p.X2 != nullptr) return false;
   if (p.M % 128 != 0 || p.K % 64 != 0 || p.K < 256 || p.ldx % 64 != 0 || p.ldw % 64 != 0) return false;
   if ((uint64_t)p.ldx * 16u >= (1ull << 31) || (uint64_t)p.ldw * 16u >= (1ull << 31)) return false;
   if (p.rowbias && p.rb_div % 128 != 0) return false;
@@ -451,6 +451,7 @@ int try_launch_persist(hipStream_t stream, GemmParams& p, int flags) {
   if (!plan_persist<CONV, EPI>(p, flags, p.ws != nullptr, pl)) return -1000;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
   p.ksplit = pl.S; p.nk_item = (int)(p.K / 64) / pl.S;
+  p.direct = (CONV == 0 && EPI == EPI_LINEAR && pl.S == 1 && p.X2 == nullptr && a3d_gemm_kernel_of(flags) == A3D_GEMM_DIRECT) ? 1 : 0;
   return A3D_FN(a3d_launch_gemm_pp)(CONV, EPI, pl.nb, stream, p, pl.cus);
 }
 
@@ -477,14 +478,14 @@ int launch_bk(hipStream_t stream, GemmParams& p, int64_t nblk) {
 template <int CONV, int EPI = EPI_LINEAR>
 int launch(hipStream_t stream, GemmParams& p, int flags) {
   if (flags & ~(A3D_GEMM_RESERVED_CUS_MASK | A3D_GEMM_KERNEL_MASK)) return A3D_EINVAL;
-  if (a3d_gemm_kernel_of(flags) > A3D_GEMM_TILE128) return A3D_EINVAL;
+  if (a3d_gemm_kernel_of(flags) > A3D_GEMM_DIRECT) return A3D_EINVAL;
   if constexpr (CONV == 0 && EPI == EPI_LINEAR) {
     // small token matrices: the LDS-DMA ring kernel (gemm_ring.hip) when the persistent grid would be under-filled or lose to it
     RingPlan rp;
     if (plan_ring(p, flags, rp)) {
       PPPlan pl;
       bool ring = true;
-      if (plan_persist<CONV, EPI>(p, flags, p.ws != nullptr, pl)) {
+      if (a3d_gemm_kernel_of(flags) != A3D_GEMM_RING && plan_persist<CONV, EPI>(p, flags, p.ws != nullptr, pl)) {
         const int64_t tiles = pl.tiles_m * pl.tiles_n * pl.S;
         const int64_t pp_cost = ((tiles + rp.cus_plan - 1) / rp.cus_plan) * (256 + 64 * pl.nb) * RING_VS_PP_PCT;
         ring = pl.S == 1 && rp.cost * 100 < pp_cost;

@@ -75,9 +75,12 @@ A3D_DEV void pp_barrier() {
 // SPLIT: split-K work items (GemmParams::ksplit > 1) — a separate instantiation: the item bookkeeping and the fp32 partial stores cost the
 // unsplit kernels registers they do not have (the conv instantiations sit at 256)
 // TWO: two-source A operand (GemmParams::X2; dense only) — its own instantiation for the same reason
-template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false, bool TWO = false>
+// DIRECT: W rows staged in the permuted order of direct_epilogue (gemm_common.h) and that epilogue instead of the LDS transposition (dense linear
+// epilogues only; A3D_GEMM_DIRECT in the call's flags word)
+template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false, bool TWO = false, bool DIRECT = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   static_assert(!TWO || CONV == 0, "the two-source A operand is a dense-GEMM feature");
+  static_assert(!DIRECT || (CONV == 0 && EPI == EPI_LINEAR && !SPLIT && !TWO), "the direct epilogue is a dense linear-epilogue feature");
   using PC = PPCfg<NB>;
   constexpr int PH = 1, NPH = 4;              // k-steps per phase, phases per K-tile
   constexpr int NP = 4 + NB;                  // DMA pieces per wave and K-tile: X 0..3, W 0..NB-1
@@ -107,7 +110,18 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
   const uint32_t wrd_last = (uint32_t)PC::XBYTES + (uint32_t)(wblk_last * 32 + l31) * 128u;
 
   const uint32_t vx0 = (uint32_t)(lr * p.ldx * 2 + ((pos ^ (lr >> 1)) << 4));
-  const uint32_t vw0 = (uint32_t)(lr * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4));
+  // DIRECT: LDS row 8 pc + lr of the W image (MFMA row 8 b + 4 g + c of its 32-block: b = pc & 3, lr = 4 g + c) holds W row
+  // 32 (pc >> 2) + 16 g + 4 b + c: the lane part of the source offset is (16 (lr >> 2) + (lr & 3)) rows, the piece part wro[i]
+  const uint32_t vw0 = DIRECT ? (uint32_t)((16 * (lr >> 2) + (lr & 3)) * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4))
+                              : (uint32_t)(lr * p.ldw * 2 + ((pos ^ (lr >> 1)) << 4));
+  uint32_t wro[DIRECT ? NB : 1];
+  if constexpr (DIRECT) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int pc = wid * NB + i;
+      wro[i] = (uint32_t)((32 * (pc >> 2) + 4 * (pc & 3)) * p.ldw * 2);
+    }
+  }
   uint32_t aoff[CONV ? 4 : 1];
   uint32_t amask[CONV ? 2 : 1];
   // scalar copies of the tap masks: bit set <=> ALL 8 pixels of the piece are inside the image for that tap.  Such a (piece, tap) — 90 % of them
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
     if constexpr (CONV != 0) xck = (uint64_t)(uintptr_t)p.X - (uint64_t)cbias * 2u + (uint64_t)kofs * 2u;
     if constexpr (CONV == 0) xk = (uint64_t)(uintptr_t)(p.X + (ld_m0 + wid * 32) * p.ldx + kofs);
     if constexpr (TWO) xk2 = (uint64_t)(uintptr_t)(p.X2 + (ld_m0 + wid * 32) * p.ldx2);
-    wk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + wid * (NB * 8)) * p.ldw + kofs);
+    wk = (uint64_t)(uintptr_t)(p.W + (ld_n0 + (DIRECT ? 0 : wid * (NB * 8))) * p.ldw + kofs);
     if (EPI == EPI_LINEAR && p.rowbias) rbk = (uint64_t)(uintptr_t)(p.rowbias + (ld_m0 / p.rb_div) * p.N + ld_n0);
     if constexpr (CONV != 0) {
       amask[0] = 0; amask[1] = 0;
@@ -248,7 +262,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
     for (int i = 0; i < NB; ++i) {
       if (4 + i < A || 4 + i >= B) continue;
       const int pc = wid * NB + i;
-      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), (const void*)(uintptr_t)(wk + (uint64_t)(uint32_t)(i * sw8)), dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
+      const uint32_t wpo = DIRECT ? wro[DIRECT ? i : 0] : (uint32_t)(i * sw8);
+      glds16_s(vw0 ^ (uint32_t)((pc & 1) << 6), (const void*)(uintptr_t)(wk + (uint64_t)wpo), dst + (uint32_t)PC::XBYTES + (uint32_t)pc * 1024u);
     }
     if constexpr (B == NP) {
       if constexpr (CONV != 0) {
@@ -388,6 +403,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const GemmParams p) {
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(wsi + ((tn * 2 + tm) * 4 + q) * 256) =
                 float4{acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+    } else if constexpr (DIRECT) {
+      direct_epilogue<NB, RES>(p, acc, reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE),
+                               reinterpret_cast<const uint16_t*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE + 1280),
+                               m0, n0, wm, wblk, wblk_last, lane);
     } else {
       persist_epilogue<EPI, NB, RES>(p, acc, reinterpret_cast<float*>(smem_b + (buf ^ 1) * PC::STAGE) + wid * (32 * 68),
                                      reinterpret_cast<const float*>(smem_b + PC::BIAS_OFF + cur_par * PC::BIAS_STRIDE),
@@ -455,16 +474,16 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const GemmParams p) 
     }
 }
 
-template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false, bool TWO = false>
+template <int CONV, int EPI, int NB, bool RES, bool SPLIT = false, bool TWO = false, bool DIRECT = false>
 int launch_pp(hipStream_t stream, const GemmParams& p, int cus) {
   using PC = PPCfg<NB>;
   static uint64_t attr_done = 0;
   if (int rc = a3d_once_per_device(attr_done, [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT, TWO>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT, TWO, DIRECT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, PC::SMEM); })) return rc;
   const int64_t ntiles = p.tiles_m * p.tiles_n * (SPLIT ? p.ksplit : 1);
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT, TWO><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
+  gemm_pp_kernel<CONV, EPI, NB, RES, SPLIT, TWO, DIRECT><<<dim3(grid), dim3(512), PC::SMEM, stream>>>(p);
   if (int rc = a3d_launch_status()) return rc;
   if constexpr (SPLIT) {
     splitk_reduce_kernel<NB><<<dim3((unsigned)(p.tiles_m * p.tiles_n), NB), dim3(512), 0, stream>>>(p);
@@ -491,6 +510,13 @@ int launch_pp_conv(int epi, int nb, hipStream_t stream, const GemmParams& p, int
     if (nb == 5) return launch_pp<CONV, EPI_LINEAR, 5, false, true>(stream, p, cus);
     if (nb == 4) return launch_pp<CONV, EPI_LINEAR, 4, false, true>(stream, p, cus);
     return A3D_EUNSUPPORTED;
+  }
+  if constexpr (CONV == 0) {
+    if (p.direct) {            // direct epilogue (A3D_GEMM_DIRECT)
+      if (nb == 5) return p.R ? launch_pp<0, EPI_LINEAR, 5, true, false, false, true>(stream, p, cus) : launch_pp<0, EPI_LINEAR, 5, false, false, false, true>(stream, p, cus);
+      if (nb == 4) return p.R ? launch_pp<0, EPI_LINEAR, 4, true, false, false, true>(stream, p, cus) : launch_pp<0, EPI_LINEAR, 4, false, false, false, true>(stream, p, cus);
+      return A3D_EUNSUPPORTED;
+    }
   }
   if (nb == 5) return p.R ? launch_pp<CONV, EPI_LINEAR, 5, true>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 5, false>(stream, p, cus);
   if (nb == 4) return p.R ? launch_pp<CONV, EPI_LINEAR, 4, true>(stream, p, cus) : launch_pp<CONV, EPI_LINEAR, 4, false>(stream, p, cus);

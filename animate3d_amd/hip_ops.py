@@ -232,11 +232,11 @@ class HipOps:
             self._ws_buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
         return self._ws_buf
 
-    def _gemm_flags(self, tile128: bool) -> int:
+    def _gemm_flags(self, tile128: bool, ring: bool = False, direct: bool = False) -> int:
         r = int(self.reserved_cus)
         if not 0 <= r <= 0xFF:
             raise ValueError(f"reserved_cus = {self.reserved_cus}: the flags word of a3d_gemm / a3d_conv3x3 carries 0..255 reserved compute units")
-        return r | (0x100 if tile128 else 0)
+        return r | (0x100 if tile128 else (0x200 if ring else (0x300 if direct else 0)))
 
     # ---- helpers
     def _stream(self):
@@ -257,8 +257,10 @@ class HipOps:
 
     # ---- GEMM family
     def gemm(self, x, w, bias=None, *, residual=None, alpha: float = 1.0, beta: float = 1.0, rowbias=None, rb_div: int = 1, out=None,
-             tile128: bool = False):
-        """``tile128`` forces the 128 x 128-tile kernel (A3D_GEMM_TILE128: bit-identical results; parity tests and A/B timing)."""
+             tile128: bool = False, ring: bool = False, direct: bool = False):
+        """``tile128`` forces the register-staged 128 x 128-tile kernel (A3D_GEMM_TILE128), ``ring`` the LDS-DMA ring kernel where the shape
+        allows it (A3D_GEMM_RING), ``direct`` the persistent kernel's LDS-free epilogue (A3D_GEMM_DIRECT): bit-identical results; parity tests
+        and A/B timing."""
         x, w = self._act(x, "gemm.x"), self._act(w, "gemm.w")
         M, K = x.shape
         N = w.shape[0]
@@ -273,7 +275,7 @@ class HipOps:
             assert rowbias.is_contiguous() and rowbias.shape[1] == N
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.numel() == N
-        flags = self._gemm_flags(tile128)
+        flags = self._gemm_flags(tile128, ring, direct)
         args = (self._stream(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(rowbias), rb_div,
                 _p(residual), residual.stride(0) if residual is not None else 0, _p(y), y.stride(0), M, N, K, alpha, beta, flags)
         if self.split_k and self.split_k_gemm and not tile128 and M <= 32768 and K >= 1152:

@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  It carries
                  launch stream inside the timed region, against the dense bf16 MFMA peak; ``ceilings`` adds the second
                  ceiling that binds at head_dim 40 — the v_exp issue rate measured with tools/ubench_exp.hip — and ``traffic``
                  the HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (read from
-                 profiles/r4_flash_pmc_traffic.json, else round 3's; null when that file does not describe this kernel and launch shape);
+                 profiles/r6_flash_pmc_traffic.json (a pass over the final tree of round 6), else older rounds'; null when no file describes this kernel and launch shape);
   groups       — per kernel family (attention by head dim, GEMM, fused GEGLU GEMM, 3x3 conv, norms, ...): ms per step and
                  achieved TFLOP/s or GB/s, from one extra instrumented forward OUTSIDE the timed region;
   cpu_baseline — the CPU oracle (plain-PyTorch fp32 restatement of the reference forward; the reference itself cannot be
@@ -322,7 +322,7 @@ def box_calibration(ops, dev):
 
 def _pmc_traffic(S0, groups, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass, if it matches this kernel and launch shape."""
-    for name in ("r4_flash_pmc_traffic.json", "r3_flash_pmc_traffic.json"):      # newest pass first; the kernel is unchanged since round 3
+    for name in ("r6_flash_pmc_traffic.json", "r4_flash_pmc_traffic.json", "r3_flash_pmc_traffic.json"):      # newest pass first (round 6: re-run on the final tree)
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
             if rec.get("kernel") == kernel and rec.get("kv_len") == S0 and rec.get("groups") == groups:

@@ -66,12 +66,18 @@ typedef struct a3d_rowmap {
  * `flags` (also of a3d_gemm_geglu / a3d_conv3x3; 0 = defaults) is a per-call launch parameter — the library keeps no tuning state:
  *   bits 0-7   A3D_GEMM_RESERVED_CUS: compute units the persistent kernel's grid leaves free for concurrently running kernels
  *              (the sharded path passes the CUs an in-flight RCCL all-gather needs; at least 32 CUs are always used);
- *   bits 8-9   kernel choice: 0 = automatic (persistent 256-row-tile kernel for the big token matrices, 128 x 128 tiles otherwise),
- *              A3D_GEMM_TILE128 = always the 128 x 128-tile kernel (same K order and epilogue arithmetic: bit-identical results;
- *              A/B measurements and the parity tests).  Other bits must be zero (A3D_EINVAL). */
+ *   bits 8-9   kernel choice: 0 = automatic (persistent 256-row-tile kernel for the big token matrices; round 6: the LDS-DMA ring kernel
+ *              with 128-row tiles for the small ones — UNet levels 2 / 3 of a multi-GPU rank, the 4D-SDS shape —; 128 x 128 register-staged
+ *              tiles for ragged shapes), A3D_GEMM_TILE128 = always the register-staged 128 x 128 kernel, A3D_GEMM_RING = the ring kernel
+ *              whenever the shape allows it (a3d_gemm only; falls back to the automatic choice otherwise), A3D_GEMM_DIRECT = the persistent
+ *              kernel storing straight from the accumulator layout (a3d_gemm only).  All kernels walk K in the same
+ *              order with the same epilogue arithmetic: bit-identical results (A/B measurements and the parity tests).  Other bits must be
+ *              zero (A3D_EINVAL). */
 #define A3D_GEMM_RESERVED_CUS_MASK 0xff
 #define A3D_GEMM_KERNEL_MASK 0x300
 #define A3D_GEMM_TILE128 0x100
+#define A3D_GEMM_RING 0x200
+#define A3D_GEMM_DIRECT 0x300   /* the persistent kernel with its direct (LDS-free) epilogue where the shape allows it: measurement of round 6 */
 int a3d_gemm_bf16(a3d_stream_t stream, const void* X, int64_t ldx, const void* W, int64_t ldw,
                   const float* bias, const void* rowbias, int64_t rb_div, const void* R, int64_t ldr,
                   void* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags);

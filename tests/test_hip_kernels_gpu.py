@@ -147,6 +147,9 @@ def test_gemm_persistent_path(ops, ref, M, N, K):
         check(f"gemm persistent {name} {M}x{N}x{K}", got, ref.gemm(x, w, bias, **kw))
         assert torch.equal(got, classic), f"persistent vs 128x128 kernel differ ({name})"
         assert torch.equal(got, pinned), f"persistent kernel with reserved CUs differs ({name})"
+        # round 6: the direct (LDS-free) epilogue of the same kernel (A3D_GEMM_DIRECT): W rows staged in a permuted order, stores from the MFMA layout
+        assert torch.equal(got, ops.gemm(x, w, bias, direct=True, **kw)), f"direct epilogue differs ({name})"
+        assert torch.equal(ops.gemm(x, w, None, direct=True, **kw), ops.gemm(x, w, None, tile128=True, **kw)), f"direct epilogue differs without a bias ({name})"
     big = rnd(M, 3 * K, seed=16)
     xs = big[:, K:2 * K]
     out = torch.zeros(M, 2 * N, device="cuda", dtype=BF)

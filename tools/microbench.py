@@ -215,6 +215,46 @@ def bench_smallm(ops):
         print(f"conv3x3 B={B:3d} {H}x{W} {Cin}->{Cout}: " + "  |  ".join(out), flush=True)
 
 
+def bench_onewave(ops):
+    """VERDICT r5 item 4b, first half: the one-wave-per-SIMD GEMM (gemm_ring.hip with 128 x 320 tiles: 256 threads, one wave per SIMD, serial
+    epilogue) against the shipped two-waves-per-SIMD ping-pong kernel (256 x 320 tiles) on the epilogue-bound short-K shapes of level 0 / 1,
+    in-graph GPU time.  The ring kernel has no second accumulator set: if its main loop + serial epilogue is far behind here, hiding the
+    epilogue cannot win the 8 % the experiment was asked to show."""
+    print("== short-K linears at the level-0 / 1 shapes: persistent ping-pong kernel (default) | one wave per SIMD, 128 x 320 tiles (ring=True); in-graph us / TFLOP/s")
+    for (M, N, K, r) in [(524288, 960, 320, 0), (524288, 1280, 320, 0), (524288, 320, 320, 1), (524288, 320, 1280, 1), (131072, 1920, 640, 0),
+                         (131072, 640, 640, 1), (131072, 640, 2560, 1), (32768, 1280, 1280, 0), (32768, 1280, 5120, 1)]:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N) if r else None
+        fl = 2.0 * M * N * K
+        out = []
+        for name, kw in (("ping-pong 256x320", {}), ("one-wave 128x320", dict(ring=True))) * 2:
+            gt = graph_time(lambda: ops.gemm(x, w, bias, residual=res, **kw), n=10)
+            out.append(f"{name} {gt:7.1f} us {fl / gt / 1e6:7.1f} TF/s")
+        assert torch.equal(ops.gemm(x, w, bias, residual=res), ops.gemm(x, w, bias, residual=res, ring=True))
+        print(f"M={M:6d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + "  |  ".join(out), flush=True)
+
+
+def bench_directepi(ops):
+    """the persistent kernel with the direct epilogue (W rows permuted on the DMA source address so that a lane holds 16
+    consecutive columns of one output row: two 16-byte stores per lane and 32 x 32 tile, bias / rowbias / residual read in that layout, no LDS
+    transposition) against the shipped LDS-transposing epilogue.  In-graph GPU time, alternating; results must be bit-identical."""
+    print("== persistent GEMM: LDS-transposing epilogue (shipped) | direct epilogue (direct=True); in-graph us / TFLOP/s")
+    for (M, N, K, r, b) in [(524288, 1280, 320, 0, 1), (524288, 960, 320, 0, 0), (524288, 960, 320, 0, 1), (524288, 320, 320, 1, 1), (524288, 320, 640, 1, 1), (524288, 320, 1280, 1, 1),
+                            (131072, 1920, 640, 0, 0), (131072, 640, 640, 1, 1), (131072, 640, 2560, 1, 1), (131072, 2560, 640, 0, 1),
+                            (32768, 1280, 1280, 0, 1), (32768, 3840, 1280, 0, 0), (32768, 1280, 5120, 1, 1)]:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda") if b else None
+        res = rnd(M, N) if r else None
+        fl = 2.0 * M * N * K
+        out = []
+        for name, kw in (("transposing", {}), ("direct", dict(direct=True))) * 2:
+            gt = graph_time(lambda: ops.gemm(x, w, bias, residual=res, **kw), n=10)
+            out.append(f"{name} {gt:7.1f} us {fl / gt / 1e6:7.1f} TF/s")
+        same = torch.equal(ops.gemm(x, w, bias, residual=res), ops.gemm(x, w, bias, residual=res, direct=True))
+        print(f"M={M:6d} N={N:5d} K={K:5d}{' +res' if r else '     '}{' +bias' if b else '      '}: " + "  |  ".join(out) + f"  | bit-identical: {same}", flush=True)
+
+
 def bench_gn(ops):
     print("== GroupNorm (+SiLU) instances: B x rows x C; median us / GB/s (algorithmic: read + write)")
     for (B, rows, C) in [(16, 256, 1280), (16, 64, 1280), (1, 1024, 1280), (1, 4096, 1280), (16, 1024, 640), (16, 4096, 320), (32, 256, 1280), (32, 64, 1280),
@@ -413,7 +453,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "flash160": lambda o: bench_flash(o, ((160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),

@@ -1,4 +1,4 @@
-"""rocprofv3 counter CSVs (two passes: FETCH_SIZE, WRITE_SIZE) of tools/pmc_workload.py -> profiles/r2_flash_pmc_traffic.json + .md.
+"""rocprofv3 counter CSVs (two passes: FETCH_SIZE, WRITE_SIZE) of tools/pmc_workload.py -> profiles/r<N>_flash_pmc_traffic.json + .md.
 Unit and gfx950 correction come from the calibration kernel in the same trace (MI355X_MICROARCH.md, HBM section): the elementwise
 multiply reads and writes 2 013 265 920 bytes each; whatever factor maps its counter values to those bytes is applied to the kernel."""
 import csv
