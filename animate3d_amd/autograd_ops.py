@@ -71,10 +71,29 @@ _PLACEHOLDERS = {}
 
 
 class _Deferred:
-    """Weight gradients parked by ``PackW.backward`` while ``deferred_param_grads()`` is active."""
+    """Weight gradients parked by ``PackW.backward`` while ``deferred_param_grads()`` is active.  Parked slices keep their fused fp32
+    gradient buffers alive (AccumulateGrad would have consumed and freed each as it arrived), so the list is flushed — one multi-tensor add —
+    whenever more than ``FLUSH_BYTES`` are parked: the extra peak memory is bounded by that, not by one fp32 copy of every trainable gradient."""
     active = False
     dst: list = []
     src: list = []
+    parked_bytes = 0
+    FLUSH_BYTES = 256 << 20
+
+    @classmethod
+    def park(cls, dst, src):
+        cls.dst.append(dst)
+        cls.src.append(src)
+        cls.parked_bytes += src.numel() * src.element_size()
+        if cls.parked_bytes > cls.FLUSH_BYTES:
+            cls.flush()
+
+    @classmethod
+    def flush(cls):
+        dst, src, cls.dst, cls.src, cls.parked_bytes = cls.dst, cls.src, [], [], 0
+        if dst:
+            with torch.no_grad():
+                torch._foreach_add_(dst, src)
 
 
 @contextlib.contextmanager
@@ -88,14 +107,11 @@ def deferred_param_grads():
     try:
         yield
     except BaseException:
-        st.dst, st.src = [], []
+        st.dst, st.src, st.parked_bytes = [], [], 0
         raise
     finally:
         st.active = prev
-    dst, src, st.dst, st.src = st.dst, st.src, [], []
-    if dst:
-        with torch.no_grad():
-            torch._foreach_add_(dst, src)
+    st.flush()
 
 
 def _placeholder(w: torch.Tensor) -> torch.Tensor:
@@ -116,7 +132,7 @@ class PackW(torch.autograd.Function):
     def forward(ctx, dtype, interleave, sink, *masters):
         ctx.interleave, ctx.sink = interleave, sink
         ctx.rows = [m.shape[0] for m in masters]
-        ctx.masters = masters
+        ctx.save_for_backward(*masters)          # (not pinned on ctx: the graph frees them with its other saved tensors)
         if len(masters) == 1:
             w = masters[0].to(dtype)
         else:                        # cast while concatenating: no fp32 copy of the fused operand in between
@@ -147,10 +163,9 @@ class PackW(torch.autograd.Function):
         for i, n in enumerate(ctx.rows):
             gi = g[r:r + n] if ctx.needs_input_grad[3 + i] else None
             if gi is not None and _Deferred.active:
-                m = ctx.masters[i]
+                m = ctx.saved_tensors[i]
                 if m.is_leaf and m.grad is not None and m.grad.dtype == gi.dtype and m.grad.shape == gi.shape:
-                    _Deferred.dst.append(m.grad)          # deferred_param_grads(): added after the pass, all weights in one launch
-                    _Deferred.src.append(gi)
+                    _Deferred.park(m.grad, gi)            # deferred_param_grads(): added in multi-tensor launches, not one per weight
                     gi = None
             outs.append(gi)
             r += n
@@ -179,8 +194,7 @@ def _param_grad(p, g):
     itself (its ``.grad`` then takes it in the multi-tensor add after the pass), handed to autograd otherwise."""
     if (g is not None and _Deferred.active and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
             and p.grad.dtype == g.dtype and p.grad.shape == g.shape):
-        _Deferred.dst.append(p.grad)
-        _Deferred.src.append(g)
+        _Deferred.park(p.grad, g)
         return None
     return g
 
@@ -196,11 +210,37 @@ def _weight_grad(ctx_sink, w, dw32: torch.Tensor) -> torch.Tensor:
     return dw32.to(w.dtype)
 
 
+class _WeightRows(torch.autograd.Function):
+    """``w[r0:r1]`` whose backward keeps the sink consumers' stride-0 zero placeholder memory-free: autograd's own slice backward would
+    materialise it as a dense full-size zero tensor, which ``PackW.backward`` then takes for a real gradient (a full-width fp32 add per pass:
+    w_kvq and qkv_img in the frame-sharded and first-frame paths)."""
+
+    @staticmethod
+    def forward(ctx, w, r0, r1):
+        ctx.shape, ctx.r0, ctx.r1 = tuple(w.shape), r0, r1
+        ctx.set_materialize_grads(False)
+        return w[r0:r1]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        if g.dim() > 0 and all(s_ == 0 for s_ in g.stride()):      # the placeholder of _weight_grad: pass one of the parent's shape on
+            key = (g.dtype, g.device)
+            z = _PLACEHOLDERS.get(key)
+            if z is None:
+                z = _PLACEHOLDERS[key] = torch.zeros((), dtype=g.dtype, device=g.device)
+            return z.expand(ctx.shape), None, None
+        full = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)      # a consumer that went around the sink: a real gradient
+        full[ctx.r0:ctx.r1] = g
+        return full, None, None
+
+
 def weight_rows(w: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
     """``w[r0:r1]`` of a packed kernel weight that keeps the fp32 gradient path: the slice carries a sink that deposits into rows
     [r0, r1) of the parent's (plain slicing drops ``_a3d_sink``, and the consumer's weight gradient would travel and be summed in 16 bits)."""
-    v = w[r0:r1]
     sink = getattr(w, "_a3d_sink", None)
+    v = _WeightRows.apply(w, r0, r1) if (sink is not None and w.requires_grad) else w[r0:r1]
     if sink is not None:
         v._a3d_sink = _SinkRows(sink, r0, w.shape[0])
     return v
@@ -467,8 +507,8 @@ class _GroupNorm(torch.autograd.Function):
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, aops, x, gamma, beta, eps, pe1, pe1_div, pe2, pe2_div, two):
-        ctx.aops, ctx.eps, ctx.beta = aops, eps, beta
-        ctx.save_for_backward(x, gamma)
+        ctx.aops, ctx.eps = aops, eps
+        ctx.save_for_backward(x, gamma, beta)
         ctx.set_materialize_grads(False)
         out = aops.base.layer_norm(x, gamma, beta, eps, pe1=pe1, pe1_div=pe1_div, pe2=pe2, pe2_div=pe2_div, two=two)
         return out if two else out
@@ -476,7 +516,7 @@ class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         base = ctx.aops.base
-        x, gamma = ctx.saved_tensors
+        x, gamma, beta = ctx.saved_tensors
         need = ctx.needs_input_grad
         dys = [d for d in dys if d is not None]
         if not dys:
@@ -485,7 +525,7 @@ class _LayerNorm(torch.autograd.Function):
         if len(dys) > 1:                     # both outputs of a two-encoding call were used: their gradients add (fp32 sum, one rounding)
             d = d + dys[1]
         dx, dg, db = base.layer_norm_bwd(x, d, gamma, ctx.eps, need_param=need[2] or need[3])
-        return (None, (dx if need[1] else None), _param_grad(gamma, dg if need[2] else None), _param_grad(ctx.beta, db if need[3] else None),
+        return (None, (dx if need[1] else None), _param_grad(gamma, dg if need[2] else None), _param_grad(beta, db if need[3] else None),
                 None, None, None, None, None, None)
 
 

@@ -652,11 +652,13 @@ class HipOps:
         return dq, dk, dv
 
     def _kv_map_covers(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int, rows: int) -> bool:
-        """``rowmap_covers`` for this attention's key map, decided once per map on the device and cached."""
+        """``rowmap_covers`` for this attention's key map, decided once per map and cached — on the CPU: the answer is a function of a few
+        integers, and a device-side unique / min / max with read-backs would be a host synchronisation inside the first backward of every
+        map (it would also fail under HIP-graph capture of a training step)."""
         key = (kmap.gdiv, kmap.ga, kmap.gb, kmap.seg_len, kmap.seg_stride, groups, q_per_kv, kv_len, rows)
         hit = self._kv_cover_cache.get(key)
         if hit is None:
-            hit = self._kv_cover_cache[key] = rowmap_covers(kmap, groups, q_per_kv, kv_len, rows, self.device)
+            hit = self._kv_cover_cache[key] = rowmap_covers(kmap, groups, q_per_kv, kv_len, rows, "cpu")
         return hit
 
     def _shared_kv_rows(self, kmap: RowMap, groups: int, q_per_kv: int, kv_len: int) -> torch.Tensor:

@@ -544,6 +544,46 @@ def test_packed_weight_with_a_sink_consumer_and_a_sliced_consumer_keeps_both_gra
     assert w._a3d_sink.grad32 is None
 
 
+def test_weight_rows_slice_keeps_the_placeholder_memory_free(monkeypatch):
+    """ADVICE r5: a ``weight_rows`` slice whose consumer is the FIRST sink consumer of the pass hands autograd the stride-0 zero placeholder;
+    autograd's plain slice backward would turn it into a dense full-size zero tensor, and PackW.backward would add that to the sink's gradient
+    (a full-width fp32 materialisation + add per pass).  ``weight_rows`` is its own autograd node now: what reaches PackW.backward is stride 0."""
+    from animate3d_amd import autograd_ops as A
+    torch.manual_seed(0)
+    m1 = torch.randn(6, 8, requires_grad=True)
+    m2 = torch.randn(4, 8, requires_grad=True)
+    w = A.pack_weight(torch.float32, [m1, m2])
+    x = torch.randn(5, 8)
+
+    class SinkGemm(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x_, w_, sink):
+            ctx.save_for_backward(x_, w_)
+            ctx.sink = sink
+            return x_ @ w_.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x_, w_ = ctx.saved_tensors
+            return None, A._weight_grad(ctx.sink, w_, dy.t() @ x_), None
+
+    seen = []
+    real_backward = A.PackW.backward
+
+    def spy(ctx, dw):
+        seen.append(None if dw is None else tuple(dw.stride()))
+        return real_backward(ctx, dw)
+    monkeypatch.setattr(A.PackW, "backward", staticmethod(spy))
+    rows = A.weight_rows(w, 0, 6)                      # the slice consumer runs its backward FIRST (it is the later op of the forward)
+    y_full = SinkGemm.apply(x, w, w._a3d_sink)
+    y_rows = SinkGemm.apply(x, rows, rows._a3d_sink)
+    (y_full.sum() * 2.0 + y_rows.sum() * 3.0).backward()
+    w_ref = torch.cat([m1.detach(), m2.detach()], 0).requires_grad_(True)
+    ((x @ w_ref.t()).sum() * 2.0 + (x @ w_ref[:6].t()).sum() * 3.0).backward()
+    assert torch.allclose(m1.grad, w_ref.grad[:6], atol=1e-6) and torch.allclose(m2.grad, w_ref.grad[6:], atol=1e-6)
+    assert seen and all(st is None or all(v == 0 for v in st) for st in seen), seen      # never a dense tensor
+
+
 def test_split_cols_collects_the_piece_gradients_in_one_buffer():
     """AutogradOps.split_cols on a fused K | V | Q | Q_i2v projection output: Q and Q_i2v feed one attention each (their dQ is written
     straight into the columns of the projection output's gradient buffer), K and V feed both (autograd sums the two dK / dV, the sum is
@@ -636,10 +676,26 @@ def test_deferred_param_grads_equal_autograd_accumulation():
     # an exception inside the context drops what was parked instead of adding half a pass
     with pytest.raises(RuntimeError, match="stop"):
         with A.deferred_param_grads():
-            A._Deferred.dst.append(next(iter(params.values())).grad)
-            A._Deferred.src.append(torch.ones(()))
+            gpar = next(iter(params.values())).grad
+            A._Deferred.park(gpar, torch.ones_like(gpar))
             raise RuntimeError("stop")
-    assert not A._Deferred.dst and not A._Deferred.src and not A._Deferred.active
+    assert not A._Deferred.dst and not A._Deferred.src and not A._Deferred.active and A._Deferred.parked_bytes == 0
+
+    # parked slices are flushed in chunks (bounded extra peak memory), with the same sums
+    for p in params.values():
+        p.grad.zero_()
+    old, A._Deferred.FLUSH_BYTES = A._Deferred.FLUSH_BYTES, 4096
+    parked.clear()
+    torch._foreach_add_ = spy
+    try:
+        with A.deferred_param_grads():
+            _loss(model, inp, target).backward()
+    finally:
+        torch._foreach_add_ = real
+        A._Deferred.FLUSH_BYTES = old
+    assert len(parked) > 3
+    for k, p in params.items():
+        assert torch.equal(p.grad, g0[k]), k
 
 
 def test_rowmap_coverage_decides_the_zero_fill_of_dk_dv():
