@@ -182,7 +182,7 @@ class TimedOps:
         self.flops.append(work)
         return out
 
-    def shape_summary(self, top=40):
+    def shape_summary(self, top=90):
         agg = {}
         for _, e0, e1, (fl, by), shp in self.records:
             d = agg.setdefault(shp, [0, 0.0, 0.0, 0.0])
@@ -358,7 +358,7 @@ def main():
     ap.add_argument("--no-groups", action="store_true", help="skip the instrumented forward behind the 'groups' object")
     ap.add_argument("--dtype", choices=("bf16", "fp16"), default=None, help="kernel storage type (default: what BASELINE.json states for the configuration)")
     ap.add_argument("--graph", action="store_true", help="also time the same steps replayed from a HIP graph (capture_graph)")
-    ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 40 by time)")
+    ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 90 by time)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration kernels behind the 'box' object")
     ap.add_argument("--rank-shape", type=str, default="", help="single process, no process group: time the COMPUTE leg of rank 0 of the multi-GPU layout "
@@ -572,7 +572,7 @@ def main():
             line["groups"] = groups
         if comm is not None:
             line["communication"] = comm
-        if world == 1 and not args.no_box and rpar is None:
+        if world == 1 and not args.no_box:
             line["box"] = box_calibration(ops._ops, dev)
         if world == 1 and not args.no_cpu_baseline and rpar is None:
             line["cpu_baseline"] = cpu_baseline(args.cpu_threads)
