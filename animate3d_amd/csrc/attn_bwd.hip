@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   const int total_tiles = ntiles * ((MODE == MODE_DKV) ? p.q_per_kv : 1);
   u32x4_t n1[NPT], n2[NPT];
   float stat_r = 0.f;
+  const float inv_do_scale = 1.f / p.do_scale;
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int64_t grp_r = (MODE == MODE_DKV) ? grp_c + t / ntiles : grp_c;      // group the row maps see
     const int r0 = (t % ntiles) * BR;
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
       if (tid < 2 * BR) {
         int s = r0 + (tid % BR); if (s >= rlen) s = rlen - 1;
         const int64_t si = (grp_r * p.heads + head) * (int64_t)p.q_len + s;
-        stat_r = (tid < BR) ? p.lse2[si] : p.delta[si];
+        // delta enters as dP's starting value: dP_raw - delta / do_scale (do_scale is applied once, to the finished gradients)
+        stat_r = (tid < BR) ? p.lse2[si] : -p.delta[si] * inv_do_scale;
       }
     }
   };
@@ -206,6 +208,101 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
     }
   };
 
+  // Round 6.  (a) VALU diet of the gradient passes: dP's accumulator STARTS at -delta / do_scale (a lane constant in the dQ pass, one LDS
+  // value per row in the dK|dV pass), so dS = P (dP_raw - delta / do_scale) is one multiply — do_scale is applied once, to the finished dQ / dK —,
+  // and the select that zeroes P for rows beyond the sequence only exists in the instantiation of a ragged last tile: 2.5-3 plain VALU
+  // instructions per score + the exp, where there were 5.5-6.  (b) Software pipeline inside a row tile: the two score-shaped products of
+  // sub-tile u + 1 are issued before the exp / dS arithmetic of sub-tile u, whose gradient products in turn run under the arithmetic of u + 1.
+  // (the second score set is 32 registers: the pipeline exists where it fits the 256-register budget of two workgroups per CU without
+  // spilling — the dQ pass up to head_dim 64; the dK|dV pass (235 registers before) and head_dim 80 keep the lean arithmetic only)
+  constexpr bool PIPE = (MODE == MODE_DQ) && D <= 64 && NU > 1;
+  f32x16_t sS[PIPE ? 2 : 1][CT], sP[PIPE ? 2 : 1][CT];
+  auto score_products = [&](const uint16_t* N1, const uint16_t* N2, const float (*rstat)[BR], int u, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      if constexpr (MODE == MODE_DQ) {
+        const float d0 = -dl_c[c] * inv_do_scale;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sS[slot][c][r] = 0.f; sP[slot][c][r] = d0; }
+      } else if constexpr (MODE == MODE_DKV) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 da = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g]);
+          const float4 db = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g + 4]);
+          sP[slot][c][8 * h] = da.x; sP[slot][c][8 * h + 1] = da.y; sP[slot][c][8 * h + 2] = da.z; sP[slot][c][8 * h + 3] = da.w;
+          sP[slot][c][8 * h + 4] = db.x; sP[slot][c][8 * h + 5] = db.y; sP[slot][c][8 * h + 6] = db.z; sP[slot][c][8 * h + 7] = db.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sS[slot][c][r] = 0.f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sS[slot][c][r] = 0.f; sP[slot][c][r] = 0.f; }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(N1 + 32 * u * NROW + nrow_off + 16 * ks);
+      const u32x4_t a2 = *reinterpret_cast<const u32x4_t*>(N2 + 32 * u * NROW + nrow_off + 16 * ks);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        sS[slot][c] = mfma32(a1, cA[c][ks], sS[slot][c]);
+        sP[slot][c] = mfma32(a2, cB[c][ks], sP[slot][c]);
+      }
+    }
+  };
+  // exp / dS arithmetic and the gradient products of sub-tile u (scores in slot); RAGGED: rows beyond rlen exist in this tile
+  auto gradient_step = [&](const uint16_t* N1, const uint16_t* N2, const float (*rstat)[BR], int r0, int u, int slot, auto ragged_c) __attribute__((always_inline)) {
+    constexpr bool RAGGED = decltype(ragged_c)::value;
+    const int rbase = r0 + 32 * u + 8 * g;          // row of register r: rbase + 16*(r>>3) + (r&7)
+    float ls[16];                                   // MODE_DKV: log-sum-exp of the 16 rows this lane holds
+    if constexpr (MODE == MODE_DKV) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 la = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g]);
+        const float4 lb = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g + 4]);
+        ls[8 * h] = la.x; ls[8 * h + 1] = la.y; ls[8 * h + 2] = la.z; ls[8 * h + 3] = la.w;
+        ls[8 * h + 4] = lb.x; ls[8 * h + 5] = lb.y; ls[8 * h + 6] = lb.z; ls[8 * h + 7] = lb.w;
+      }
+    }
+    u32x4_t dsf[CT][2], pf[CT][2];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float pv[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float lse = (MODE == MODE_DQ) ? lse_c[c] : ls[r];
+        pv[r] = __builtin_amdgcn_exp2f(fmaf(sS[slot][c][r], p.scale_log2, -lse));
+        if constexpr (RAGGED) { if (!(rbase + 16 * (r >> 3) + (r & 7) < rlen)) pv[r] = 0.f; }
+        ds[r] = pv[r] * sP[slot][c][r];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dsf[c][h][j] = pack16(ds[8 * h + 2 * j], ds[8 * h + 2 * j + 1]);
+          pf[c][h][j] = pack16(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // A = X^T [d = 32 mt + l31][rows 32 u + 16 h + 8 g .. + 7] straight from the natural image: two transposing reads of 4 rows each
+        const uint16_t* const tsrc = N1 + (32 * u + 16 * h) * NROW + 32 * mt + tr_off;
+        const u32x2_t f1a = lds_tr16_b64(tsrc), f1b = lds_tr16_b64(tsrc + 4 * NROW);
+        const u32x4_t f1 = {f1a[0], f1a[1], f1b[0], f1b[1]};
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc1[c][mt] = mfma32(f1, dsf[c][h], acc1[c][mt]);        // dQ^T += K^T dS^T   /   dK^T += Q^T dS
+        if constexpr (MODE == MODE_DKV) {
+          const uint16_t* const tsrc2 = N2 + (32 * u + 16 * h) * NROW + 32 * mt + tr_off;
+          const u32x2_t f2a = lds_tr16_b64(tsrc2), f2b = lds_tr16_b64(tsrc2 + 4 * NROW);
+          const u32x4_t f2 = {f2a[0], f2a[1], f2b[0], f2b[1]};
+#pragma unroll
+          for (int c = 0; c < CT; ++c) acc2[c][mt] = mfma32(f2, pf[c][h], acc2[c][mt]);       // dV^T += dO^T P
+        }
+      }
+  };
+
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -215,33 +312,18 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
     const uint16_t* const N2 = N1 + N_ELEMS;
     const float (*const rstat)[BR] = rstat_all[t & 1];
     if (t + 1 < total_tiles) load_tile(t + 1);
+    if constexpr (MODE == MODE_STATS) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      // ---- the two score-shaped products of this 32-row sub-tile, for the wave's CT column sub-tiles (A fragments shared)
-      f32x16_t s[CT], dp[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[c][r] = 0.f; dp[c][r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(N1 + 32 * u * NROW + nrow_off + 16 * ks);
-        const u32x4_t a2 = *reinterpret_cast<const u32x4_t*>(N2 + 32 * u * NROW + nrow_off + 16 * ks);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          s[c] = mfma32(a1, cA[c][ks], s[c]);
-          dp[c] = mfma32(a2, cB[c][ks], dp[c]);
-        }
-      }
-      const int rbase = r0 + 32 * u + 8 * g;          // row of register r: rbase + 16*(r>>3) + (r&7)
-      if constexpr (MODE == MODE_STATS) {
+      for (int u = 0; u < NU; ++u) {
+        score_products(N1, N2, rstat, u, 0);
+        const int rbase = r0 + 32 * u + 8 * g;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           float sv[16];
           float mx = -INFINITY;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            sv[r] = (rbase + 16 * (r >> 3) + (r & 7) < rlen) ? s[c][r] * p.scale_log2 : -INFINITY;
+            sv[r] = (rbase + 16 * (r >> 3) + (r & 7) < rlen) ? sS[0][c][r] * p.scale_log2 : -INFINITY;
             mx = fmaxf(mx, sv[r]);
           }
           mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -252,64 +334,26 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
           for (int r = 0; r < 16; ++r) {
             const float e = __builtin_amdgcn_exp2f(sv[r] - m_new);
             l_run[c] += e;
-            t_run[c] = fmaf(e, dp[c][r], t_run[c]);
+            t_run[c] = fmaf(e, sP[0][c][r], t_run[c]);
           }
           m_run[c] = m_new;
         }
-      } else {
-        float ls[16], dl[16];                         // MODE_DKV: statistics of the 16 rows this lane holds
-        if constexpr (MODE == MODE_DKV) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const float4 la = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g]);
-            const float4 lb = *reinterpret_cast<const float4*>(&rstat[0][32 * u + 16 * h + 8 * g + 4]);
-            const float4 da = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g]);
-            const float4 db = *reinterpret_cast<const float4*>(&rstat[1][32 * u + 16 * h + 8 * g + 4]);
-            ls[8 * h] = la.x; ls[8 * h + 1] = la.y; ls[8 * h + 2] = la.z; ls[8 * h + 3] = la.w;
-            ls[8 * h + 4] = lb.x; ls[8 * h + 5] = lb.y; ls[8 * h + 6] = lb.z; ls[8 * h + 7] = lb.w;
-            dl[8 * h] = da.x; dl[8 * h + 1] = da.y; dl[8 * h + 2] = da.z; dl[8 * h + 3] = da.w;
-            dl[8 * h + 4] = db.x; dl[8 * h + 5] = db.y; dl[8 * h + 6] = db.z; dl[8 * h + 7] = db.w;
-          }
-        }
-        u32x4_t dsf[CT][2], pf[CT][2];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          float pv[16], ds[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool ok = rbase + 16 * (r >> 3) + (r & 7) < rlen;
-            const float lse = (MODE == MODE_DQ) ? lse_c[c] : ls[r];
-            const float del = (MODE == MODE_DQ) ? dl_c[c] : dl[r];
-            pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[c][r], p.scale_log2, -lse)) : 0.f;
-            ds[r] = pv[r] * fmaf(dp[c][r], p.do_scale, -del);
-          }
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              dsf[c][h][j] = pack16(ds[8 * h + 2 * j], ds[8 * h + 2 * j + 1]);
-              pf[c][h][j] = pack16(pv[8 * h + 2 * j], pv[8 * h + 2 * j + 1]);
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            // A = X^T [d = 32 mt + l31][rows 32 u + 16 h + 8 g .. + 7] straight from the natural image: two transposing reads of 4 rows each
-            const uint16_t* const tsrc = N1 + (32 * u + 16 * h) * NROW + 32 * mt + tr_off;
-            const u32x2_t f1a = lds_tr16_b64(tsrc), f1b = lds_tr16_b64(tsrc + 4 * NROW);
-            const u32x4_t f1 = {f1a[0], f1a[1], f1b[0], f1b[1]};
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc1[c][mt] = mfma32(f1, dsf[c][h], acc1[c][mt]);        // dQ^T += K^T dS^T   /   dK^T += Q^T dS
-            if constexpr (MODE == MODE_DKV) {
-              const uint16_t* const tsrc2 = N2 + (32 * u + 16 * h) * NROW + 32 * mt + tr_off;
-              const u32x2_t f2a = lds_tr16_b64(tsrc2), f2b = lds_tr16_b64(tsrc2 + 4 * NROW);
-              const u32x4_t f2 = {f2a[0], f2a[1], f2b[0], f2b[1]};
-#pragma unroll
-              for (int c = 0; c < CT; ++c) acc2[c][mt] = mfma32(f2, pf[c][h], acc2[c][mt]);       // dV^T += dO^T P
-            }
-          }
       }
+    } else {
+      const bool ragged = r0 + BR > rlen;                     // workgroup-uniform
+      if constexpr (PIPE) score_products(N1, N2, rstat, 0, 0);
+      static_for<NU>([&](auto u_c) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_c)::value;
+        constexpr int slot = PIPE ? (u & 1) : 0;
+        if constexpr (PIPE) { if constexpr (u + 1 < NU) score_products(N1, N2, rstat, u + 1, (u + 1) & 1); }
+        else score_products(N1, N2, rstat, u, 0);
+        if constexpr (D >= 160) {               // (512 registers in use there: one body, with the select)
+          gradient_step(N1, N2, rstat, r0, u, slot, std::true_type{});
+        } else {
+          if (ragged) gradient_step(N1, N2, rstat, r0, u, slot, std::true_type{});
+          else gradient_step(N1, N2, rstat, r0, u, slot, std::false_type{});
+        }
+      });
     }
 #ifdef A3D_EXP_BWD_SINGLEBUF      // A/B build (python -m animate3d_amd.build --experiment A3D_EXP_BWD_SINGLEBUF): round 2's flow, two barriers per tile
     __syncthreads();
@@ -356,9 +400,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
           }
       };
       if constexpr (MODE == MODE_DQ) {
-        write(p.dQ, p.dqm, acc1[c], p.scale);
+        write(p.dQ, p.dqm, acc1[c], p.scale * p.do_scale);
       } else {
-        write(p.dK, p.dkm, acc1[c], p.scale);
+        write(p.dK, p.dkm, acc1[c], p.scale * p.do_scale);
         write(p.dV, p.dkm, acc2[c], p.do_scale);
       }
     }

@@ -361,6 +361,8 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 90 by time)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration kernels behind the 'box' object")
+    ap.add_argument("--gather-kv", action="store_true", help="sharded / --rank-shape runs: all-gather the projected K|V (2C wide) instead of the attention's "
+                    "input tokens (C wide, K|V projected locally for all views): ShardPlan.gather_tokens = False")
     ap.add_argument("--rank-shape", type=str, default="", help="single process, no process group: time the COMPUTE leg of rank 0 of the multi-GPU layout "
                     "cfg,views,frames (its local rows, K|V projections over the gathered token count, q_len != kv_len attention, split-K off, CU "
                     "reservation while a gather would be in flight), every collective replaced by a local copy of the right size; the line's metric says so")
@@ -420,10 +422,12 @@ def main():
         from animate3d_amd.parallel import rank_shape_unet
         rpar = rank_shape_unet(model, tuple(int(v) for v in args.rank_shape.split(",")))
         rpar.configure(V // n, n, F)
+        rpar.gather_tokens = not args.gather_kv
     if world > 1:
         from animate3d_amd.parallel import shard_unet
         layout = tuple(int(v) for v in args.layout.split(",")) if args.layout else None
         par = shard_unet(model, layout=layout, shape=(V // n, n, F))
+        par.gather_tokens = not args.gather_kv
     inp = make_inputs(cfg, V, n, F, hw, dev)
 
     def sync():
@@ -562,7 +566,8 @@ def main():
                                   "algorithmic_flop_per_rank": work / P,
                                   "would_receive_bytes_per_step": rpar.gather_bytes / args.steps, "collectives_per_step": rpar.collectives / args.steps,
                                   "modelled_link_ms": _link_ms(rpar, args.steps),
-                                  "reserved_cus_during_gathers": rpar.reserve_cus}
+                                  "reserved_cus_during_gathers": rpar.reserve_cus,
+                                  "gathers": "attention input tokens (K|V projected locally for all views)" if rpar.gather_tokens else "projected K|V"}
         if rpar is None and args.config == 2 and (n, F, lat) == (n0, F0, lat0):
             line["config2_25_ddim_steps_seconds"] = 25.0 * ms_per_step / 1e3
         if graph_ms is not None:
