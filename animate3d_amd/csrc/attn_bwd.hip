@@ -432,7 +432,13 @@ int launch(hipStream_t s, const BwdParams& p, int groups_y) {
 template <int MODE>
 int dispatch(hipStream_t s, const BwdParams& p, int head_dim, int groups_y) {
   switch (head_dim) {
-    case 40: return launch<40, MODE, 2, 1>(s, p, groups_y);
+#ifdef A3D_EXP_BWD_NU2
+    case 40: return launch<40, MODE, 2, 1>(s, p, groups_y);      // measurement build: round 5's 64-row tiles
+#else
+    // round 6: 128-row tiles at head_dim 40 (57 KB of LDS, still two workgroups per CU): half the barriers per score, 2.28 -> 2.12 ms per
+    // level-0 backward (profiles/r6_microbench_attn_bwd.log); head_dim 80 would drop to one workgroup per CU (90 KB) and stays at 64 rows
+    case 40: return launch<40, MODE, 4, 1>(s, p, groups_y);
+#endif
     case 64: return launch<64, MODE, 2, 1>(s, p, groups_y);
     case 80: return launch<80, MODE, 2, 1>(s, p, groups_y);
     case 160: return launch<160, MODE, 1, 1>(s, p, groups_y);

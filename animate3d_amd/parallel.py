@@ -111,6 +111,15 @@ class ShardPlan:
         self.frame_group_root = self._global_rank(self.cfg_rank, self.view_rank, 0)
         return self
 
+    def local_videos_on(self, V: int, n: int, device) -> torch.Tensor:
+        """``local_videos`` as a tensor on ``device``, cached per (V, n, layout, device): the forward asks for it on every call, and a fresh
+        host-to-device copy per call is a synchronising transfer (and illegal under HIP-graph capture)."""
+        key = (V, n, self.cfg_shards, self.view_shards, self.cfg_rank, self.view_rank, str(device))
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        if key not in cache:
+            cache[key] = self.local_videos(V, n).to(device)
+        return cache[key]
+
     def local_videos(self, V: int, n: int) -> torch.Tensor:
         """Indices (into the (b n) ordered video axis) of this rank's videos, in local (b n) order."""
         b = V // n

@@ -1101,7 +1101,7 @@ class MVUNetMotionModel(nn.Module):
         V_full, n_full, F_full, f0 = V, n, F, 0
         if par is not None:
             par.configure(V // n, n, F)
-            idx = par.local_videos(V, n).to(dev)
+            idx = par.local_videos_on(V, n, dev)
             f0, F = par.frame_range(F)
             sample = sample.index_select(0, idx)[:, :, f0:f0 + F]
             encoder_hidden_states = encoder_hidden_states.to(dev).index_select(0, idx)

@@ -455,6 +455,7 @@ if __name__ == "__main__":
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
          "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
+         "flashshort": lambda o: bench_flash(o, ((80, 4, 16, 256, 2), (80, 4, 16, 128, 2), (80, 4, 16, 512, 2), (80, 1, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 4, 16, 64, 2), (160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
          "flash40s": lambda o: bench_flash(o, ((40, 4, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 1, 16, 4096, 2))),
          "flash80": lambda o: bench_flash(o, ((80, 4, 16, 1024, 2), (80, 8, 32, 1024, 1), (80, 2, 3, 96, 2))),
          "flash160": lambda o: bench_flash(o, ((160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
