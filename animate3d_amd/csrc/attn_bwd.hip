@@ -58,8 +58,31 @@ A3D_DEV int kperm(int i) {
   return 16 * (b >> 1) + 8 * g + 4 * (b & 1) + j;
 }
 
-template <int D, int MODE, int NU, int CT, bool ALIGNED, int OCC>
+// LDS-DMA: 64 lanes x 16 B -> LDS[lds_dst + 16 lane] under a wave-uniform lane mask; source = scalar base + per-lane byte offset.  Not counted by
+// the compiler: s_waitcnt vmcnt by hand (flash_common.h has the same helper for the forward kernels).
+A3D_DEV void bwd_glds16_m(uint32_t voff, const void* sbase, uint32_t lds_dst, uint64_t mask) {
+  unsigned keep;
+  uint64_t ex;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(mask) : "memory");
+}
+A3D_DEV const uint16_t* bwd_scalar(const uint16_t* ptr) {      // wave-uniform by construction; say so
+  const uint64_t a = (uint64_t)(uintptr_t)ptr;
+  return (const uint16_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+}
+
+// DMA (round 6): the row tiles go global -> LDS by LDS-DMA instead of through registers.  Timing ablations (profiles/r6_attn_bwd_ablations.log)
+// put a quarter of a head_dim-40 backward into the row-tile hand-over — 2 x NPT global loads per thread issued before the tile's MFMAs,
+// 2 x NPT ds_write_b128 behind them, their waits — and nothing into the barrier itself.  With DMA the next tile is requested at the START of an
+// iteration into the other buffer (free since the barrier that ended the previous iteration) and has the whole tile's compute time to land;
+// the iteration ends with s_waitcnt vmcnt(0) + the same one barrier.  Same LDS image (padded natural rows; pad / contraction-padding slots are
+// never written: those lanes are masked off), same double buffer, so the occupancy is unchanged.  Launches whose row tiles are consecutive
+// rows (ALIGNED) and whose row count is a multiple of the tile (no clamped rows) — every training shape of the UNet — take it.
+template <int D, int MODE, int NU, int CT, bool ALIGNED, int OCC, bool DMA = false>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
+  static_assert(!DMA || ALIGNED, "DMA staging needs consecutive rows per tile");
   constexpr int BR = 32 * NU;              // rows per LDS tile
   constexpr int DK = (D + 15) / 16 * 16;   // contraction length of the score products, zero padded
   constexpr int KS = DK / 16;
@@ -146,6 +169,24 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   // transposing reads: lane (16-lane group q4 = lane >> 4, i16) addresses row 8 g + (i16 >> 2) (+ 4 for the second read), columns 16 (q4 & 1) + 4 (i16 & 3) .. + 3
   const int tr_off = (8 * g + ((lane & 15) >> 2)) * NROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
+  // ---- DMA lanes: 16-byte slot s of a tensor's tile image is row s / SPR, chunk s % SPR (chunks >= DCH: padding, never written);
+  // instruction j covers slots 64 j .. 64 j + 63, wave w issues j = w, w + 4, ...
+  constexpr int SPR = NROW / 8, NSLOT = BR * SPR, NI = (NSLOT + 63) / 64, NIW = (NI + 3) / 4;
+  uint32_t voffA[DMA ? NIW : 1], voffB[DMA ? NIW : 1];
+  uint64_t dmask[DMA ? NIW : 1];
+  if constexpr (DMA) {
+    const int64_t lda_ = (MODE == MODE_DKV) ? p.qm.ld : p.km.ld, ldb_ = (MODE == MODE_DKV) ? p.dom.ld : p.km.ld;
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int slot = 64 * (wid + 4 * i) + lane;
+      const int row = slot / SPR, ch = slot % SPR;
+      const bool ok = slot < NSLOT && ch < DCH;
+      voffA[i] = ok ? (uint32_t)((row * lda_ + ch * 8) * 2) : 0u;
+      voffB[i] = ok ? (uint32_t)((row * ldb_ + ch * 8) * 2) : 0u;
+      dmask[i] = __builtin_amdgcn_ballot_w64(ok);
+    }
+  }
+
   // ---- row-tile staging through registers: the loads of tile t+1 are issued before tile t's MFMAs, the LDS writes after them
   const uint16_t* const src_a = ((MODE == MODE_DKV) ? p.Q : p.K) + hoff;      // row-side tensors: (Q, dO) in DKV, (K, V) otherwise
   const uint16_t* const src_b = ((MODE == MODE_DKV) ? p.dO : p.V) + hoff;
@@ -171,15 +212,31 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
         row_a = row_of(ra, s); row_b = (MODE == MODE_DKV) ? row_of(rb, s) : row_a;
       }
     };
+    if constexpr (DMA) {
+      // (tile t goes into buffer t & 1: the caller guarantees its last readers have passed a barrier)
+      const uint16_t* const ba = bwd_scalar(src_a + tile_a * ld_a);
+      const uint16_t* const bb = bwd_scalar(src_b + tile_b * ld_b);
+      const uint32_t l1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(smem + (t & 1) * 2 * N_ELEMS);
+      const uint32_t l2 = l1 + (uint32_t)N_ELEMS * 2u;
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int c = tid + 256 * i;
-      if (NCH % 256 == 0 || c < NCH) {
-        const int r = c / DCH, ch = c % DCH;
-        int64_t row_a, row_b;
-        rows_of(r0 + r, row_a, row_b);
-        n1[i] = *reinterpret_cast<const u32x4_t*>(src_a + row_a * ld_a + ch * 8);
-        n2[i] = *reinterpret_cast<const u32x4_t*>(src_b + row_b * ld_b + ch * 8);
+      for (int i = 0; i < NIW; ++i) {
+        const int j = wid + 4 * i;
+        if (j < NI) {
+          bwd_glds16_m(voffA[i], ba, l1 + (uint32_t)j * 1024u, dmask[i]);
+          bwd_glds16_m(voffB[i], bb, l2 + (uint32_t)j * 1024u, dmask[i]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        const int c = tid + 256 * i;
+        if (NCH % 256 == 0 || c < NCH) {
+          const int r = c / DCH, ch = c % DCH;
+          int64_t row_a, row_b;
+          rows_of(r0 + r, row_a, row_b);
+          n1[i] = *reinterpret_cast<const u32x4_t*>(src_a + row_a * ld_a + ch * 8);
+          n2[i] = *reinterpret_cast<const u32x4_t*>(src_b + row_b * ld_b + ch * 8);
+        }
       }
     }
     if constexpr (MODE == MODE_DKV) {
@@ -194,13 +251,17 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
     uint16_t* const S1 = smem + buf * 2 * N_ELEMS;
     uint16_t* const S2 = S1 + N_ELEMS;
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the tile have landed (the barrier that follows publishes them)
+    } else {
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int c = tid + 256 * i;
-      if (NCH % 256 == 0 || c < NCH) {
-        const int r = c / DCH, ch = c % DCH;
-        *reinterpret_cast<u32x4_t*>(S1 + r * NROW + ch * 8) = n1[i];
-        *reinterpret_cast<u32x4_t*>(S2 + r * NROW + ch * 8) = n2[i];
+      for (int i = 0; i < NPT; ++i) {
+        const int c = tid + 256 * i;
+        if (NCH % 256 == 0 || c < NCH) {
+          const int r = c / DCH, ch = c % DCH;
+          *reinterpret_cast<u32x4_t*>(S1 + r * NROW + ch * 8) = n1[i];
+          *reinterpret_cast<u32x4_t*>(S2 + r * NROW + ch * 8) = n2[i];
+        }
       }
     }
     if constexpr (MODE == MODE_DKV) {
@@ -311,7 +372,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
     const uint16_t* const N1 = smem + (t & 1) * 2 * N_ELEMS;
     const uint16_t* const N2 = N1 + N_ELEMS;
     const float (*const rstat)[BR] = rstat_all[t & 1];
+#if !defined(A3D_EXP_BWD_NOSTAGE)
     if (t + 1 < total_tiles) load_tile(t + 1);
+#endif
     if constexpr (MODE == MODE_STATS) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -359,6 +422,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_kernel(const BwdParams p) {
     __syncthreads();
     if (t + 1 < total_tiles) store_tile((t + 1) & 1);
     __syncthreads();
+#elif defined(A3D_EXP_BWD_NOSTAGE)      // timing ablations (results wrong): no row-tile loads / LDS stores after tile 0; == 2: no barrier either
+    if (t == 0) store_tile(1);
+#if A3D_EXP_BWD_NOSTAGE != 2
+    __syncthreads();
+#endif
 #else
     // tile t+1 goes into the other buffer: its last readers (tile t-1) passed the barrier of the previous iteration
     if (t + 1 < total_tiles) store_tile((t + 1) & 1);
@@ -422,7 +490,16 @@ int launch(hipStream_t s, const BwdParams& p, int groups_y) {
   // (measured, round 3: three workgroups per CU for the 168-register dQ pass and 128-row tiles at head_dim 40 change nothing: 2.33-2.44 ms
   // per level-0 backward in every variant, profiles/README.md)
   constexpr int OCC = (CT == 1 && (D <= 64 || (D == 80 && MODE != MODE_DKV))) ? 2 : 1;
-  if (aligned) attn_bwd_kernel<D, MODE, NU, CT, true, OCC><<<grid, dim3(256), 0, s>>>(p);
+  const int rlen = (MODE == MODE_DKV) ? p.q_len : p.kv_len;
+  // LDS-DMA staging: consecutive rows per tile, no clamped rows, 32-bit lane offsets, 16-byte aligned rows (checked by the entry point)
+  const int64_t ld_max = p.qm.ld > p.km.ld ? (p.qm.ld > p.dom.ld ? p.qm.ld : p.dom.ld) : (p.km.ld > p.dom.ld ? p.km.ld : p.dom.ld);
+#ifdef A3D_EXP_BWD_NODMA
+  const bool dma = false;
+#else
+  const bool dma = MODE != MODE_STATS && aligned && rlen % BR == 0 && (int64_t)BR * ld_max * 2 < (1ll << 31);
+#endif
+  if (dma) attn_bwd_kernel<D, MODE, NU, CT, true, OCC, true><<<grid, dim3(256), 0, s>>>(p);
+  else if (aligned) attn_bwd_kernel<D, MODE, NU, CT, true, OCC><<<grid, dim3(256), 0, s>>>(p);
   else attn_bwd_kernel<D, MODE, NU, CT, false, OCC><<<grid, dim3(256), 0, s>>>(p);
   return a3d_launch_status();
 }
