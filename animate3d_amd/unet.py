@@ -316,11 +316,33 @@ class MVUNetMotionModel(nn.Module):
         """:530-539."""
 
     def enable_freeu(self, s1: float, s2: float, b1: float, b2: float) -> None:
-        """:562-585 (FreeU re-weighting of the up blocks' backbone / skip features) is not implemented; no caller of the reference uses it."""
-        raise NotImplementedError("FreeU is not implemented on the MI355X path")
+        """:562-585: the four FreeU factors (arXiv 2309.11497) are set on every up block; the arithmetic is diffusers' ``apply_freeu`` in front
+        of each ``torch.cat([hidden_states, res_hidden_states], 1)`` of up blocks 0 and 1: the first half of the backbone channels x b1 / b2, the
+        2 x 2 lowest frequencies of every skip plane x s1 / s2 (``_freeu``; inference only).  No caller of the reference uses it."""
+        self._freeu_factors = (float(s1), float(s2), float(b1), float(b2))
 
     def disable_freeu(self) -> None:
-        """:587-594.  FreeU is never on."""
+        """:587-594."""
+        self._freeu_factors = None
+
+    def _freeu(self, idx: int, x, skip, B2: int, H: int, W: int):
+        """``apply_freeu(resolution_idx = idx, ...)`` on token rows.  The backbone half is scaled in the storage type (as the reference's in-place
+        multiply); the skip features go through rocFFT in fp32 over the (H, W) axes of their [B2, H, W, C] view (the reference transforms
+        power-of-two planes in the model's dtype and others in fp32: fp32 always is the more accurate of the two) — like FreeInit's
+        filter (denoise.py) this is torch.fft on device tensors, the one place besides it where the step leaves the C-ABI."""
+        fz = getattr(self, "_freeu_factors", None)
+        if fz is None or idx > 1:
+            return x, skip
+        s1, s2, b1, b2 = fz
+        b, sc = (b1, s1) if idx == 0 else (b2, s2)
+        half = x.shape[1] // 2
+        x = x.clone()
+        x[:, :half] *= b
+        f = torch.fft.fftshift(torch.fft.fftn(skip.view(B2, H, W, -1).float(), dim=(1, 2)), dim=(1, 2))
+        cr, cc = H // 2, W // 2
+        f[:, cr - 1:cr + 1, cc - 1:cc + 1, :] *= sc
+        skip = torch.fft.ifftn(torch.fft.ifftshift(f, dim=(1, 2)), dim=(1, 2)).real.to(skip.dtype).reshape(skip.shape).contiguous()
+        return x, skip
 
     def set_default_attn_processor(self) -> None:
         """:542-555 only works while every processor is a stock diffusers one and raises otherwise; this model always carries the
@@ -1022,6 +1044,8 @@ class MVUNetMotionModel(nn.Module):
         if getattr(self, "_training_enabled", False) and torch.is_grad_enabled():
             if self.parallel is not None and self.parallel.world > 1:
                 raise NotImplementedError("a sharded (shard_unet) model is inference-only; training shards the batch (train.py: DDP)")
+            if getattr(self, "_freeu_factors", None) is not None:
+                raise NotImplementedError("FreeU (enable_freeu) is an inference-time re-weighting; the training path does not differentiate it")
             self._active_ops = self._autograd_ops()
             self._packed = None        # the parameters are about to change: the next no_grad call (validation) packs them afresh
             try:
@@ -1209,9 +1233,11 @@ class MVUNetMotionModel(nn.Module):
         if mid_block_additional_residual is not None:
             x = plus(x, mid_block_additional_residual, h_, w_)
         lvl = len(sizes) - 1
-        for blk, pk in zip(self.up_blocks, P.up):
+        for bi, (blk, pk) in enumerate(zip(self.up_blocks, P.up)):
             for j, rp in enumerate(pk.resnets):
                 skip = skips.pop()
+                if getattr(self, "_freeu_factors", None) is not None:
+                    x, skip = self._freeu(bi, x, skip, B2, h_, w_)
                 # inference on an op set with the two-source kernels: no concatenation pass (the pair goes to _resnet); training forwards
                 # (autograd op set, checkpointed layers take one tensor) keep the concat
                 pair = self._active_ops is None and hasattr(ops, "gemm2") and hasattr(ops, "group_norm2")

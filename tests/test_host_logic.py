@@ -341,6 +341,31 @@ def _residual_shapes(cfg, B2, hw):
     return shapes, (B2, boc[-1], h, w)
 
 
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (12, 20)])
+def test_freeu_matches_the_restated_diffusers_arithmetic(hw):
+    """enable_freeu (unet_motion_mv_model.py:562-585) stores four factors on the up blocks; diffusers' up blocks then run apply_freeu in front
+    of every skip concatenation of up blocks 0 and 1 (backbone half x b, low frequencies of the skip x s).  Product (token rows, rocFFT / torch.fft
+    over the H, W axes of the NHWC view) against the oracle's NCHW restatement (oracle/freeu_ref.py; third-party arithmetic: parity unpinned),
+    power-of-two and other plane sizes (12 x 20 also takes the forced-upsample-size path), and: off again = bit-identical to never on."""
+    from oracle.freeu_ref import freeu
+    ocfg, ref, model = _pair(2, 2, hw)
+    inp = O.synthetic_inputs(ocfg, 2, 2, 2, hw, seed=9)
+    y_off = model(**inp).sample
+    y_plain = ref(**inp).sample
+    factors = dict(s1=0.9, s2=0.2, b1=1.5, b2=1.6)             # the FreeU repository's SD1.5 values
+    with freeu(ref, **factors):
+        y_ref = ref(**inp).sample
+    assert torch.equal(ref(**inp).sample, y_plain)              # the context manager restores the oracle
+    model.enable_freeu(**factors)
+    y = model(**inp).sample
+    np.testing.assert_allclose(y.numpy(), y_ref.numpy(), rtol=2e-3, atol=2e-4)
+    assert (y_ref - y_plain).abs().max() > 1e-2 * y_plain.abs().max()      # it does something
+    model.disable_freeu()
+    assert torch.equal(model(**inp).sample, y_off)
+
+
 @pytest.mark.parametrize("hw", [(8, 8), (12, 20)])
 def test_controlnet_residual_inputs(hw):
     """unet_motion_mv_model.py:787-796, 816-817: additional residuals on the skip connections and on the mid block's output
@@ -414,8 +439,8 @@ def test_motion_module_save_load_freeze_surface(tmp_path):
     with pytest.raises(KeyError):
         other.load_motion_modules(SimpleNamespace(state_dict=lambda: {k: v for k, v in sd.items() if "down_blocks.1" not in k}))
     other.fuse_qkv_projections(); other.unfuse_qkv_projections(); other.enable_forward_chunking(2, 1); other.disable_forward_chunking(); other.disable_freeu()
-    with pytest.raises(NotImplementedError):
-        other.enable_freeu(0.9, 0.2, 1.2, 1.4)
+    other.enable_freeu(0.9, 0.2, 1.2, 1.4); other.disable_freeu()          # (arithmetic: test_freeu_matches_the_restated_diffusers_arithmetic)
+    assert other._freeu_factors is None
     with pytest.raises(ValueError):
         other.set_default_attn_processor()
     with pytest.raises(ValueError):

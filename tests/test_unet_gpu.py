@@ -425,3 +425,34 @@ def test_forward_parity_on_a_peaked_softmax(dtype, bar):
         # fp16 storage: P has a 20-binade window above the sampled offset; at sd 3 a minority of workgroups may go exact (profiles/README.md,
         # round 5: the OR-predictor sent EVERY workgroup there and nobody noticed because the results stayed right)
         assert (voted + rerun) * 2 <= launched, f"{voted} + {rerun} of {launched} workgroups left the fast path at score sd 3"
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.bfloat16, 3e-2), (torch.float16, 6e-3)], ids=["bf16", "fp16"])
+def test_freeu_on_the_hip_path(dtype, bar):
+    """enable_freeu (unet_motion_mv_model.py:562-585) on the kernels: two real-width levels (up block 0 at 8 x 8, up block 1 at 16 x 16), the
+    FreeU repository's SD1.5 factors, against the oracle with diffusers' apply_freeu restated (oracle/freeu_ref.py; parity unpinned);
+    switched off again the model reproduces its plain output bit for bit; a HIP-graph capture with FreeU on replays."""
+    from oracle.freeu_ref import freeu
+    arch = dict(block_out_channels=(320, 640), down_has_attn=(True, True), layers_per_block=1)
+    n, F, hw, V = 2, 2, (16, 16), 2
+    ocfg = O.UNetConfig(**arch)
+    ref = O.build_dense(ocfg, n, F, hw, seed=0)
+    hip = MVUNetMotionModel(UNetConfig(**arch), num_views=n, device="cuda")
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(dtype).eval()
+    inp = O.synthetic_inputs(ocfg, V, n, F, hw, seed=31)
+    cinp = _cuda(inp)
+    y_plain = hip(**cinp).sample
+    factors = dict(s1=0.9, s2=0.2, b1=1.5, b2=1.6)
+    with freeu(ref, **factors):
+        y_ref = ref(**inp).sample
+    hip.enable_freeu(**factors)
+    y = hip(**cinp).sample
+    e, mx, sc = _rel(y, y_ref)
+    moved = _rel(y, y_plain)[0]
+    print(f"[parity] FreeU ({dtype}): hip-vs-oracle rel_l2={e:.3e} max_abs={mx:.3e} (|ref|max {sc:.3e}); FreeU moves the output by {moved:.3e}")
+    assert torch.isfinite(y).all() and e <= bar and moved > 5 * e
+    step = hip.capture_graph(**cinp)
+    assert torch.equal(step(**cinp).sample, y)
+    hip.disable_freeu()
+    assert torch.equal(hip(**cinp).sample, y_plain)
