@@ -4,7 +4,9 @@
     python bench.py --gpus 1 --steps 3 --warmup 1
     python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W [--layout cfg,views,frames]
+           bench.py --gpus N --steps K --warmup W [--layout cfg,views,frames] [--gather-kv]
+    python bench.py --rank-shape 2,4,1                     # ONE GPU: the compute leg of rank 0 of an 8-GPU layout (collectives replaced by local
+                                                           # copies of the right size; link time modelled, not measured); the line's metric says so
 
 One "step" = one MVUNetMotionModel.forward on the CFG-doubled batch exactly as the reference pipeline
 issues it (pipeline.py:1008-1020).  Default workload = BASELINE config 2 (the configuration the metric is quoted on):
