@@ -42,18 +42,15 @@ constexpr float DM_L_BAD = 1.2676506e30f;          // 2^100: beyond this the max
 // row maximum within ~2^100 of the estimate works and the first 32 keys are sample enough.  fp16 holds 2^-24 .. 2^16: the window is
 // [estimate - 4, estimate + 20) — the sample is 32 keys spread evenly over the whole key range (one extra 2.5-KB DMA and 3 MFMAs per
 // query sub-tile), the bias is small so that the row maximum stays a normal number, and a row that still overflows (P = inf, the
-// row sum is not finite) sends its workgroup to the exact pass like any other overflow.
+// row sum is not finite) sends its workgroup to the exact pass like any other overflow.  Round 6: the bias grows with the sample's
+// spread (flash_common.h: f16_sampled_bias — up to 12, the window then ends 28 units above the sample maximum), and a row whose sample
+// predicts an overflow even so never starts the max-free pass (the workgroup votes).
 #ifdef A3D_STORAGE_F16
-constexpr float DM_BIAS = 4.f;
+constexpr float DM_BIAS = F16_BIAS;
 constexpr bool DM_SAMPLED = true;
-// ... and a row whose sample already predicts an overflow never starts the max-free pass: with sample standard deviation sd (log2
-// units) the maximum of 16 384 scores is expected ~2.4 sd above the maximum of 32 (Gaussian tails: 4.4 sd vs 2.0 sd); the workgroup
-// goes straight to the exact pass when 3.4 sd (one sd of safety) would leave the 20-unit window, i.e. sd^2 > DM_VAR_MAX.
-constexpr float DM_VAR_MAX = 28.f;
 #else
 constexpr float DM_BIAS = 40.f;
 constexpr bool DM_SAMPLED = false;
-constexpr float DM_VAR_MAX = 0.f;           // (unused)
 #endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t dm_smem[];
@@ -267,6 +264,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
       for (int nb = 0; nb < 2 * QT; ++nb) oacc16[mb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
   const int nt = p.kv_len / 64;               // launcher guarantees kv_len % 64 == 0, nt >= 4, aligned segments
+  [[maybe_unused]] const float cmax_sds = f16_expected_max_sds(p.kv_len);
   auto prologue_dma = [&]() __attribute__((always_inline)) {      // (sample sub-tile,) tiles 0, 1, 2 requested; all but tile 2 complete
     dma_reset();
     if constexpr (DM_SAMPLED && TRY_NOMAX)
@@ -291,15 +289,20 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qs][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float b = bias;
       if constexpr (DM_SAMPLED) {
-        float sm = 0.f, sq = 0.f;
+        if (bias != 0.f) {                 // (the exact pass starts from the plain maximum)
+          float sm = 0.f, sq = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sm += s[qs][r]; sq = fmaf(s[qs][r], s[qs][r], sq); }
-        sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
-        const float mean = sm * (1.f / 32.f);
-        wide = wide || !(sq * (1.f / 32.f) - mean * mean <= DM_VAR_MAX);
+          for (int r = 0; r < 16; ++r) { sm += s[qs][r]; sq = fmaf(s[qs][r], s[qs][r], sq); }
+          sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+          const float mean = sm * (1.f / 32.f);
+          bool wq;
+          b = f16_sampled_bias(mx, mean, sq * (1.f / 32.f) - mean * mean, cmax_sds, wq);
+          wide = wide || wq;
+        }
       }
-      const float new_off = round16(mx + bias);
+      const float new_off = round16(mx + b);
       m_off[qs] = new_off;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[qs][r] -= new_off;

@@ -33,14 +33,13 @@ constexpr int E_SMEM_BYTES = E_SAMPLE + E_UNITB;
 constexpr float E_L_BAD = 1.2676506e30f;           // 2^100
 // max-free offset = maximum of 32 sample scores + E_BIAS: bf16 keeps the first 32 keys and a wide margin, fp16 (P within 2^-24 .. 2^16)
 // samples 32 keys spread over the key range and keeps the row maximum a normal number (flash_attn_dm.hip, DM_BIAS)
+// (round 6: plus a lift towards the expected row maximum, flash_common.h: f16_sampled_bias)
 #ifdef A3D_STORAGE_F16
-constexpr float E_BIAS = 4.f;
+constexpr float E_BIAS = F16_BIAS;
 constexpr bool E_SAMPLED = true;
-constexpr float E_VAR_MAX = 28.f;                   // sample variance (log2 units squared) above which the workgroup skips the max-free pass
 #else
 constexpr float E_BIAS = 40.f;
 constexpr bool E_SAMPLED = false;
-constexpr float E_VAR_MAX = 0.f;           // (unused)
 #endif
 
 extern __shared__ __attribute__((aligned(16))) uint8_t e_smem[];
@@ -195,13 +194,15 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     bool wide = false;
-    if constexpr (E_SAMPLED) {      // spread of the sample scores: does it predict an overflow of fp16's window? (flash_attn_dm.hip, DM_VAR_MAX)
-      float sm = 0.f, sq = 0.f;
+    if constexpr (E_SAMPLED) {      // spread of the sample scores: lift the window towards the expected row maximum; does it still predict an overflow?
+      if (bias != 0.f) {
+        float sm = 0.f, sq = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sm += s[r]; sq = fmaf(s[r], s[r], sq); }
-      sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
-      const float mean = sm * (1.f / 32.f);
-      wide = !(sq * (1.f / 32.f) - mean * mean <= E_VAR_MAX);
+        for (int r = 0; r < 16; ++r) { sm += s[r]; sq = fmaf(s[r], s[r], sq); }
+        sm += __shfl_xor(sm, 32); sq += __shfl_xor(sq, 32);
+        const float mean = sm * (1.f / 32.f);
+        bias = f16_sampled_bias(mx, mean, sq * (1.f / 32.f) - mean * mean, f16_expected_max_sds(p.kv_len), wide);
+      }
     }
     m_off = mx + bias;
 #pragma unroll

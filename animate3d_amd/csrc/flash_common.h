@@ -43,6 +43,26 @@ A3D_DEV int kperm(int i) {
 
 A3D_DEV float round16(float x) { return lo16(pack16(x, 0.f)); }
 
+// fp16 storage, max-free pass of the LDS-DMA kernels: where to put the window of P = exp2(S - offset) — fp16 holds 2^-24 .. 2^16 — from
+// the statistics of 32 sample scores of a query (maximum mx, mean, variance; log2 units).  Rounds 3-5: offset = mx + 4, i.e. the window
+// ends 20 units above the sample maximum; for Gaussian scores the maximum of 16 384 sits ~1.85 sd (+- 0.6 sd) above the maximum of 32, so
+// at score sd 3 (natural units: 4.3 log2 units) 1-2 % of the rows overflowed, which is every 512-query workgroup: the whole launch fell
+// back to the exact pass (+13-19 %: profiles/r5_flash_score_spread.log).  Round 6: the offset is LIFTED towards the expected row maximum
+// mean + c(kv_len) sd (c = the expected maximum of kv_len standard normals: 3.2 at 1 024 keys, 3.9 at 16 384), by at most F16_LIFT_MAX so
+// that the sample maximum itself stays a normal fp16 number (2^-(4 + 8)): a distribution with lighter tails than the prediction loses
+// nothing but the subnormal tail of the tail.  `wide`: even the lifted window is predicted to overflow (3.7 sigma of the prediction's
+// own scatter: 0.6 sd) — the workgroup votes on it (> 25 % of its queries -> exact pass at once).
+constexpr float F16_BIAS = 4.f, F16_LIFT_MAX = 8.f, F16_TOP = 16.f;
+A3D_DEV float f16_expected_max_sds(int kv_len) {      // E[max of n standard normals], n = 2^8 .. 2^16: 2.85 + 0.175 (log2 n - 8)
+  return 2.85f + 0.175f * (float)(31 - __builtin_clz((unsigned)(kv_len < 256 ? 256 : kv_len)) - 8);
+}
+A3D_DEV float f16_sampled_bias(float mx, float mean, float var, float cmax, bool& wide) {
+  const float sd = __builtin_amdgcn_sqrtf(fmaxf(var, 0.f));
+  const float lift = fminf(fmaxf(fmaf(cmax, sd, mean) - mx, 0.f), F16_LIFT_MAX);
+  wide = !(fmaf(cmax + 2.2f, sd, mean) <= mx + F16_BIAS + lift + F16_TOP);      // (NaN statistics: wide)
+  return F16_BIAS + lift;
+}
+
 
 // LDS-DMA: 64 lanes x 16 B, lane i -> LDS[lds_dst + 16 i]; source = scalar base + per-lane byte offset.  Not counted by the
 // compiler: s_waitcnt vmcnt by hand.

@@ -422,9 +422,10 @@ def test_forward_parity_on_a_peaked_softmax(dtype, bar):
     if dtype == torch.bfloat16:
         assert voted == 0 and rerun == 0, "bf16 storage: sd 3 is far inside the 2^100 window, nothing may leave the fast path"
     else:
-        # fp16 storage: P has a 20-binade window above the sampled offset; at sd 3 a minority of workgroups may go exact (profiles/README.md,
-        # round 5: the OR-predictor sent EVERY workgroup there and nobody noticed because the results stayed right)
-        assert (voted + rerun) * 2 <= launched, f"{voted} + {rerun} of {launched} workgroups left the fast path at score sd 3"
+        # fp16 storage: P has a 20- to 28-binade window above the sample maximum (round 6: lifted with the sample's spread); at sd 3 a small
+        # minority of workgroups may go exact (profiles/README.md, round 5: the OR-predictor sent EVERY workgroup there and nobody noticed
+        # because the results stayed right)
+        assert (voted + rerun) * 20 <= launched, f"{voted} + {rerun} of {launched} workgroups left the fast path at score sd 3"
 
 
 @pytest.mark.parametrize("dtype,bar", [(torch.bfloat16, 3e-2), (torch.float16, 6e-3)], ids=["bf16", "fp16"])

@@ -98,7 +98,7 @@ def bench_flashdm(ops, scales=(1.0, 0.0, 3.0)):
             print(f"level-0 D=40 scale={sc} {name:8s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err vs generic = {err:.2e}", flush=True)
 
 
-def bench_flashspread(_ops, sds=(0.3, 1.0, 3.0, 6.0)):
+def bench_flashspread(_ops, sds=(0.3, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0)):
     """The LDS-DMA attention kernels (head_dim 40 at the level-0 launch shape, head_dim 80 at the level-1 shape) on scores of a given
     spread: q, k ~ N(0, sd) so that scale * q.k has standard deviation sd (natural-log units, what softmax sees); v ~ N(0, 1).  Per
     storage type: the default dispatch (max-free pass, exact re-run per workgroup when its row sums leave the window — fp16 storage also when the
@@ -118,7 +118,11 @@ def bench_flashspread(_ops, sds=(0.3, 1.0, 3.0, 6.0)):
                 k = (torch.randn(rows, C, device="cuda") * sd ** 0.5).to(dt)
                 v = torch.randn(rows, C, device="cuda").to(dt)
                 ref = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, plain=True).float()
+                cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+                ops.attn_counters = cnt                   # a3d_flash_attn_counted: [0] voted exact, [1] re-ran after an overflow, [2] workgroups
                 out = ops.flash_attn(q, k, v, qm, qm, G, heads, S, S).float()
+                ops.attn_counters = None
+                voted, rerun, launched = (int(x) for x in cnt[:3].tolist())
                 err = ((out - ref).norm() / (ref.norm() + 1e-30)).item()
                 reps = 5 if D == 40 else 11
                 t_def, _ = timeit(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S), reps=reps)
@@ -126,7 +130,8 @@ def bench_flashspread(_ops, sds=(0.3, 1.0, 3.0, 6.0)):
                 base = t_def if base is None else base
                 share = min(1.0, max(0.0, (t_def - base) / t_ex))
                 print(f"{str(dt)[6:]:8s} D={D:3d} S={S:5d} score sd={sd:3.1f}: default {t_def:7.3f} ms {flops / t_def / 1e9:7.1f} TF/s | exact pass only {t_ex:7.3f} ms | "
-                      f"exact-pass share of the default launch ~{share:4.2f} | err vs generic kernel {err:.2e}", flush=True)
+                      f"exact-pass share of the default launch ~{share:4.2f} | workgroups {launched}: voted exact {voted}, re-ran after overflow {rerun} | "
+                      f"err vs generic kernel {err:.2e}", flush=True)
 
 
 def bench_gemm(ops):
