@@ -427,7 +427,7 @@ constexpr int RING_VS_PP_PCT = A3D_RING_VS_PP_PCT;
 inline bool plan_ring(const GemmParams& p, int flags, RingPlan& out) {
   if (a3d_gemm_kernel_of(flags) == A3D_GEMM_TILE128 || a3d_gemm_kernel_of(flags) == A3D_GEMM_DIRECT || p.out_f32 || !p.vec16 || p.X2 != nullptr) return false;
   if (p.M % 128 != 0 || p.K % 64 != 0 || p.K < 256 || p.ldx % 64 != 0 || p.ldw % 64 != 0) return false;
-  if ((uint64_t)p.ldx * 16u >= (1ull << 31) || (uint64_t)p.ldw * 16u >= (1ull << 31)) return false;
+  if ((uint64_t)p.ldx * 64u >= (1ull << 32) || (uint64_t)p.ldw * 256u >= (1ull << 32)) return false;      // 32-bit piece offsets: 3 x 16 ldx, 9 x 16 ldw bytes
   if (p.rowbias && p.rb_div % 128 != 0) return false;
   int n = 0;
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, a3d_current_device()) != hipSuccess || n <= 0) n = 256;

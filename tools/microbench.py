@@ -79,6 +79,25 @@ def bench_flash(ops, shapes=((40, 4, 16, 4096, 2), (80, 4, 16, 1024, 2), (160, 4
             print(f"D={D:3d} S={S:5d} G={G} {name:8s}: {med:8.3f} ms  {flops / med / 1e9:7.1f} TF/s (best {flops / mn / 1e9:7.1f})  err={err:.2e}")
 
 
+def bench_flashdt(_ops):
+    """bf16 against fp16 storage on the LDS-DMA kernels at short and long key counts (in-graph timing): what fp16's sampled-offset prologue
+    (one extra 32-key sample tile, its MFMAs, the statistics and the workgroup vote) costs per workgroup."""
+    for (D, n, F, L, b) in ((40, 4, 16, 1024, 1), (40, 4, 16, 4096, 1), (40, 4, 16, 256, 1), (80, 4, 16, 256, 1), (80, 4, 16, 1024, 1)):
+        heads, C = 8, 8 * D
+        rows = b * n * F * L
+        qm = RowMap(F, n * F * L, L, L, F * L)
+        S, G = n * L, b * F
+        flops = 4.0 * G * S * S * C
+        line = f"D={D:3d} S={S:5d} G={G}:"
+        for dt in (torch.bfloat16, torch.float16):
+            ops = HipOps(act_dtype=dt)
+            q, k, v = (torch.randn(rows, C, device="cuda").to(dt) for _ in range(3))
+            for name, kw in (("default", {}), ("exact", dict(exact=True))):
+                us = graph_time(lambda: ops.flash_attn(q, k, v, qm, qm, G, heads, S, S, **kw), n=20 if S <= 4096 else 3)
+                line += f"  {str(dt)[6:]} {name} {us:8.1f} us {flops / us / 1e6:6.1f} TF/s |"
+        print(line, flush=True)
+
+
 def bench_flashdm(ops, scales=(1.0, 0.0, 3.0)):
     """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel (default), its exact
     pass alone and the generic kernel, interleaved rounds in one process.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
@@ -458,7 +477,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "flashdt": bench_flashdt, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flashshort": lambda o: bench_flash(o, ((80, 4, 16, 256, 2), (80, 4, 16, 128, 2), (80, 4, 16, 512, 2), (80, 1, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 4, 16, 64, 2), (160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
          "flash40s": lambda o: bench_flash(o, ((40, 4, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 1, 16, 4096, 2))),
