@@ -98,6 +98,24 @@ def bench_flashdt(_ops):
         print(line, flush=True)
 
 
+def bench_flashrank(ops):
+    """The level-0 attention launch as a rank of a multi-GPU layout sees it (its own views' queries against the gathered keys of all views:
+    q_len = views_local x L, kv_len = 4 L) next to the single-GPU launch, same keys per group: time per workgroup round should not differ."""
+    D, n, F, L = 40, 4, 16, 4096
+    heads, C = 8, 8 * D
+    k, v = rnd(n * F * L, C), rnd(n * F * L, C)
+    km = RowMap(F, n * F * L, L, L, F * L)
+    for n_loc in (4, 2, 1):
+        q = rnd(n_loc * F * L, C)
+        qm = RowMap(F, n_loc * F * L, L, L, F * L)
+        S_q, S_kv, G = n_loc * L, n * L, F
+        flops = 4.0 * G * S_q * S_kv * C
+        for rep in range(2):
+            us = graph_time(lambda: ops.flash_attn(q, k, v, qm, km, G, heads, S_q, S_kv), n=4)
+            wgs = heads * (S_q // 512) * G
+            print(f"D=40 G={G} q_len={S_q:5d} kv_len={S_kv}: {us:9.1f} us  {flops / us / 1e6:7.1f} TF/s  | {wgs} workgroups = {wgs / 256:.0f} rounds of 256: {us / (wgs / 256):7.1f} us per round", flush=True)
+
+
 def bench_flashdm(ops, scales=(1.0, 0.0, 3.0)):
     """Level-0 launch shape of BASELINE config 2 (32 groups x 8 heads x 16384 x 16384, head_dim 40): the LDS-DMA staged kernel (default), its exact
     pass alone and the generic kernel, interleaved rounds in one process.  Input scales: randn, zeros (clock ceiling), randn x 3 (peaky scores)."""
@@ -477,7 +495,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "flashdt": bench_flashdt, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "flashdt": bench_flashdt, "flashrank": bench_flashrank, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flashshort": lambda o: bench_flash(o, ((80, 4, 16, 256, 2), (80, 4, 16, 128, 2), (80, 4, 16, 512, 2), (80, 1, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 4, 16, 64, 2), (160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
          "flash40s": lambda o: bench_flash(o, ((40, 4, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 1, 16, 4096, 2))),
