@@ -257,6 +257,26 @@ def bench_smallm(ops):
         print(f"conv3x3 B={B:3d} {H}x{W} {Cin}->{Cout}: " + "  |  ".join(out), flush=True)
 
 
+def bench_shortk(ops):
+    """In-graph time of the short-K linears / GEGLU projections of levels 0 / 1 on the default dispatch (A/B of side builds: A3D_LIB=...)."""
+    import os
+    print(f"== short-K shapes, default dispatch, in-graph us / TFLOP/s  (library: {os.environ.get('A3D_LIB', 'shipped')})")
+    for (M, N, K, r, geglu) in [(524288, 960, 320, 0, 0), (524288, 1280, 320, 0, 0), (524288, 2560, 320, 0, 1), (524288, 320, 320, 1, 0), (524288, 320, 640, 1, 0),
+                                (524288, 320, 1280, 1, 0), (131072, 1920, 640, 0, 0), (131072, 5120, 640, 0, 1), (131072, 640, 640, 1, 0), (131072, 640, 2560, 1, 0),
+                                (32768, 3840, 1280, 0, 0), (32768, 10240, 1280, 0, 1), (32768, 1280, 5120, 1, 0)]:
+        x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, device="cuda")
+        res = rnd(M, N) if r else None
+        fl = 2.0 * M * N * K
+        if geglu:
+            wi, bi = ops.interleave_geglu(w), ops.interleave_geglu(bias)
+            fn = lambda: ops.gemm_geglu(x, wi, bi)
+        else:
+            fn = lambda: ops.gemm(x, w, bias, residual=res)
+        ts = [graph_time(fn, n=10) for _ in range(3)]
+        print(f"{'geglu' if geglu else 'gemm '} M={M:6d} N={N:5d} K={K:5d}{' +res' if r else '     '}: " + "  ".join(f"{t:7.1f}" for t in ts) + f" us   {fl / min(ts) / 1e6:7.1f} TF/s", flush=True)
+
+
 def bench_onewave(ops):
     """VERDICT r5 item 4b, first half: the one-wave-per-SIMD GEMM (gemm_ring.hip with 128 x 320 tiles: 256 threads, one wave per SIMD, serial
     epilogue) against the shipped two-waves-per-SIMD ping-pong kernel (256 x 320 tiles) on the epilogue-bound short-K shapes of level 0 / 1,
@@ -495,7 +515,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for w in which:
         {"flash": bench_flash, "vae": bench_vae, "loop": bench_loop, "graph": bench_graph, "gemm": bench_gemm, "conv": bench_conv, "misc": bench_misc,
-         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "directepi": bench_directepi, "flashspread": bench_flashspread, "flashdt": bench_flashdt, "flashrank": bench_flashrank, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
+         "flashdm": bench_flashdm, "smallm": bench_smallm, "gn": bench_gn, "onewave": bench_onewave, "shortk": bench_shortk, "directepi": bench_directepi, "flashspread": bench_flashspread, "flashdt": bench_flashdt, "flashrank": bench_flashrank, "gemmscale": bench_gemmscale, "gemmcal": bench_gemmcal, "wgrad": bench_wgrad, "attnbwd": bench_attnbwd, "flash16": bench_flash16,
          "flash40": lambda o: bench_flash(o, ((40, 4, 16, 4096, 2),)),
          "flashshort": lambda o: bench_flash(o, ((80, 4, 16, 256, 2), (80, 4, 16, 128, 2), (80, 4, 16, 512, 2), (80, 1, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 4, 16, 64, 2), (160, 4, 16, 256, 2), (160, 4, 16, 64, 2))),
          "flash40s": lambda o: bench_flash(o, ((40, 4, 16, 1024, 2), (40, 4, 16, 256, 2), (40, 1, 16, 4096, 2))),
