@@ -629,7 +629,16 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
       launch<80, 64, 1, OFS_ACC>(aligned, groups, s, p);
       break;
     case 64: launch<64, 64, 1, OFS_FMA>(aligned, groups, s, p); break;        // CLIP text tower (12 heads of 64)
-    case 160: launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p); break;
+    case 160:
+      // LDS-DMA staged kernel on eight waves (flash_attn_dm160.hip, round 6): 64-key tiles from 256 keys, both storage types
+      // (16-byte stores: O and its row pitch must be 16-byte multiples — the entry point itself only asks for 8)
+      if (!plain && !p.causal && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 128 && ((kmap->seg_len % 64 == 0) || (kv_len <= kmap->seg_len)) &&
+          (reinterpret_cast<uintptr_t>(O) & 15u) == 0 && omap->ld % 8 == 0) {
+        if (int rc = A3D_FN(a3d_launch_flash_dm160)(exact ? 0 : 1, groups, s, p)) return rc;
+        break;
+      }
+      launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p);
+      break;
     default: return A3D_EUNSUPPORTED;
   }
   return a3d_launch_status();

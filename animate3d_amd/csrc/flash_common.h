@@ -111,5 +111,6 @@ A3D_DEV uint32_t fa_lds_addr(const void* p) {
 // flash_attn_dm.hip / flash_attn_dm80.hip (one definition per storage type; internal to the library: hidden visibility)
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_flash_dm)(int flags, int groups, hipStream_t s, const AttnParams& p);
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_flash_dm80)(int flags, int groups, hipStream_t s, const AttnParams& p);
+__attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_flash_dm160)(int flags, int groups, hipStream_t s, const AttnParams& p);
 // cross_attn.hip: two short key sets (text + IP tokens), head_dim 40; A3D_EUNSUPPORTED = not this kernel's shape
 __attribute__((visibility("hidden"))) int A3D_FN(a3d_launch_cross_attn40)(int groups, hipStream_t s, const AttnParams& p);
