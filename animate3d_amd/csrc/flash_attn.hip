@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const AttnParams p) 
   }
   // ---- K/V staging: per-thread source pointers, advanced tile by tile
   const int64_t ld = kmp.ld;
-  const int64_t kgbase = (grp / kmp.gdiv) * kmp.ga + (grp % kmp.gdiv) * kmp.gb;
+  const int64_t kgbase = map_group_base(kmp, grp);
   const uint16_t* const Kh = Kp + hoff;
   const uint16_t* const Vh = Vp + hoff;
   const uint32_t seg_len = (uint32_t)kmp.seg_len;
@@ -630,6 +630,7 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
       break;
     case 64: launch<64, 64, 1, OFS_FMA>(aligned, groups, s, p); break;        // CLIP text tower (12 heads of 64)
     case 160:
+#ifndef A3D_EXP_R5_PATHS      // (measurement build: the generic kernel as in rounds 1-5)
       // LDS-DMA staged kernel on eight waves (flash_attn_dm160.hip, round 6): 64-key tiles from 256 keys, both storage types
       // (16-byte stores: O and its row pitch must be 16-byte multiples — the entry point itself only asks for 8)
       if (!plain && !p.causal && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 128 && ((kmap->seg_len % 64 == 0) || (kv_len <= kmap->seg_len)) &&
@@ -637,6 +638,7 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
         if (int rc = A3D_FN(a3d_launch_flash_dm160)(exact ? 0 : 1, groups, s, p)) return rc;
         break;
       }
+#endif
       launch<160, 32, 1, OFS_FMA>(aligned, groups, s, p);
       break;
     default: return A3D_EUNSUPPORTED;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
   // physical row (s - 320) / 5, which holds key 16 (r / 16) + 4 (r & 3) + ((r >> 2) & 3).  Wave w issues slots 64 w .. + 63
   // (instruction A: K for w < 5, V otherwise) and 512 + 16 w .. + 15 (instruction B, 16 lanes: V).
   const int64_t ld = p.km.ld;
-  const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
+  const int64_t kgbase = map_group_base(p.km, grp);
   const uint32_t seg_len = (uint32_t)p.km.seg_len;
   const int64_t tile_step = (int64_t)64 * ld;
   const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024 / QT, 4 / QT) void flash_attn_dm_kernel(const 
   if constexpr (DM_SAMPLED) {
     const int ss = (64 * w + lane) % 160;
     const int64_t key = (int64_t)(ss / 5) * (p.kv_len / 32);
-    voffS = (uint32_t)((((key / p.km.seg_len) * p.km.seg_stride + key % p.km.seg_len) * ld + (ss % 5) * 8) * 2);
+    voffS = (uint32_t)((map_seq(p.km, key) * ld + (ss % 5) * 8) * 2);
   }
   const uint64_t maskS = w < 2 ? ~0ull : (w == 2 ? 0xffffffffull : 0ull);
 

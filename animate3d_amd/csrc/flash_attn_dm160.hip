@@ -38,13 +38,18 @@ constexpr float F_L_HI = 1.2676506e30f;            // 2^100: beyond this the max
 constexpr float F_BIAS = F16_BIAS;
 constexpr bool F_SAMPLED = true;
 constexpr float F_L_LO = 1.220703125e-4f;          // 2^-13: a row sum below it has no normal fp16 P at all
-constexpr int F_SMEM_BYTES = F_SAMPLE + F_UNITB;
+constexpr int F_VOFF = F_SAMPLE + F_UNITB;
 #else
 constexpr float F_BIAS = 40.f;
 constexpr bool F_SAMPLED = false;
 constexpr float F_L_LO = 7.8886091e-31f;           // 2^-100
-constexpr int F_SMEM_BYTES = F_SAMPLE;
+constexpr int F_VOFF = F_SAMPLE;
 #endif
+// The five DMA source offsets of a lane live in LDS after the prologue ([instruction][thread], 10 KB), not in registers: the key loop runs at ~250
+// of its 256 registers, and a spilled offset comes back through scratch_load + s_waitcnt vmcnt(0) — i.e. behind the LDS-DMA pieces issued just
+// before it, a full memory round trip inside every iteration (measured: 1 097 -> 1 381 us at 4 096 keys when two of them spilled).  An LDS read
+// one pipeline slot ahead of its DMA instruction costs nothing.
+constexpr int F_SMEM_BYTES = F_VOFF + F_NDMA * 512 * 4;
 A3D_DEV int f_kswz(int row) { return (row >> 2) & 3; }      // K chunk swizzle of a row
 
 extern __shared__ __attribute__((aligned(16))) uint8_t f_smem[];
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
   // ---- DMA lanes.  Chunk slot s of a tile buffer (16 B at byte 16 s): s < 1280 is K row s / 20, position s % 20 = chunk ^ ((row >> 2) & 3);
   // s >= 1280 is V row (s - 1280) / 20, chunk (s - 1280) % 20.  Instruction i of wave w covers slots 64 (8 i + w) .. + 63: K for 8 i + w < 20.
   const int64_t ld = p.km.ld;
-  const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
+  const int64_t kgbase = map_group_base(p.km, grp);
   const uint32_t seg_len = (uint32_t)p.km.seg_len;
   const int64_t tile_step = (int64_t)64 * ld;
   const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;
@@ -84,6 +89,13 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
   uint32_t voff[NDMA];
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) voff[i] = slot_src(64 * (8 * i + w) + lane);
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) *reinterpret_cast<uint32_t*>(f_smem + F_VOFF + (i * 512 + tid) * 4) = voff[i];
+  // (the reader rebuilds its lane index from mbcnt instead of keeping a table address live: in the fp16 build that register was the next one spilled)
+  auto tab = [&](int I) __attribute__((always_inline)) -> uint32_t {
+    const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return *reinterpret_cast<const uint32_t*>(f_smem + (ln * 4u + (uint32_t)(F_VOFF + I * 2048 + w * 256)));
+  };
   // sample sub-tile (F_SAMPLED): slot s < 640 is chunk s % 20 (swizzled like every K row) of sample row s / 20 = key (s / 20) * (kv_len / 32);
   // instruction i of wave w covers slots 64 (8 i + w) ..: waves 0..7 one each, waves 0 and 1 a second one
   uint32_t voffS[2] = {0u, 0u};
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
     for (int i = 0; i < 2; ++i) {
       const int ss = (64 * (8 * i + w) + lane) % (32 * F_CPR), prow = ss / F_CPR;
       const int64_t key = (int64_t)prow * (p.kv_len / 32);
-      voffS[i] = (uint32_t)((((key / p.km.seg_len) * p.km.seg_stride + key % p.km.seg_len) * ld + ((ss % F_CPR) ^ f_kswz(prow)) * 8) * 2);
+      voffS[i] = (uint32_t)((map_seq(p.km, key) * ld + ((ss % F_CPR) ^ f_kswz(prow)) * 8) * 2);
     }
   }
 
@@ -115,10 +127,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
   };
   auto tile_base = [&](int tile) __attribute__((always_inline)) -> uint32_t { return (uint32_t)((tile % F_RING) * F_TILEB); };
   // instruction I of this wave's share of a tile; the last one moves the bases on
-  auto dma_i = [&](int tile, auto i_c) __attribute__((always_inline)) {
+  auto dma_i = [&](int tile, auto i_c, uint32_t vo) __attribute__((always_inline)) {
     constexpr int I = decltype(i_c)::value;
     const bool isk = 8 * I + w < F_CPR;               // wave-uniform
-    dm_glds16(voff[I], isk ? gK : gV, lds0 + tile_base(tile) + 1024u * (uint32_t)(8 * I + w));
+    dm_glds16(vo, isk ? gK : gV, lds0 + tile_base(tile) + 1024u * (uint32_t)(8 * I + w));
     if constexpr (I == NDMA - 1) {
       seg_off += 64;
       int64_t stp = tile_step;
@@ -126,8 +138,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
       gK += stp; gV += stp;
     }
   };
-  auto dma_tile = [&](int tile) __attribute__((always_inline)) {
-    static_for<NDMA>([&](auto i_c) __attribute__((always_inline)) { dma_i(tile, i_c); });
+  auto dma_tile = [&](int tile) __attribute__((always_inline)) {          // (offsets from the LDS table: written by this thread itself, no barrier needed)
+    static_for<NDMA>([&](auto i_c) __attribute__((always_inline)) { dma_i(tile, i_c, tab(decltype(i_c)::value)); });
   };
   // (sample sub-tile,) tiles 0 and 1: requested before anything else of the prologue — the Q rows are fetched under them —, complete for
   // everybody after prologue_wait
@@ -364,16 +376,17 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
     auto iteration = [&](int t, auto first_c, auto last_c, auto dma_c_) __attribute__((always_inline)) {
       constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value, DMA = decltype(dma_c_)::value;
       // tile t + 2 goes into the buffer tile t - 1 left at the barrier that ended the previous iteration
+      // (a lane's source offset is read from the LDS table one slot ahead of its DMA instruction)
+      [[maybe_unused]] uint32_t vo = 0u;
       auto even_hook = [&](auto s_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
-        if constexpr (DMA && s == 1) dma_i(t + 2, std::integral_constant<int, 0>{});
-        if constexpr (DMA && s == 4) dma_i(t + 2, std::integral_constant<int, 1>{});
-        if constexpr (DMA && s == 7) dma_i(t + 2, std::integral_constant<int, 2>{});
+        if constexpr (DMA && s % 3 == 0 && s < 9) vo = tab(s / 3);
+        if constexpr (DMA && s % 3 == 1 && s < 9) dma_i(t + 2, std::integral_constant<int, s / 3>{}, vo);
       };
       auto odd_hook = [&](auto s_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value;
-        if constexpr (DMA && s == 1) dma_i(t + 2, std::integral_constant<int, 3>{});
-        if constexpr (DMA && s == 4) dma_i(t + 2, std::integral_constant<int, 4>{});
+        if constexpr (DMA && s % 3 == 0 && s < 6) vo = tab(3 + s / 3);
+        if constexpr (DMA && s % 3 == 1 && s < 6) dma_i(t + 2, std::integral_constant<int, 3 + s / 3>{}, vo);
       };
       const uint32_t tb = tile_base(t), tn = tile_base(t + 1);
       // even step j = 2t:  O += V(t-1)[32..63] P(2t-1), S(2t+1) from K(t) keys 32..63, P(2t) from S(2t); reads V(t)[0..31]

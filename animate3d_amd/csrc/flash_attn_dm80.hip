@@ -42,6 +42,12 @@ constexpr float E_BIAS = 40.f;
 constexpr bool E_SAMPLED = false;
 #endif
 
+#ifdef A3D_EXP_R5_PATHS
+constexpr bool E_EARLY_DMA = false;      // measurement build: round 5's prologue order (Q rows first) and 8-byte stores, for the same-box A/B
+#else
+constexpr bool E_EARLY_DMA = true;
+#endif
+
 extern __shared__ __attribute__((aligned(16))) uint8_t e_smem[];
 A3D_DEV u32x4_t e_lds128(uint32_t off) { return *reinterpret_cast<const u32x4_t*>(e_smem + off); }
 A3D_DEV u32x2_t e_ldstr(uint32_t off) { return lds_tr16_b64(reinterpret_cast<const uint16_t*>(e_smem + off)); }
@@ -67,25 +73,11 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     reinterpret_cast<uint16_t*>(e_smem + E_CV)[i] = (vb == 0 || vb == 160 || vb == 2560 || vb == 2720) ? ONE16 : (uint16_t)0;
   }
 
-  // ---- Q^T fragments (pre-scaled by scale * log2 e)
-  const int q_idx = qt * BQ + wid * 32 + l31;
-  u32x4_t qf[KS];
-  {
-    const int64_t q_row = map_row(p.qm, grp, q_idx < p.q_len ? q_idx : p.q_len - 1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      u32x4_t wq = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + 16 * ks + 8 * g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wq[j] = pack16(lo16(wq[j]) * p.scale_log2, hi16(wq[j]) * p.scale_log2);
-      qf[ks] = wq;
-    }
-  }
-
   // ---- DMA lanes.  Chunk slot s of a tile buffer (16 B at byte 16 s): s < 640 is K row s / 10, position s % 10 = chunk ^ ((row >> 3) & 1);
   // s >= 640 is V physical row (s - 640) / 10, chunk (s - 640) % 10; physical row r holds key (r & ~7) | ((r & 7) >> 1) + 4 (r & 1).
   // Wave w issues slots 64 w .. (A: K), 512 + 64 w .. (B: K for w < 2, V otherwise), 1024 + 32 w .. + 31 (C, 32 lanes: V).
   const int64_t ld = p.km.ld;
-  const int64_t kgbase = (grp / p.km.gdiv) * p.km.ga + (grp % p.km.gdiv) * p.km.gb;
+  const int64_t kgbase = map_group_base(p.km, grp);
   const uint32_t seg_len = (uint32_t)p.km.seg_len;
   const int64_t tile_step = (int64_t)64 * ld;
   const int64_t wrap_step = (p.km.seg_stride - p.km.seg_len) * ld;
@@ -105,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
   if constexpr (E_SAMPLED) {
     const int ss = (64 * w + lane) % 320, prow = ss / 10;
     const int64_t key = (int64_t)prow * (p.kv_len / 32);
-    voffS = (uint32_t)((((key / p.km.seg_len) * p.km.seg_stride + key % p.km.seg_len) * ld + ((ss % 10) ^ ((prow >> 3) & 1)) * 8) * 2);
+    voffS = (uint32_t)((map_seq(p.km, key) * ld + ((ss % 10) ^ ((prow >> 3) & 1)) * 8) * 2);
   }
   const uint64_t maskS = w < 5 ? ~0ull : 0ull;
 
@@ -140,6 +132,33 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     if (seg_off >= seg_len) { stp += wrap_step; seg_off = 0; }
     gA += stp; gB += stp; gC += stp;
   };
+  // (sample sub-tile,) tiles 0, 1, 2: requested before anything else of the prologue (round 6: the Q rows are fetched under them; at 1 024 keys the
+  // prologue is a sixth of a workgroup's time); all but tile 2 complete for everybody after prologue_wait
+  auto prologue_issue = [&]() __attribute__((always_inline)) {
+    dma_reset();
+    if constexpr (E_SAMPLED && TRY_NOMAX)
+      dm_glds16_m(voffS, dm_scalar(p.K + hoff + kgbase * ld), lds0 + (uint32_t)(E_SAMPLE + 1024 * (w < 5 ? w : 0)), maskS);
+    dma_a(0); dma_b(0); dma_c(0);
+    dma_a(1); dma_b(1); dma_c(1);
+    dma_a(2); dma_b(2); dma_c(2);
+  };
+  auto prologue_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory"); };
+  if constexpr (E_EARLY_DMA) prologue_issue();
+
+  // ---- Q^T fragments (pre-scaled by scale * log2 e)
+  const int q_idx = qt * BQ + wid * 32 + l31;
+  u32x4_t qf[KS];
+  {
+    const int64_t q_row = map_row(p.qm, grp, q_idx < p.q_len ? q_idx : p.q_len - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4_t wq = *reinterpret_cast<const u32x4_t*>(p.Q + q_row * p.qm.ld + hoff + 16 * ks + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wq[j] = pack16(lo16(wq[j]) * p.scale_log2, hi16(wq[j]) * p.scale_log2);
+      qf[ks] = wq;
+    }
+  }
+
 
   f32x16_t oacc[MT];
   f32x16_t minit;             // -offset in every element: C operand of the first QK^T MFMA
@@ -173,15 +192,6 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
     for (int r = 0; r < 16; ++r) minit[r] = 0.f;
   };
   const int nt = p.kv_len / 64;               // launcher guarantees kv_len % 64 == 0, nt >= 4, aligned segments
-  auto prologue_dma = [&]() __attribute__((always_inline)) {      // (sample sub-tile,) tiles 0, 1, 2 requested; all but tile 2 complete
-    dma_reset();
-    if constexpr (E_SAMPLED && TRY_NOMAX)
-      dm_glds16_m(voffS, dm_scalar(p.K + hoff + kgbase * ld), lds0 + (uint32_t)(E_SAMPLE + 1024 * (w < 5 ? w : 0)), maskS);
-    dma_a(0); dma_b(0); dma_c(0);
-    dma_a(1); dma_b(1); dma_c(1);
-    dma_a(2); dma_b(2); dma_c(2);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NDMA) : "memory");
-  };
   // first offset: exact maximum of the query's first 32 scores (+ bias); leaves the re-based scores in s
   auto first_scores = [&](f32x16_t& s, float& m_off, float bias, uint32_t koff = 0u) __attribute__((always_inline)) -> bool {
     read_k(koff);
@@ -220,25 +230,47 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
       p.lse[((int64_t)grp * p.heads + head) * p.q_len + q_idx] = __builtin_amdgcn_logf(l_tot) - minit[0];
     if (q_idx < p.q_len) {      // lane holds O[q = l31][d = 32*mt + 8*qd + 4*g + j]
       uint16_t* orow = p.O + map_row(p.om, grp, q_idx) * p.om.ld + hoff;
+      const bool wide_rows = E_EARLY_DMA && !p.accumulate && ((reinterpret_cast<uintptr_t>(p.O) | (uintptr_t)(p.om.ld * 2)) & 15u) == 0;      // (workgroup-uniform)
+      if (wide_rows) {
+        // round 6: the two halves of a wave hold alternate 4-dim groups of one row; one v_permlane32_swap per packed word hands each half 8
+        // CONSECUTIVE dims of two groups: five 16-byte stores per lane instead of ten 8-byte ones (the store tail is issue-bound)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int d = 32 * mt + 8 * qd + 4 * g;
-          if (d < D) {
-            float v[4];
+          for (int pr = 0; pr < 2; ++pr) {
+            if (32 * mt + 16 * pr >= D) continue;
+            u32x4_t v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = oacc[mt][4 * qd + j] * inv;
-            if (p.accumulate) {
-              const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
-              v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
+            for (int c = 0; c < 2; ++c) {
+              const uint32_t w0 = pack16(oacc[mt][8 * pr + 2 * c] * inv, oacc[mt][8 * pr + 2 * c + 1] * inv);
+              const uint32_t w1 = pack16(oacc[mt][8 * pr + 4 + 2 * c] * inv, oacc[mt][8 * pr + 4 + 2 * c + 1] * inv);
+              const auto r = __builtin_amdgcn_permlane32_swap(w0, w1, false, false);
+              v[c] = r[0];
+              v[2 + c] = r[1];
             }
-            u32x2_t o;
-            o[0] = pack16(v[0], v[1]);
-            o[1] = pack16(v[2], v[3]);
-            *reinterpret_cast<u32x2_t*>(orow + d) = o;
+            *reinterpret_cast<u32x4_t*>(orow + 32 * mt + 16 * pr + 8 * g) = v;
           }
-        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int d = 32 * mt + 8 * qd + 4 * g;
+            if (d < D) {
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = oacc[mt][4 * qd + j] * inv;
+              if (p.accumulate) {
+                const u32x2_t prev = *reinterpret_cast<const u32x2_t*>(orow + d);
+                v[0] += lo16(prev[0]); v[1] += hi16(prev[0]); v[2] += lo16(prev[1]); v[3] += hi16(prev[1]);
+              }
+              u32x2_t o;
+              o[0] = pack16(v[0], v[1]);
+              o[1] = pack16(v[2], v[3]);
+              *reinterpret_cast<u32x2_t*>(orow + d) = o;
+            }
+          }
+      }
     }
     return true;
   };
@@ -299,7 +331,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
       }
     };
 
-    prologue_dma();
+    if constexpr (!E_EARLY_DMA) prologue_issue();
+    prologue_wait();
     {
       float m_off;
       if constexpr (E_SAMPLED) {
@@ -356,11 +389,12 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
   // ================================================================================================================
   // Exact pass: lazy running maximum per 32-key sub-tile, un-pipelined (after an overflow of the max-free pass, or always)
   // ================================================================================================================
-  auto run_exact = [&]() __attribute__((always_inline)) {
+  auto run_exact = [&](auto rerun_c) __attribute__((always_inline)) {
     clear_o();
     float m_off;
     f32x16_t sc;
-    prologue_dma();
+    if constexpr (decltype(rerun_c)::value || !E_EARLY_DMA) prologue_issue();      // (every wave has left the LDS images: the vote / the row-sum check were barriers)
+    prologue_wait();
     first_scores(sc, m_off, 0.f);
     for (int t = 0; t < nt; ++t) {
       const bool more = t + 3 < nt;
@@ -408,9 +442,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm80_kernel(const AttnParam
   __syncthreads();        // constant region written
   dm_count(p, 2);
   if constexpr (TRY_NOMAX) {
-    if (!run_fast()) run_exact();
+    if (!run_fast()) run_exact(std::true_type{});
   } else {
-    run_exact();
+    run_exact(std::false_type{});
   }
 }
 

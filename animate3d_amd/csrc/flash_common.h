@@ -30,9 +30,19 @@ constexpr int OFS_FMA = 0, OFS_PAD = 1, OFS_ACC = 2;
 constexpr float LAZY_THR = 6.0f;     // log2 units: P may reach 2^6 before the offset moves
 
 
-A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) {
-  return (g / m.gdiv) * m.ga + (g % m.gdiv) * m.gb + (s / m.seg_len) * m.seg_stride + (s % m.seg_len);
+// Row maps in 32-bit arithmetic: groups (<= 65 535) and sequence positions (< 2^30) are checked by the entry points; a divisor beyond 2^31 is
+// larger than any dividend, so clamping it leaves quotient 0 / remainder = dividend.  (A 64-bit division is a ~100-instruction routine on
+// this chip and every workgroup's prologue had five to seven of them: ~1 us of a 25-50 us workgroup at 1 024 keys.)
+A3D_DEV uint32_t map_clamp32(int64_t d) { return d > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)d; }
+A3D_DEV int64_t map_group_base(const a3d_rowmap& m, int64_t g) {
+  const uint32_t g32 = (uint32_t)g, gd = map_clamp32(m.gdiv), gq = g32 / gd, gr = g32 - gq * gd;
+  return (int64_t)gq * m.ga + (int64_t)gr * m.gb;
 }
+A3D_DEV int64_t map_seq(const a3d_rowmap& m, int64_t s) {      // row of sequence position s relative to its group's base
+  const uint32_t s32 = (uint32_t)s, sl = map_clamp32(m.seg_len), sq = s32 / sl, sr = s32 - sq * sl;
+  return (int64_t)sq * m.seg_stride + (int64_t)sr;
+}
+A3D_DEV int64_t map_row(const a3d_rowmap& m, int64_t g, int64_t s) { return map_group_base(m, g) + map_seq(m, s); }
 
 // K row (within a 32-row sub-tile) that feeds MFMA A-row i: chosen so that result register r of a
 // lane in half g is key 16*(r>>3) + 8*g + (r&7).
