@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
     // Step j (20 slots of one MFMA each): slots 0..9: O += V^T(j-1)·P(j-1) (fragments read during step j-1), slots 10..19: S(j+1) = K(j+1)·Q^T;
     // the VALU turns S(j) (sCur) into P(j) (pCur) over all slots.  kOff / vOff: LDS byte offsets of K sub-tile j+1 and V sub-tile j.
     // K fragment ks is read in slot 5 + ks (five slots ahead of its MFMA), V^T fragment i of sub-tile j in slot 10 + i (consumed in slot i of step j+1).
-    // A step without the P·V block (the very first) finds its K fragments read already; one without the QK block (the very last) reads no V.
+    // A step without the P·V block (the very first) finds its first five K fragments read already; one without the QK block (the very last) reads no V.
     auto step = [&](auto do_qk_c, auto do_pv_c, f32x16_t& sCur, f32x16_t& sNext, u32x4_t (&pCur)[2], u32x4_t (&pPrev)[2],
                     uint32_t kOff, uint32_t vOff, auto&& hook) __attribute__((always_inline)) {
       constexpr bool DO_QK = decltype(do_qk_c)::value, DO_PV = decltype(do_pv_c)::value;
@@ -335,8 +335,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
             sNext = mfma32(kf[ks], qf[ks], sNext);
           }
         }
-        if constexpr (DO_QK && DO_PV) {
-          if constexpr (s >= NPV - KAHEAD && s - (NPV - KAHEAD) < KS) read_k1(std::integral_constant<int, s - (NPV - KAHEAD)>{}, ke, ko);
+        if constexpr (DO_QK) {          // (a step without the P·V block finds fragments 0 .. KAHEAD-1 read already)
+          constexpr int ks_rd = s - (NPV - KAHEAD);
+          if constexpr (ks_rd >= (DO_PV ? 0 : KAHEAD) && ks_rd < KS) read_k1(std::integral_constant<int, ks_rd>{}, ke, ko);
         }
         if constexpr (DO_QK && s >= NPV) read_v1(std::integral_constant<int, s - NPV>{}, va);
         hook(s_c);
@@ -370,7 +371,11 @@ __global__ __launch_bounds__(512, 2) void flash_attn_dm160_kernel(const AttnPara
       } else {
         first_scores(sA, F_BIAS, 0u);
       }
-      read_k((uint32_t)F_UNITB);               // K(0) keys 32..63 for step 0
+      {                                        // K(0) keys 32..63 for step 0: its first five fragments (the step reads the others itself)
+        uint32_t ke = kc_even + (uint32_t)F_UNITB, ko = kc_odd + (uint32_t)F_UNITB;
+        asm volatile("" : "+v"(ke), "+v"(ko));
+        static_for<5>([&](auto ks_c) __attribute__((always_inline)) { read_k1(ks_c, ke, ko); });
+      }
     }
 
     auto iteration = [&](int t, auto first_c, auto last_c, auto dma_c_) __attribute__((always_inline)) {
