@@ -103,10 +103,10 @@ def test_level1_launch_shape_head_dim_80(dtype, tol, gain):
 @pytest.mark.parametrize("L", [256, 64])
 def test_level2_launch_shape_head_dim_160(dtype, tol, gain, L):
     """Level 2 of BASELINE config 2: 4 views x L = 256 tokens = 1 024 x 1 024 per group, 8 heads, head_dim 160, two groups, and L = 64
-    (level 3: 256 keys) — the launch shapes of the generic kernel (flash_attn_kernel<160, 32, 1, OFS_FMA>) in the benchmark, which the
-    small kernel tests only reach with random data: spikes at keys 191 / 192 (or 127 / 128), in the last tile and in the last key; gain 11 =
-    ~200 log2 units above the bulk (the lazy running maximum has to move by that much mid-row).  Round 5 measured a one-wave-per-SIMD
-    LDS-DMA kernel at these shapes against it — equal at 1 024 keys, +10 % at 2 048, not shipped (profiles/r5_flash_dw160_one_wave_per_simd.patch)."""
+    (level 3: 256 keys) — since round 6 the launch shapes of flash_attn_dm160_kernel (LDS-DMA staged, eight waves; `plain` = the generic kernel
+    flash_attn_kernel<160, 32, 1, OFS_FMA> that served them in rounds 1-5), which the small kernel tests only reach with random data: spikes at keys 191 / 192 (or 127 / 128), in the last tile and in the last key; gain 11 =
+    ~200 log2 units above the bulk (the max-free pass overflows and the workgroup re-runs exactly; in the generic kernel the lazy running
+    maximum has to move by that much mid-row)."""
     ops = _ops(dtype)
     heads, S, q, k, v, qm, k0 = _case(dtype, 160, 4, 2, L, 192 if L == 256 else 128, gain if gain < 10 else (1.0, 1.25, gain, 1.5))
     for km, name in ((qm, "multi-view"), (k0, "first-frame")):
