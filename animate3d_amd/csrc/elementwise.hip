@@ -230,7 +230,7 @@ extern "C" int a3d_channel_mix_f32(a3d_stream_t stream, const float* X, const fl
 #endif
 
 #ifndef A3D_STORAGE_F16
-extern "C" const char* a3d_version(void) { return "animate3d_hip gfx950 r5 (bf16 + fp16 storage)"; }
+extern "C" const char* a3d_version(void) { return "animate3d_hip gfx950 r6 (bf16 + fp16 storage)"; }
 #endif
 
 extern "C" int A3D_FN(a3d_geglu)(a3d_stream_t stream, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t M, int64_t N) {
