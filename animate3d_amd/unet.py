@@ -73,6 +73,8 @@ class MVUNetMotionModel(nn.Module):
         self._pack_grad = False             # True while _pack_train re-packs trainable sub-modules under autograd
         self._train_ops = None              # AutogradOps over the op set once enable_training() was called
         self._active_ops = None
+        self._cond = None                   # inference: the stacked conditioning projections of the running forward (_project_conditioning)
+        self.stack_conditioning = True      # False: one projection per layer, as in rounds 1-5 (same-box A/B of the stacking)
         self._pe_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.parallel = None                # set by animate3d_amd.parallel.shard_unet
         self._frames = (0, 0)               # (frames of the call, first frame of this rank): set by forward
@@ -600,8 +602,61 @@ class MVUNetMotionModel(nn.Module):
         P.up = [self._pack_block(b) for b in self.up_blocks]
         P.norm_out = (self._f(self.conv_norm_out.weight), self._f(self.conv_norm_out.bias))
         P.conv_out = (self._conv_w(self.conv_out), self._f(self.conv_out.bias))
+        P.cond = self._pack_conditioning(P)
         self._packed = P
         return P
+
+    def _pack_conditioning(self, P):
+        """Round 6.  The projections that see only the conditioning — ``time_emb_proj`` of the 22 ResNets (rows: SiLU(temb) per video),
+        ``to_k | to_v`` of the 16 text cross-attentions and of their IP-adapter image tokens (unet_motion_mv_model.py:754-764 hands every
+        block the same tokens) — stacked row-wise into three operands: three GEMMs per forward instead of 54 launches of one or a few tile
+        rows each (15-30 us apiece, the latency of their K loops: ~1.3 ms of a 70-ms 4D-SDS step or rank step).  Every layer pack gets its
+        row offset; the per-layer operands stay (training packs and the differentiable path use them)."""
+        blocks = [*P.down, P.mid, *P.up]
+        res = [r for b in blocks for r in b.resnets]
+        t2d = [t for b in blocks if b.t2d is not None for t in b.t2d]
+        c = SimpleNamespace(temb=None, kv_text=None, kv_ip=None, perm={}, widths=[r.temb[0].shape[0] for r in res])
+        if res:
+            off = 0
+            for r in res:
+                r.temb_off = (off, r.temb[0].shape[0])
+                off += r.temb[0].shape[0]
+            c.temb = (torch.cat([r.temb[0] for r in res], 0).contiguous(), torch.cat([r.temb[1] for r in res], 0).contiguous(), off)
+        if t2d:
+            off = 0
+            for t in t2d:
+                t.kv_off = (off, t.kv_text.shape[0])
+                off += t.kv_text.shape[0]
+            c.kv_text = torch.cat([t.kv_text for t in t2d], 0).contiguous()
+            if all(len(t.kv_ip) == 1 and t.kv_ip[0].shape[0] == t.kv_text.shape[0] for t in t2d):
+                c.kv_ip = torch.cat([t.kv_ip[0] for t in t2d], 0).contiguous()
+        return c
+
+    def _project_conditioning(self, c, semb, text_rows, ip_rows):
+        """The three stacked projections of one forward (see _pack_conditioning).  The time projections are consumed as per-layer
+        [rows, N] row-bias matrices of the first convolution (contiguous: a3d_conv3x3's rowbias has no row pitch), so the [rows, sum N]
+        product is regrouped into consecutive [rows, N_i] blocks by one gather; the K | V products are read in place (column views)."""
+        ops = self.ops
+        out = SimpleNamespace(tp=None, M=0, kvt=None, kvi=None)
+        if c.temb is not None:
+            M = semb.shape[0]
+            perm = c.perm.get(M)
+            if perm is None:
+                total = c.temb[2]
+                idx = torch.arange(M * total, device=semb.device).view(M, total)
+                parts, off = [], 0
+                for w in c.widths:
+                    parts.append(idx[:, off:off + w].reshape(-1))
+                    off += w
+                perm = c.perm[M] = torch.cat(parts).contiguous()
+            out.tp = ops.gemm(semb, c.temb[0], c.temb[1]).reshape(-1).index_select(0, perm)
+            out.M = M
+        if c.kv_text is not None:
+            out.kvt = ops.gemm(text_rows, c.kv_text)
+            if c.kv_ip is not None and len(ip_rows) == 1:
+                out.kvi = ops.gemm(ip_rows[0], c.kv_ip)
+        return out
+
 
     def _pe_spatial(self, C: int, h: int, w: int) -> torch.Tensor:
         """2-D sine PE table [h*w, C] for one level (embeddings.py:59-96), cached per geometry."""
@@ -666,7 +721,12 @@ class MVUNetMotionModel(nn.Module):
                 h = ops.group_norm2(xa, xb, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
         else:
             h = ops.group_norm(x, B2, L, pk.n1[0], pk.n1[1], g, pk.eps, True)
-        tp = ops.gemm(semb, pk.temb[0], pk.temb[1])                       # time_emb_proj(SiLU(temb))
+        c = self._cond
+        if c is not None and c.tp is not None and hasattr(pk, "temb_off"):       # inference: one stacked projection per forward
+            o, N = pk.temb_off
+            tp = c.tp[c.M * o: c.M * (o + N)].view(c.M, N)
+        else:
+            tp = ops.gemm(semb, pk.temb[0], pk.temb[1])                   # time_emb_proj(SiLU(temb))
         h, _, _ = ops.conv3x3(h, B2, H, W, pk.c1[0], pk.c1[1], rowbias=tp, rb_div=rb_rows * L)
         h = ops.group_norm(h, B2, L, pk.n2[0], pk.n2[1], g, pk.eps, True)
         if sc is None:
@@ -772,12 +832,13 @@ class MVUNetMotionModel(nn.Module):
         ops = self.ops
         C = n2.shape[1]
         q2 = ops.gemm(n2, pk.q2)
-        kvt = ops.gemm(text_rows, pk.kv_text)
+        c = self._cond if hasattr(pk, "kv_off") else None
+        kvt = c.kvt[:, pk.kv_off[0]: pk.kv_off[0] + 2 * C] if c is not None and c.kvt is not None else ops.gemm(text_rows, pk.kv_text)
         qc = RowMap(gdiv=1, ga=L, gb=0, seg_len=L, seg_stride=0)
         ca = None
         fused = getattr(ops, "flash_attn2", None)
         if fused is not None and len(ip_rows) == 1:          # one adapter (the released configuration): text + image tokens in one launch
-            kvi = ops.gemm(ip_rows[0], pk.kv_ip[0])
+            kvi = c.kvi[:, pk.kv_off[0]: pk.kv_off[0] + 2 * C] if c is not None and c.kvi is not None else ops.gemm(ip_rows[0], pk.kv_ip[0])
             nt = pk.ip_tokens[0]
             ca = fused(q2, kvt[:, :C], kvt[:, C:], kvi[:, :C], kvi[:, C:], qc, RowMap(F, T, 0, T, 0), RowMap(F, nt, 0, nt, 0), B2, pk.heads,
                        L, T, nt, out_scale2=pk.ip_scale[0])
@@ -1053,7 +1114,10 @@ class MVUNetMotionModel(nn.Module):
             finally:
                 self._active_ops = None
         with torch.no_grad():
-            return self._forward_impl(sample, timestep, encoder_hidden_states, packed=None, **kw)
+            try:
+                return self._forward_impl(sample, timestep, encoder_hidden_states, packed=None, **kw)
+            finally:
+                self._cond = None          # (layer methods called on their own, e.g. by the per-block tests, project per layer)
 
     def _reject_attention_mask(self, attention_mask, sample, num_views):
         """``attention_mask`` (:639, 700-703, 778-841) cannot be honoured — by the reference either.  It becomes an additive bias
@@ -1178,6 +1242,11 @@ class MVUNetMotionModel(nn.Module):
             img = img_embeds.to(device=dev, dtype=adt).reshape(V, -1).contiguous()
             pr = ops.gemm(img, P.ip[0], P.ip[1]).reshape(V * cfg.ip_num_tokens, cfg.cross_attention_dim)
             ip_rows.append(ops.layer_norm(pr, P.ip[2], P.ip[3], P.ip[4]))
+
+        # (inference: the conditioning-only projections of all layers in three GEMMs, _pack_conditioning)
+        self._cond = None
+        if self.stack_conditioning and self._active_ops is None and getattr(P, "cond", None) is not None and P is self._packed:
+            self._cond = self._project_conditioning(P.cond, semb, text_rows, ip_rows)
 
         # 3. conv_in over im2col patches; from here on x is [(V F) h w, C] rows
         x = ops.gemm(ops.im2col_in(sample), P.conv_in[0], P.conv_in[1])

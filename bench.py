@@ -362,6 +362,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="also time the same steps replayed from a HIP graph (capture_graph)")
     ap.add_argument("--shapes", action="store_true", help="print the instrumented forward per op shape on stderr (top 90 by time)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (default: picked by a short GEMM probe)")
+    ap.add_argument("--per-layer-conditioning", action="store_true", help="A/B: project the time embedding / text / IP tokens once per layer (54 small GEMMs, "
+                    "rounds 1-5) instead of stacked (3 GEMMs, MVUNetMotionModel.stack_conditioning)")
     ap.add_argument("--no-box", action="store_true", help="skip the box calibration kernels behind the 'box' object")
     ap.add_argument("--gather-kv", action="store_true", help="sharded / --rank-shape runs: all-gather the projected K|V (2C wide) instead of the attention's "
                     "input tokens (C wide, K|V projected locally for all views): ShardPlan.gather_tokens = False")
@@ -415,6 +417,7 @@ def main():
     model = MVUNetMotionModel(cfg, ops=ops, num_views=n, device=dev)
     model.init_synthetic(seed=0)
     model = model.to(torch_dtype).eval()
+    model.stack_conditioning = not args.per_layer_conditioning
     assert model.ops.act_dtype == torch_dtype
     dom_kernel = DOMINANT_KERNEL[dtype_name]
     par = rpar = None
