@@ -188,3 +188,33 @@ def test_fp16_window_follows_the_sample_spread(D, S, sd):
     print(f"[parity] fp16 D={D} S={S} score sd {sd}: rel L2 {err:.3e}, worst row {worst:.3e}; workgroups {launched}, voted exact {voted}, re-ran {rerun}")
     assert torch.isfinite(got).all() and err <= 1.5e-3 and worst <= 0.05, (err, worst)
     assert launched > 0 and voted == 0 and rerun * 20 <= launched, (launched, voted, rerun)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-3), (torch.float16, 1.5e-3)])
+def test_head_dim_160_staged_kernel_off_the_square_shapes(dtype, tol):
+    """flash_attn_dm160_kernel (round 6) away from the benchmark's square launches: what a view-sharded rank sees — the queries of ONE view
+    against the gathered keys of all four (q_len 384 != kv_len 1 536, so the second 256-query tile is half empty and the key segments wrap
+    inside the gathered buffer) —, and the accumulating epilogue (out_scale 0.5 into an existing buffer: the 8-byte read-modify-write path
+    instead of the 16-byte stores)."""
+    ops = _ops(dtype)
+    D, heads, n, F, L = 160, 8, 4, 2, 384
+    C = heads * D
+    g = torch.Generator(device="cuda").manual_seed(160)
+    q = torch.randn(F * L, C, generator=g, device="cuda").to(dtype)                       # one view's rows: (f, token)
+    kv = torch.randn(n * F * L, 2 * C, generator=g, device="cuda").to(dtype)              # gathered K | V of all views: (view, f, token)
+    k, v = kv[:, :C], kv[:, C:]
+    qm = RowMap(F, F * L, L, L, F * L)
+    km = RowMap(F, n * F * L, L, L, F * L)
+    want = chunked_attention_fp32(q, k, v, qm, km, F, heads, L, n * L)
+    got = ops.flash_attn(q, k, v, qm, km, F, heads, L, n * L).float()
+    plain = ops.flash_attn(q, k, v, qm, km, F, heads, L, n * L, plain=True).float()
+    err = ((got - want).norm() / want.norm()).item()
+    worst = ((got - want).norm(dim=1) / (want.norm(dim=1) + 1e-6)).max().item()
+    print(f"[parity] head_dim 160, 384 queries x 1 536 gathered keys {dtype}: rel L2 {err:.3e} (generic kernel {((plain - want).norm() / want.norm()).item():.3e}), worst row {worst:.3e}")
+    assert torch.isfinite(got).all() and err <= tol and worst <= 0.05, (err, worst)
+    base = torch.randn(F * L, C, generator=g, device="cuda").to(dtype)
+    acc = ops.flash_attn(q, k, v, qm, km, F, heads, L, n * L, out=base.clone(), out_scale=0.5, accumulate=True).float()
+    want_acc = base.float() + 0.5 * want
+    err_acc = ((acc - want_acc).norm() / want_acc.norm()).item()
+    print(f"[parity] head_dim 160 accumulate, out_scale 0.5 {dtype}: rel L2 {err_acc:.3e}")
+    assert err_acc <= (4e-3 if dtype == torch.bfloat16 else 1.5e-3), err_acc

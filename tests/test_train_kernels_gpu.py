@@ -83,9 +83,9 @@ def _lse_reference(q, k, qmap, kmap, groups, heads, q_len, kv_len):
     return out
 
 
-@pytest.mark.parametrize("C,n,F,L", [(320, 4, 2, 256), (320, 2, 2, 96), (640, 4, 2, 256), (640, 2, 3, 40), (1280, 3, 2, 16), (1280, 2, 2, 64)])
+@pytest.mark.parametrize("C,n,F,L", [(320, 4, 2, 256), (320, 2, 2, 96), (640, 4, 2, 256), (640, 2, 3, 40), (1280, 3, 2, 16), (1280, 2, 2, 64), (1280, 4, 2, 64)])
 def test_flash_attn_log_sum_exp_feeds_the_backward(ops, ref, C, n, F, L):
-    """a3d_flash_attn_lse (every kernel that serves the training shapes: the LDS-DMA kernels at head_dim 40 / 80 from 256 / 512 keys,
+    """a3d_flash_attn_lse (every kernel that serves the training shapes: the LDS-DMA kernels at head_dim 40 / 80 / 160 from 256 / 512 / 256 keys,
     the plain kernel elsewhere) returns the log2 softmax denominator per query; with it and a3d_attn_delta (rowsum(dO * O) per head)
     a3d_flash_attn_bwd skips its statistics pass: same gradients as the recomputing path, multi-view and first-frame maps."""
     dt, b, heads = ops.act_dtype, 2, 8
