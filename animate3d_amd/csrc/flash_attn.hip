@@ -633,7 +633,9 @@ static int flash_attn_impl(a3d_stream_t stream, const void* Q, const void* K, co
 #ifndef A3D_EXP_R5_PATHS      // (measurement build: the generic kernel as in rounds 1-5)
       // LDS-DMA staged kernel on eight waves (flash_attn_dm160.hip, round 6): 64-key tiles from 256 keys, both storage types
       // (16-byte stores: O and its row pitch must be 16-byte multiples — the entry point itself only asks for 8)
-      if (!plain && !p.causal && kv_len % 64 == 0 && kv_len >= 256 && q_len >= 128 && ((kmap->seg_len % 64 == 0) || (kv_len <= kmap->seg_len)) &&
+      // (no lower bound on q_len: the choice must depend on the KEY side only — a view-sharded rank sees a quarter of the queries against the same gathered
+      // keys, 64 at level 3, and has to reproduce the unsharded launch bit for bit; a workgroup with few valid queries costs what any workgroup costs)
+      if (!plain && !p.causal && kv_len % 64 == 0 && kv_len >= 256 && ((kmap->seg_len % 64 == 0) || (kv_len <= kmap->seg_len)) &&
           (reinterpret_cast<uintptr_t>(O) & 15u) == 0 && omap->ld % 8 == 0) {
         if (int rc = A3D_FN(a3d_launch_flash_dm160)(exact ? 0 : 1, groups, s, p)) return rc;
         break;

@@ -1,4 +1,4 @@
-// Level-2 / level-3 multi-view and first-frame attention (head_dim 160, aligned K/V from 256 keys): the LDS-DMA design of
+// Level-2 / level-3 multi-view and first-frame attention (head_dim 160, aligned K/V from 256 keys, any number of queries): the LDS-DMA design of
 // flash_attn_dm80.hip — global_load_lds staging, PV-first software pipeline, max-free 16-bit softmax with an exact re-run — at head_dim 160,
 // on EIGHT waves (two per SIMD, 256 registers each).  Replaces xformers.ops.memory_efficient_attention at attention_processor.py:405, 416,
 // 656 for the 1 024-key level-2 shapes, which ran on the generic register-staged kernel (flash_attn.hip) at 0.22 of the matrix peak for six
